@@ -1,0 +1,89 @@
+"""ctypes binding of the C ABI (include/cvxpnpl_amd.h).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` /
+``python -m cvxpnpl_amd.build``.  There is NO CPU fallback: if the library is missing,
+or no GPU is visible, the solver entry points raise.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcvxpnpl_amd.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+# every symbol include/cvxpnpl_amd.h declares
+EXPORTS = (
+    "cvxpnpl_default_opts", "cvxpnpl_solve_batch", "cvxpnpl_recover_multi", "cvxpnpl_assemble_batch",
+    "cvxpnpl_event_create", "cvxpnpl_event_record", "cvxpnpl_event_elapsed_ms", "cvxpnpl_event_destroy",
+    "cvxpnpl_last_error", "cvxpnpl_version", "cvxpnpl_device_count",
+)
+
+STATUS_NAMES = {0: "certified", 1: "rank>1", 2: "uncertified", 3: "nonfinite", 4: "reflection"}
+
+
+class Opts(C.Structure):
+    """cvxpnpl_opts_t"""
+    _fields_ = [
+        ("eps", C.c_double), ("max_iters", C.c_int32), ("rho", C.c_double), ("alpha", C.c_double),
+        ("first_check", C.c_int32), ("check_every", C.c_int32), ("res_tol", C.c_double),
+        ("jacobi_sweeps", C.c_int32), ("layout", C.c_int32),
+    ]
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libcvxpnpl_amd.so (loudly)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `python -m cvxpnpl_amd.build`). "
+            "cvxpnpl_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.cvxpnpl_default_opts.argtypes = [C.POINTER(Opts)]
+    L.cvxpnpl_default_opts.restype = None
+    L.cvxpnpl_solve_batch.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_int32, C.POINTER(Opts), C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cvxpnpl_solve_batch.restype = C.c_int
+    L.cvxpnpl_assemble_batch.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cvxpnpl_assemble_batch.restype = C.c_int
+    L.cvxpnpl_recover_multi.argtypes = [_dp, _dp, _dp, _dp]
+    L.cvxpnpl_recover_multi.restype = C.c_int
+    L.cvxpnpl_event_create.restype = C.c_void_p
+    L.cvxpnpl_event_record.argtypes = [C.c_void_p, C.c_void_p]
+    L.cvxpnpl_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+    L.cvxpnpl_event_destroy.argtypes = [C.c_void_p]
+    L.cvxpnpl_event_destroy.restype = None
+    L.cvxpnpl_last_error.restype = C.c_char_p
+    L.cvxpnpl_version.restype = C.c_char_p
+    L.cvxpnpl_device_count.restype = C.c_int
+    _lib = L
+    return L
+
+
+def default_opts(**overrides):
+    o = Opts()
+    lib().cvxpnpl_default_opts(C.byref(o))
+    for k, v in overrides.items():
+        if v is None:
+            continue
+        if not hasattr(o, k):
+            raise TypeError(f"unknown solver option {k!r}")
+        setattr(o, k, v)
+    return o
+
+
+def last_error():
+    return lib().cvxpnpl_last_error().decode()

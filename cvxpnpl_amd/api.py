@@ -1,0 +1,190 @@
+"""Host side of the drop-in boundary: cvxpnpl's pnp / pnl / pnpl and batched variants.
+
+Signatures, defaults, return type and warning / NaN behaviour of the three public functions
+follow the reference (cvxpnpl.py:523-530, :555-562, :586-595, :493-498, :516-519).  The
+arithmetic runs in the HIP library (include/cvxpnpl_amd.h) on the current torch device;
+PyTorch is used for device memory and streams only.
+"""
+import ctypes as C
+import warnings
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+__all__ = ["pnp", "pnl", "pnpl", "pnp_batch", "pnl_batch", "pnpl_batch", "BatchResult"]
+
+
+class BatchResult(dict):
+    """R [B,3,3], t [B,3], status [B] int32, iters [B] int32, cost [B,2] (||Ar||^2, dobj),
+    work [B,2] (rank, sweeps) and optionally Z [B,55]; torch tensors on the input device."""
+    __getattr__ = dict.__getitem__
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("cvxpnpl_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+
+
+def _as_dev(x, device, shape_tail):
+    if x is None:
+        return None
+    if not isinstance(x, torch.Tensor):
+        x = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64))
+    x = x.to(device=device, dtype=torch.float64).contiguous()
+    if tuple(x.shape[-len(shape_tail):]) != tuple(shape_tail):
+        raise ValueError(f"expected trailing shape {shape_tail}, got {tuple(x.shape)}")
+    return x
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else C.c_void_p(0)
+
+
+def pnpl_batch(pts_2d, line_2d, pts_3d, line_3d, K, eps: float = 1e-9, max_iters: int = 2500, want_Z: bool = False,
+               device=None, **solver_opts) -> BatchResult:
+    """Solve B independent PnPL problems of identical shape on the GPU.
+
+    pts_2d [B,n_p,2], line_2d [B,n_l,2,2], pts_3d [B,n_p,3], line_3d [B,n_l,2,3]
+    (argument order of cvxpnpl.pnpl, cvxpnpl.py:586-591); K [3,3] or [B,3,3].  Either the
+    point or the line pair may be None / empty.  torch tensors (any device) or numpy arrays.
+    """
+    _require_gpu()
+    L = _lib.lib()
+    if device is None:
+        for a in (pts_3d, line_3d, pts_2d, line_2d):
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                device = a.device
+                break
+        else:
+            device = torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    p3 = _as_dev(pts_3d, device, (3,)) if pts_3d is not None else None
+    l3 = _as_dev(line_3d, device, (2, 3)) if line_3d is not None else None
+    n_p = p3.shape[-2] if p3 is not None and p3.numel() else 0
+    n_l = l3.shape[-3] if l3 is not None and l3.numel() else 0
+    if n_p == 0 and n_l == 0:
+        raise ValueError("need at least one point or line correspondence")
+    batch = (p3 if n_p else l3).shape[0]
+    p2 = _as_dev(pts_2d, device, (2,)).reshape(batch, n_p, 2) if n_p else None
+    p3 = p3.reshape(batch, n_p, 3) if n_p else None
+    l2 = _as_dev(line_2d, device, (2, 2)).reshape(batch, n_l, 2, 2) if n_l else None
+    l3 = l3.reshape(batch, n_l, 2, 3) if n_l else None
+    Kd = _as_dev(K, device, (3, 3))
+    per = int(Kd.dim() == 3)
+    if per and Kd.shape[0] != batch:
+        raise ValueError("K must be [3,3] or [batch,3,3]")
+    opts = _lib.default_opts(eps=float(eps), max_iters=int(max_iters), **solver_opts)
+    with torch.cuda.device(device):
+        R = torch.empty((batch, 3, 3), dtype=torch.float64, device=device)
+        t = torch.empty((batch, 3), dtype=torch.float64, device=device)
+        status = torch.empty((batch,), dtype=torch.int32, device=device)
+        iters = torch.empty((batch,), dtype=torch.int32, device=device)
+        cost = torch.empty((batch, 2), dtype=torch.float64, device=device)
+        work = torch.empty((batch, 2), dtype=torch.int32, device=device)
+        Z = torch.empty((batch, 55), dtype=torch.float64, device=device) if want_Z else None
+        stream = torch.cuda.current_stream(device).cuda_stream
+        rc = L.cvxpnpl_solve_batch(batch, n_p, _ptr(p2), _ptr(p3), n_l, _ptr(l2), _ptr(l3), _ptr(Kd), per, C.byref(opts),
+                                   _ptr(R), _ptr(t), _ptr(status), _ptr(iters), _ptr(cost), _ptr(Z), _ptr(work),
+                                   C.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError(f"cvxpnpl_solve_batch failed ({rc}): {_lib.last_error()}")
+    out = BatchResult(R=R, t=t, status=status, iters=iters, cost=cost, work=work)
+    if want_Z:
+        out["Z"] = Z
+    return out
+
+
+def pnp_batch(pts_2d, pts_3d, K, eps: float = 1e-9, max_iters: int = 2500, **kw) -> BatchResult:
+    """B independent PnP problems: pts_2d [B,n,2], pts_3d [B,n,3] (cvxpnpl.pnp, cvxpnpl.py:523)."""
+    return pnpl_batch(pts_2d, None, pts_3d, None, K, eps=eps, max_iters=max_iters, **kw)
+
+
+def pnl_batch(line_2d, line_3d, K, eps: float = 1e-9, max_iters: int = 2500, **kw) -> BatchResult:
+    """B independent PnL problems: line_2d [B,n,2,2], line_3d [B,n,2,3] (cvxpnpl.pnl, cvxpnpl.py:555)."""
+    return pnpl_batch(None, line_2d, None, line_3d, K, eps=eps, max_iters=max_iters, **kw)
+
+
+def recover_multi(Z55: np.ndarray, B27: np.ndarray) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """All poses of a rank > 1 SDP solution (cvxpnpl.py:507 -> :221-343), host side."""
+    L = _lib.lib()
+    Z55 = np.ascontiguousarray(Z55, dtype=np.float64)
+    B27 = np.ascontiguousarray(B27, dtype=np.float64)
+    R, t = np.zeros((4, 3, 3)), np.zeros((4, 3))
+    dp = C.POINTER(C.c_double)
+    n = L.cvxpnpl_recover_multi(Z55.ctypes.data_as(dp), B27.ctypes.data_as(dp), R.ctypes.data_as(dp), t.ctypes.data_as(dp))
+    if n < 0:
+        raise NotImplementedError  # cvxpnpl.py:340-341
+    return [(R[i].copy(), t[i].copy()) for i in range(n)]
+
+
+def _single(pts_2d, line_2d, pts_3d, line_3d, K, eps, max_iters, verbose) -> List[Tuple[np.ndarray, np.ndarray]]:
+    def b(x, tail):
+        if x is None:
+            return None
+        x = np.asarray(x, dtype=np.float64).reshape((-1,) + tail)
+        return x[None] if len(x) else None
+
+    p2, p3 = b(pts_2d, (2,)), b(pts_3d, (3,))
+    l2, l3 = b(line_2d, (2, 2)), b(line_3d, (2, 3))
+    Kn = np.asarray(K, dtype=np.float64)
+    res = pnpl_batch(p2, l2, p3, l3, Kn, eps=eps, max_iters=max_iters, want_Z=True)
+    status = int(res.status[0])
+    if status == 3:  # cvxpnpl.py:493-498
+        if verbose:
+            warnings.warn("The SDP solver did not return a valid solution. Increasing max_iters might solve the issue.")
+        return [(np.full((3, 3), np.nan), np.full(3, np.nan))]
+    if status == 1:  # rank > 1: cvxpnpl.py:507
+        Bt = _translation_map(p2, l2, p3, l3, Kn)
+        poses = recover_multi(res.Z[0].cpu().numpy(), Bt)
+        warnings.warn("The solution is not certifiably optimal.")
+        return poses
+    if status != 0:  # cvxpnpl.py:517-519
+        warnings.warn("The solution is not certifiably optimal.")
+    if verbose:
+        print(f"cvxpnpl_amd: status={_lib.STATUS_NAMES[status]} iters={int(res.iters[0])} "
+              f"cost={float(res.cost[0, 0]):.3e} dobj={float(res.cost[0, 1]):.3e}")
+    return [(res.R[0].cpu().numpy(), res.t[0].cpu().numpy())]
+
+
+def _translation_map(p2, l2, p3, l3, Kn):
+    L = _lib.lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    a = [torch.as_tensor(x, device=dev).contiguous() if x is not None else None for x in (p2, p3, l2, l3)]
+    Kd = torch.as_tensor(Kn, device=dev).contiguous()
+    Bt = torch.empty((1, 27), dtype=torch.float64, device=dev)
+    n_p = a[1].shape[1] if a[1] is not None else 0
+    n_l = a[3].shape[1] if a[3] is not None else 0
+    rc = L.cvxpnpl_assemble_batch(1, n_p, _ptr(a[0]), _ptr(a[1]), n_l, _ptr(a[2]), _ptr(a[3]), _ptr(Kd), 0, _ptr(Bt),
+                                  C.c_void_p(0), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(_lib.last_error())
+    return Bt[0].cpu().numpy()
+
+
+def pnp(pts_2d: np.ndarray, pts_3d: np.ndarray, K: np.ndarray, eps: float = 1e-9, max_iters: int = 2500,
+        verbose: bool = False) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """Compute object poses from point 2D-3D correspondences (drop-in for cvxpnpl.pnp, cvxpnpl.py:523-552).
+
+    pts_2d -- n x 2 pixels; pts_3d -- n x 3 points; K -- 3 x 3 intrinsics; eps -- numerical
+    precision of the solver; max_iters -- iteration cap; verbose -- print solver information.
+    Returns a list of (R 3x3, t 3) with x_cam = R X + t.
+    """
+    return _single(pts_2d, None, pts_3d, None, K, eps, max_iters, verbose)
+
+
+def pnl(line_2d: np.ndarray, line_3d: np.ndarray, K: np.ndarray, eps: float = 1e-9, max_iters: int = 2500,
+        verbose: bool = False) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """Compute object poses from line 2D-3D correspondences (drop-in for cvxpnpl.pnl, cvxpnpl.py:555-583).
+
+    line_2d -- n x 2 x 2 (line, sampled point, xy); line_3d -- n x 2 x 3 (line, end point, xyz).
+    """
+    return _single(None, line_2d, None, line_3d, K, eps, max_iters, verbose)
+
+
+def pnpl(pts_2d: np.ndarray, line_2d: np.ndarray, pts_3d: np.ndarray, line_3d: np.ndarray, K: np.ndarray,
+         eps: float = 1e-9, max_iters: int = 2500, verbose: bool = False) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """Compute object poses from point and line correspondences (drop-in for cvxpnpl.pnpl, cvxpnpl.py:586-627)."""
+    return _single(pts_2d, line_2d, pts_3d, line_3d, K, eps, max_iters, verbose)

@@ -1,0 +1,36 @@
+"""Build the HIP shared library in-tree:  python -m cvxpnpl_amd.build"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "cvxpnpl_hip.hip")
+HOST_SRC = os.path.join(HERE, "csrc", "host_recover.cpp")
+OUT = os.path.join(HERE, "libcvxpnpl_amd.so")
+DEPS = [SRC, HOST_SRC, os.path.join(HERE, "csrc", "solver_core.h"), os.path.join(HERE, "csrc", "problem_io.h"),
+        os.path.join(os.path.dirname(HERE), "include", "cvxpnpl_amd.h")]
+
+
+def hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def build(force=False, verbose=False):
+    deps = [d for d in DEPS if os.path.exists(d)]
+    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in deps):
+        return OUT
+    srcs = [SRC] + ([HOST_SRC] if os.path.exists(HOST_SRC) else [])
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-o", OUT] + srcs
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -1,0 +1,172 @@
+// cvxpnpl_hip.hip -- HIP kernels (gfx950) and the C ABI of include/cvxpnpl_amd.h.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/cvxpnpl_amd.h"
+#include "problem_io.h"
+#include "solver_core.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+struct BatchArgs {
+    int64_t batch;
+    int n_p, n_l, K_per_problem;
+    const double *p2, *p3, *l2, *l3, *K;
+    double *R, *t, *cost, *Z;
+    int32_t *status, *iters, *work;
+};
+
+// ---------------------------------------------------------------------------------------
+// lane-per-problem: each lane owns one problem end to end (assembly -> ADMM -> certificate
+// -> pose); 64 independent problems per wavefront, no cross-lane traffic, no LDS.
+__global__ void __launch_bounds__(64) solve_lane_kernel(BatchArgs a, cvx::Opts o)
+{
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.batch) return;
+    cvx::ProblemView pv = cvx::make_view(b, a.n_p, a.p2, a.p3, a.n_l, a.l2, a.l3, a.K, a.K_per_problem);
+    cvx::Solution sol;
+    double Z[55];
+    cvx::solve_problem(pv, o, sol, a.Z ? Z : nullptr);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a.R[b * 9 + i] = sol.R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a.t[b * 3 + i] = sol.t[i];
+    a.status[b] = sol.status;
+    if (a.iters) a.iters[b] = sol.iters;
+    if (a.cost) { a.cost[2 * b] = sol.cost; a.cost[2 * b + 1] = sol.dobj; }
+    if (a.work) { a.work[2 * b] = sol.rank; a.work[2 * b + 1] = sol.sweeps; }
+    if (a.Z) {
+#pragma unroll
+        for (int i = 0; i < 55; ++i) a.Z[b * 55 + i] = Z[i];
+    }
+}
+
+__global__ void __launch_bounds__(64) assemble_kernel(BatchArgs a, double *Bout, double *Qout)
+{
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.batch) return;
+    cvx::ProblemView pv = cvx::make_view(b, a.n_p, a.p2, a.p3, a.n_l, a.l2, a.l3, a.K, a.K_per_problem);
+    double B[27], Q9[45];
+    bool ok = cvx::assemble(pv, B, Q9);
+    for (int i = 0; i < 27; ++i) Bout[b * 27 + i] = ok ? B[i] : NAN;
+    if (Qout)
+        for (int i = 0; i < 45; ++i) Qout[b * 45 + i] = ok ? Q9[i] : NAN;
+}
+
+int set_err(const char *what, hipError_t e)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return -2;
+}
+
+cvx::Opts to_core(const cvxpnpl_opts_t *opts)
+{
+    cvx::Opts o = cvx::default_opts();
+    if (opts) {
+        o.eps = opts->eps; o.max_iters = opts->max_iters; o.rho = opts->rho; o.alpha = opts->alpha;
+        o.first_check = opts->first_check; o.check_every = opts->check_every; o.res_tol = opts->res_tol;
+        o.jacobi_sweeps = opts->jacobi_sweeps;
+    }
+    return o;
+}
+
+} // namespace
+
+extern "C" {
+
+void cvxpnpl_default_opts(cvxpnpl_opts_t *opts)
+{
+    cvx::Opts o = cvx::default_opts();
+    opts->eps = o.eps; opts->max_iters = o.max_iters; opts->rho = o.rho; opts->alpha = o.alpha;
+    opts->first_check = o.first_check; opts->check_every = o.check_every; opts->res_tol = o.res_tol;
+    opts->jacobi_sweeps = o.jacobi_sweeps; opts->layout = CVXPNPL_LAYOUT_AUTO;
+}
+
+static int check_args(int64_t batch, int32_t n_p, const double *p2, const double *p3, int32_t n_l, const double *l2,
+                      const double *l3, const double *K)
+{
+    if (batch < 0 || n_p < 0 || n_l < 0 || (n_p == 0 && n_l == 0) || !K || (n_p > 0 && (!p2 || !p3)) || (n_l > 0 && (!l2 || !l3))) {
+        snprintf(g_err, sizeof(g_err), "cvxpnpl: bad arguments (batch=%lld n_p=%d n_l=%d)", (long long)batch, n_p, n_l);
+        return -1;
+    }
+    return 0;
+}
+
+int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, const double *d_pts_3d, int32_t n_l,
+                        const double *d_line_2d, const double *d_line_3d, const double *d_K, int32_t K_per_problem,
+                        const cvxpnpl_opts_t *opts, double *d_R, double *d_t, int32_t *d_status, int32_t *d_iters,
+                        double *d_cost, double *d_Z, int32_t *d_work, void *stream)
+{
+    if (check_args(batch, n_p, d_pts_2d, d_pts_3d, n_l, d_line_2d, d_line_3d, d_K)) return -1;
+    if (!d_R || !d_t || !d_status) { snprintf(g_err, sizeof(g_err), "cvxpnpl: R, t and status outputs are required"); return -1; }
+    if (opts && (opts->max_iters < 1 || !(opts->rho > 0) || !(opts->eps > 0) || opts->check_every < 1 || opts->first_check < 1)) {
+        snprintf(g_err, sizeof(g_err), "cvxpnpl: bad options");
+        return -1;
+    }
+    if (batch == 0) return 0;
+    BatchArgs a;
+    a.batch = batch; a.n_p = n_p; a.n_l = n_l; a.K_per_problem = K_per_problem;
+    a.p2 = d_pts_2d; a.p3 = d_pts_3d; a.l2 = d_line_2d; a.l3 = d_line_3d; a.K = d_K;
+    a.R = d_R; a.t = d_t; a.cost = d_cost; a.Z = d_Z; a.status = d_status; a.iters = d_iters; a.work = d_work;
+    cvx::Opts o = to_core(opts);
+    hipStream_t s = (hipStream_t)stream;
+    const int block = 64;
+    int64_t grid = (batch + block - 1) / block;
+    if (grid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }
+    hipLaunchKernelGGL(solve_lane_kernel, dim3((unsigned)grid), dim3(block), 0, s, a, o);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err("solve_lane_kernel launch", e);
+    return 0;
+}
+
+int cvxpnpl_assemble_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, const double *d_pts_3d, int32_t n_l,
+                           const double *d_line_2d, const double *d_line_3d, const double *d_K, int32_t K_per_problem,
+                           double *d_B, double *d_Q45, void *stream)
+{
+    if (check_args(batch, n_p, d_pts_2d, d_pts_3d, n_l, d_line_2d, d_line_3d, d_K) || !d_B) return -1;
+    if (batch == 0) return 0;
+    BatchArgs a;
+    memset(&a, 0, sizeof(a));
+    a.batch = batch; a.n_p = n_p; a.n_l = n_l; a.K_per_problem = K_per_problem;
+    a.p2 = d_pts_2d; a.p3 = d_pts_3d; a.l2 = d_line_2d; a.l3 = d_line_3d; a.K = d_K;
+    const int block = 64;
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((batch + block - 1) / block)), dim3(block), 0, (hipStream_t)stream, a, d_B, d_Q45);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err("assemble_kernel launch", e);
+    return 0;
+}
+
+void *cvxpnpl_event_create(void)
+{
+    hipEvent_t ev;
+    if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    return (void *)ev;
+}
+int cvxpnpl_event_record(void *event, void *stream)
+{
+    hipError_t e = hipEventRecord((hipEvent_t)event, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : set_err("hipEventRecord", e);
+}
+int cvxpnpl_event_elapsed_ms(void *start, void *stop, float *ms)
+{
+    hipError_t e = hipEventSynchronize((hipEvent_t)stop);
+    if (e != hipSuccess) return set_err("hipEventSynchronize", e);
+    e = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+    return e == hipSuccess ? 0 : set_err("hipEventElapsedTime", e);
+}
+void cvxpnpl_event_destroy(void *event) { if (event) hipEventDestroy((hipEvent_t)event); }
+
+const char *cvxpnpl_last_error(void) { return g_err; }
+const char *cvxpnpl_version(void) { return "cvxpnpl_amd 0.1.0 (gfx950)"; }
+int cvxpnpl_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+} // extern "C"

@@ -1,0 +1,57 @@
+// problem_io.h -- how one problem's correspondences are read and turned into (B, Q9).
+//
+// Batch layout at the C-ABI (include/cvxpnpl_amd.h): contiguous, problem-major
+//   pts_2d  [batch][n_p][2]     pts_3d  [batch][n_p][3]
+//   line_2d [batch][n_l][2][2]  line_3d [batch][n_l][2][3]     K [3][3] or [batch][3][3]
+// the layout np.stack of the reference's per-problem arguments gives (cvxpnpl.py:523-595).
+#pragma once
+#include "solver_core.h"
+
+namespace cvx {
+
+struct ProblemView {
+    int n_p, n_l;
+    const double *p2, *p3, *l2, *l3, *K;
+};
+
+CVX_HD ProblemView make_view(long b, int n_p, const double *pts_2d, const double *pts_3d, int n_l, const double *line_2d,
+                             const double *line_3d, const double *K, int K_per_problem)
+{
+    ProblemView v;
+    v.n_p = n_p; v.n_l = n_l;
+    v.p2 = n_p ? pts_2d + b * n_p * 2 : nullptr;
+    v.p3 = n_p ? pts_3d + b * n_p * 3 : nullptr;
+    v.l2 = n_l ? line_2d + b * n_l * 4 : nullptr;
+    v.l3 = n_l ? line_3d + b * n_l * 6 : nullptr;
+    v.K = K + (K_per_problem ? b * 9 : 0);
+    return v;
+}
+
+// cvxpnpl.py:523-627 up to the call of _solve_relaxation: B (3x9) and Q9 = A^T A (45 packed)
+CVX_HD bool assemble(const ProblemView &v, double *B, double *Q9)
+{
+    double Kc[9], Ki[9], det;
+    CVX_UNROLL for (int i = 0; i < 9; ++i) Kc[i] = v.K[i];
+    inv3(Kc, Ki, det);
+    Gram g;
+    gram_zero(g);
+    for (int i = 0; i < v.n_p; ++i)
+        gram_add_point(g, Ki, v.p2[2 * i], v.p2[2 * i + 1], v.p3[3 * i], v.p3[3 * i + 1], v.p3[3 * i + 2]);
+    for (int i = 0; i < v.n_l; ++i) gram_add_line(g, Ki, v.l2 + 4 * i, v.l3 + 6 * i);
+    bool ok = gram_finish(g, B, Q9);
+    return ok && (det == det) && det != 0.0;
+}
+
+CVX_HD void solve_problem(const ProblemView &v, const Opts &o, Solution &sol, double *Zout)
+{
+    double B[27], Q9[45];
+    bool ok = assemble(v, B, Q9);
+    if (!ok) { // singular N^T N or K: the reference raises LinAlgError; report a NaN pose
+        CVX_UNROLL for (int i = 0; i < 45; ++i) Q9[i] = NAN;
+        CVX_UNROLL for (int i = 0; i < 27; ++i) B[i] = NAN;
+    }
+    solve_sdp(Q9, B, o, sol, Zout);
+    if (!ok) { CVX_UNROLL for (int i = 0; i < 3; ++i) sol.t[i] = NAN; }
+}
+
+} // namespace cvx

@@ -1,0 +1,732 @@
+// solver_core.h -- the per-problem mathematics of the batched absolute-pose SDP solver.
+//
+// One problem = one 10x10, 22-equality Shor-relaxed SDP (reference: cvxpnpl.py:454-520).
+// Everything here is scalar code over one problem's registers; the HIP kernels in
+// kernels.hip instantiate it once per lane (lane-per-problem layout).  It is also
+// compilable by a host C++ compiler so that tests can step the *device algorithm* on a
+// CPU without a GPU (tests/hostsim) -- that build is test-only and never shipped.
+//
+// Pipeline (DESIGN.md has the derivations):
+//   assemble      Gram blocks of the reference's C, N matrices (cvxpnpl.py:20-153) without
+//                 forming them:  every row block is  P^T (x) T  with T = |p|^2 I - p p^T
+//                 (points) or n n^T (line end points), so  N^T N = sum T,
+//                 N^T C = sum P^T (x) T,  C^T C = sum P P^T (x) T.   B = (N^T N)^-1 N^T C
+//                 and  Q9 = C^T C - (N^T C)^T B  (= A^T A of cvxpnpl.py:549/475).
+//   admm          Douglas-Rachford splitting between the affine set {<A_i, Z> = b_i}
+//                 (cvxpnpl.py:387-451, applied in closed form -- the 22 rows are 15 disjoint
+//                 off-diagonal triples plus a 3x3 "doubly stochastic" diagonal block) and
+//                 the PSD cone (one-sided Jacobi eigendecomposition of the shifted iterate).
+//   certify       every few iterations: rank-1 rounding of Z (cvxpnpl.py:504-505), SO(3)
+//                 Newton polish of r^T Q r, dual recovery (projection of the ADMM dual onto
+//                 {S in Q - span A_i, S z = 0}), LDL^T test of S + delta I > 0.  Success is a
+//                 rigorous primal-dual certificate  0 <= pobj - dobj <= eps  for the SDP --
+//                 the same statement as the reference's check at cvxpnpl.py:516-519.
+//   fallback      no certificate by max_iters / stagnation: eigen-rank of Z at 1e-3
+//                 (cvxpnpl.py:502), rank-1 ratio, U V^T projection without determinant fix
+//                 (cvxpnpl.py:510-511), t = -B r (cvxpnpl.py:513); rank > 1 is flagged and Z is
+//                 handed to the host-side multi-solution recovery.
+#pragma once
+
+#include <math.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define CVX_HD __host__ __device__ __forceinline__
+#define CVX_UNROLL _Pragma("unroll")
+#else
+#define CVX_HD static inline
+#define CVX_UNROLL
+#endif
+
+namespace cvx {
+
+enum Status : int {
+    ST_CERTIFIED = 0,   // rank-1, certified globally optimal (gap <= eps)
+    ST_RANK_GT1 = 1,    // relaxation not tight: rank(Z) > 1, multiple poses (host recovery)
+    ST_UNCERTIFIED = 2, // rank-1 pose returned, but no certificate (max_iters / stagnation)
+    ST_NONFINITE = 3,   // NaN/inf met (degenerate input): NaN pose, cvxpnpl.py:493-498
+    ST_REFLECTION = 4   // uncertified and det(U V^T) < 0 (the reference returns it as is)
+};
+
+struct Opts {
+    double eps;        // absolute duality-gap tolerance of the certificate (reference eps)
+    int max_iters;     // ADMM iteration cap (reference max_iters)
+    double rho;        // ADMM penalty on the trace-normalised cost
+    double alpha;      // over-relaxation
+    int first_check;   // first certification attempt after this many iterations
+    int check_every;   // then every this many
+    double res_tol;    // fixed-point residual below which an uncertified solve stops
+    int jacobi_sweeps; // cap on Jacobi sweeps per PSD projection
+};
+
+CVX_HD Opts default_opts()
+{
+    Opts o;
+    o.eps = 1e-9; o.max_iters = 2500; o.rho = 0.05; o.alpha = 1.0;
+    o.first_check = 5; o.check_every = 5; o.res_tol = 1e-7; o.jacobi_sweeps = 12;
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------
+// index helpers.  sidx: 10x10 symmetric in 55 entries, identical to the reference's vech
+// order (cvxpnpl.py:346-370: columns of the lower triangle == rows of the upper triangle).
+CVX_HD constexpr int sidx(int i, int j) { return i <= j ? i * 10 - i * (i - 1) / 2 + (j - i) : j * 10 - j * (j - 1) / 2 + (i - j); }
+// 9x9 symmetric in 45 entries
+CVX_HD constexpr int qidx(int i, int j) { return i <= j ? i * 9 - i * (i - 1) / 2 + (j - i) : j * 9 - j * (j - 1) / 2 + (i - j); }
+
+// The 15 off-diagonal equality rows of cvxpnpl.py:404-435 as (i, j, sign) triples; the
+// remaining 7 rows (cvxpnpl.py:398, :404-418 with c = 1) only touch the diagonal.
+// Every off-diagonal entry of Z appears in exactly one triple.
+CVX_HD constexpr int tri_i(int t, int k)
+{
+    constexpr int T[15][3] = {{0, 3, 6}, {0, 3, 6}, {1, 4, 7}, {0, 1, 2}, {0, 1, 2}, {3, 4, 5}, {1, 2, 6}, {2, 0, 7},
+                              {0, 1, 8}, {4, 5, 0}, {5, 3, 1}, {3, 4, 2}, {2, 1, 3}, {0, 2, 4}, {1, 0, 5}};
+    return T[t][k];
+}
+CVX_HD constexpr int tri_j(int t, int k)
+{
+    constexpr int T[15][3] = {{1, 4, 7}, {2, 5, 8}, {2, 5, 8}, {3, 4, 5}, {6, 7, 8}, {6, 7, 8}, {5, 4, 9}, {3, 5, 9},
+                              {4, 3, 9}, {8, 7, 9}, {6, 8, 9}, {7, 6, 9}, {7, 8, 9}, {8, 6, 9}, {6, 7, 9}};
+    return T[t][k];
+}
+CVX_HD constexpr double tri_s(int t, int k) { return (t >= 6 && k >= 1) ? -1.0 : 1.0; }
+
+// ---------------------------------------------------------------------------------------
+// tiny helpers
+
+CVX_HD void inv3(const double *M, double *Mi, double &det)
+{
+    double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+    det = M[0] * c00 + M[1] * c01 + M[2] * c02;
+    double id = 1.0 / det;
+    Mi[0] = c00 * id; Mi[1] = (M[2] * M[7] - M[1] * M[8]) * id; Mi[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+    Mi[3] = c01 * id; Mi[4] = (M[0] * M[8] - M[2] * M[6]) * id; Mi[5] = (M[2] * M[3] - M[0] * M[5]) * id;
+    Mi[6] = c02 * id; Mi[7] = (M[1] * M[6] - M[0] * M[7]) * id; Mi[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+}
+
+// orthogonal polar factor U V^T of a 3x3 matrix (what np.linalg.svd gives as U @ Vh,
+// cvxpnpl.py:510-511; reflections are preserved).  Scaled Newton iteration
+// X <- (g X + X^-T / g) / 2.  `iters` fixed so that lanes stay convergent.
+CVX_HD void polar3(const double *M, double *R, int iters)
+{
+    double X[9];
+    CVX_UNROLL for (int i = 0; i < 9; ++i) X[i] = M[i];
+    for (int it = 0; it < iters; ++it) {
+        double Xi[9], det;
+        inv3(X, Xi, det);
+        // Frobenius scaling g = (|X^-1|_F / |X|_F)^(1/2) for the first iterations
+        double nx = 0, ni = 0;
+        CVX_UNROLL for (int i = 0; i < 9; ++i) { nx += X[i] * X[i]; ni += Xi[i] * Xi[i]; }
+        double g = (it < 4) ? sqrt(sqrt(ni / nx)) : 1.0;
+        double ig = 1.0 / g;
+        // X^-T = transpose(Xi)
+        double Y[9];
+        CVX_UNROLL for (int i = 0; i < 3; ++i)
+            CVX_UNROLL for (int j = 0; j < 3; ++j) Y[i * 3 + j] = 0.5 * (g * X[i * 3 + j] + ig * Xi[j * 3 + i]);
+        CVX_UNROLL for (int i = 0; i < 9; ++i) X[i] = Y[i];
+    }
+    CVX_UNROLL for (int i = 0; i < 9; ++i) R[i] = X[i];
+}
+
+CVX_HD double det3(const double *M)
+{
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+// ---------------------------------------------------------------------------------------
+// assembly (replaces cvxpnpl.py:20-153 + :545-549 + :475)
+
+struct Gram {
+    double M0[6];      // sum T            (N^T N), packed 00 01 02 11 12 22
+    double M1[3][6];   // sum P_a T        (N^T C blocks)
+    double M2[6][6];   // sum P_a P_b T    (C^T C blocks), ab packed 00 01 02 11 12 22
+};
+
+CVX_HD void gram_zero(Gram &g)
+{
+    CVX_UNROLL for (int i = 0; i < 6; ++i) g.M0[i] = 0;
+    CVX_UNROLL for (int a = 0; a < 3; ++a) CVX_UNROLL for (int i = 0; i < 6; ++i) g.M1[a][i] = 0;
+    CVX_UNROLL for (int a = 0; a < 6; ++a) CVX_UNROLL for (int i = 0; i < 6; ++i) g.M2[a][i] = 0;
+}
+
+CVX_HD void gram_add(Gram &g, const double *T, double X, double Y, double Z)
+{
+    const double P[3] = {X, Y, Z};
+    const double PP[6] = {X * X, X * Y, X * Z, Y * Y, Y * Z, Z * Z};
+    CVX_UNROLL for (int i = 0; i < 6; ++i) {
+        g.M0[i] += T[i];
+        CVX_UNROLL for (int a = 0; a < 3; ++a) g.M1[a][i] += P[a] * T[i];
+        CVX_UNROLL for (int a = 0; a < 6; ++a) g.M2[a][i] += PP[a] * T[i];
+    }
+}
+
+// bearing p = K^-1 [u v 1]^T (cvxpnpl.py:37) with a precomputed general inverse
+CVX_HD void bearing(const double *Ki, double u, double v, double *p)
+{
+    p[0] = Ki[0] * u + Ki[1] * v + Ki[2];
+    p[1] = Ki[3] * u + Ki[4] * v + Ki[5];
+    p[2] = Ki[6] * u + Ki[7] * v + Ki[8];
+}
+
+// one 2D-3D point correspondence: rows [p]x (R P + t) = 0 (cvxpnpl.py:43-102)
+CVX_HD void gram_add_point(Gram &g, const double *Ki, double u, double v, double X, double Y, double Z)
+{
+    double p[3];
+    bearing(Ki, u, v, p);
+    double n2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+    // [p]x^T [p]x = |p|^2 I - p p^T
+    double T[6] = {n2 - p[0] * p[0], -p[0] * p[1], -p[0] * p[2], n2 - p[1] * p[1], -p[1] * p[2], n2 - p[2] * p[2]};
+    gram_add(g, T, X, Y, Z);
+}
+
+// one 2D-3D line correspondence: rows n^T (R P_k + t) = 0 for both 3D end points,
+// n = normalised cross product of the two back-projected 2D samples (cvxpnpl.py:123-153)
+CVX_HD void gram_add_line(Gram &g, const double *Ki, const double *l2 /*u0 v0 u1 v1*/, const double *l3 /*P0 P1*/)
+{
+    double a[3], b[3];
+    bearing(Ki, l2[0], l2[1], a);
+    bearing(Ki, l2[2], l2[3], b);
+    double n[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+    double inv = 1.0 / sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    n[0] *= inv; n[1] *= inv; n[2] *= inv;
+    double T[6] = {n[0] * n[0], n[0] * n[1], n[0] * n[2], n[1] * n[1], n[1] * n[2], n[2] * n[2]};
+    gram_add(g, T, l3[0], l3[1], l3[2]);
+    gram_add(g, T, l3[3], l3[4], l3[5]);
+}
+
+// B = (N^T N)^-1 N^T C  (3x9, row-major), Q9 = C^T C - (N^T C)^T B (45 packed).
+// Returns false when N^T N is singular / non-finite (the reference raises LinAlgError).
+CVX_HD bool gram_finish(const Gram &g, double *B, double *Q9)
+{
+    const double *m = g.M0;
+    double M0[9] = {m[0], m[1], m[2], m[1], m[3], m[4], m[2], m[4], m[5]}, Mi[9], det;
+    inv3(M0, Mi, det);
+    double scale = m[0] + m[3] + m[5];
+    // singular N^T N (fewer than two distinct bearings): np.linalg.solve would raise or
+    // return garbage; the relative determinant of a usable system is >> 1e-12
+    if (!(det > 1e-12 * (scale * scale * scale) * (1.0 / 27.0))) return false;
+    // B block a (3x3): Mi * sym(M1[a]);  B[i][3a+j]
+    double Bb[3][9];
+    CVX_UNROLL for (int a = 0; a < 3; ++a) {
+        const double *s = g.M1[a];
+        double S[9] = {s[0], s[1], s[2], s[1], s[3], s[4], s[2], s[4], s[5]};
+        CVX_UNROLL for (int i = 0; i < 3; ++i)
+            CVX_UNROLL for (int j = 0; j < 3; ++j) {
+                double acc = Mi[i * 3] * S[j] + Mi[i * 3 + 1] * S[3 + j] + Mi[i * 3 + 2] * S[6 + j];
+                Bb[a][i * 3 + j] = acc;
+                B[i * 9 + 3 * a + j] = acc;
+            }
+    }
+    // Q block (a, b), a <= b:  M2[ab] - sym(M1[a]) * Bb[b]
+    constexpr int ab[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+    CVX_UNROLL for (int a = 0; a < 3; ++a) {
+        const double *s = g.M1[a];
+        double S[9] = {s[0], s[1], s[2], s[1], s[3], s[4], s[2], s[4], s[5]};
+        CVX_UNROLL for (int b = a; b < 3; ++b) {
+            const double *t = g.M2[ab[a][b]];
+            double Tm[9] = {t[0], t[1], t[2], t[1], t[3], t[4], t[2], t[4], t[5]};
+            CVX_UNROLL for (int i = 0; i < 3; ++i)
+                CVX_UNROLL for (int j = 0; j < 3; ++j) {
+                    if (a == b && j < i) continue;
+                    double acc = Tm[i * 3 + j] - (S[i * 3] * Bb[b][j] + S[i * 3 + 1] * Bb[b][3 + j] + S[i * 3 + 2] * Bb[b][6 + j]);
+                    Q9[qidx(3 * a + i, 3 * b + j)] = acc;
+                }
+        }
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------
+// the affine set of cvxpnpl.py:387-451 in closed form
+
+// E <- E - P_range(E) shifted:  project the symmetric matrix E (55 packed) onto
+// { <A_i, Z> = b_i } (homog = false) or onto its direction space { <A_i, Z> = 0 }.
+CVX_HD void proj_affine(double *E, bool homog)
+{
+    CVX_UNROLL for (int t = 0; t < 15; ++t) {
+        double m = (tri_s(t, 0) * E[sidx(tri_i(t, 0), tri_j(t, 0))] + tri_s(t, 1) * E[sidx(tri_i(t, 1), tri_j(t, 1))] +
+                    tri_s(t, 2) * E[sidx(tri_i(t, 2), tri_j(t, 2))]) * (1.0 / 3.0);
+        CVX_UNROLL for (int k = 0; k < 3; ++k) E[sidx(tri_i(t, k), tri_j(t, k))] -= tri_s(t, k) * m;
+    }
+    // diagonal block D[i][j] = Z[3j+i, 3j+i]: rows and columns sum to Z99 = 1
+    const double tgt = homog ? 0.0 : 1.0;
+    double rs[3], cs[3], tot = 0;
+    CVX_UNROLL for (int i = 0; i < 3; ++i) {
+        rs[i] = E[sidx(i, i)] + E[sidx(3 + i, 3 + i)] + E[sidx(6 + i, 6 + i)] - tgt;
+        cs[i] = E[sidx(3 * i, 3 * i)] + E[sidx(3 * i + 1, 3 * i + 1)] + E[sidx(3 * i + 2, 3 * i + 2)] - tgt;
+        tot += rs[i];
+    }
+    CVX_UNROLL for (int i = 0; i < 3; ++i)
+        CVX_UNROLL for (int j = 0; j < 3; ++j) E[sidx(3 * j + i, 3 * j + i)] -= (rs[i] + cs[j]) * (1.0 / 3.0) - tot * (1.0 / 9.0);
+    E[sidx(9, 9)] = tgt;
+}
+
+// ---------------------------------------------------------------------------------------
+// PSD projection: eigendecomposition of W by one-sided (Hestenes) Jacobi on the shifted,
+// positive definite G = W + sigma I.  On exit column j of G is lam'_j v_j.
+
+struct Eig {
+    double G[10][10]; // G[j][i]: column j, row i
+    double n2[10];    // squared column norms = lam'_j^2
+    double sigma;
+};
+
+CVX_HD void eig_load(Eig &e, const double *W)
+{
+    double fro = 0;
+    CVX_UNROLL for (int i = 0; i < 10; ++i)
+        CVX_UNROLL for (int j = i; j < 10; ++j) fro += (i == j ? 1.0 : 2.0) * W[sidx(i, j)] * W[sidx(i, j)];
+    e.sigma = 1.5 * sqrt(fro) + 1e-300;
+    CVX_UNROLL for (int j = 0; j < 10; ++j)
+        CVX_UNROLL for (int i = 0; i < 10; ++i) e.G[j][i] = W[sidx(i, j)] + (i == j ? e.sigma : 0.0);
+}
+
+CVX_HD void eig_norms(Eig &e)
+{
+    CVX_UNROLL for (int j = 0; j < 10; ++j) {
+        double s = 0;
+        CVX_UNROLL for (int i = 0; i < 10; ++i) s += e.G[j][i] * e.G[j][i];
+        e.n2[j] = s;
+    }
+}
+
+// one rotation of columns p, q; returns true if it was larger than the threshold
+CVX_HD bool eig_rotate(Eig &e, int p, int q, double tol2)
+{
+    double gam = 0;
+    CVX_UNROLL for (int i = 0; i < 10; ++i) gam += e.G[p][i] * e.G[q][i];
+    double al = e.n2[p], be = e.n2[q];
+    bool big = gam * gam > tol2 * al * be;
+    // tan of the rotation angle from  d = be - al, g2 = 2 gam  (no division by gam)
+    double d = be - al, g2 = 2.0 * gam;
+    double h = sqrt(d * d + g2 * g2);
+    double ad = fabs(d);
+    double t = (big ? g2 : 0.0) / (ad + h + 1e-300);
+    t = d < 0 ? -t : t;
+    double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+    CVX_UNROLL for (int i = 0; i < 10; ++i) {
+        double gp = e.G[p][i], gq = e.G[q][i];
+        e.G[p][i] = c * gp - s * gq;
+        e.G[q][i] = s * gp + c * gq;
+    }
+    e.n2[p] = al - t * gam;
+    e.n2[q] = be + t * gam;
+    return big;
+}
+
+// cyclic sweeps until no rotation exceeds the threshold (or max_sweeps)
+CVX_HD int eig_solve(Eig &e, int max_sweeps)
+{
+    const double tol2 = 1e-30;
+    int sweeps = 0;
+    for (; sweeps < max_sweeps; ++sweeps) {
+        eig_norms(e);
+        bool any = false;
+        CVX_UNROLL for (int p = 0; p < 9; ++p)
+            CVX_UNROLL for (int q = p + 1; q < 10; ++q) any |= eig_rotate(e, p, q, tol2);
+        if (!any) break;
+    }
+    eig_norms(e);
+    return sweeps;
+}
+
+// Wp = sum_{lam_j > 0} lam_j v_j v_j^T  (55 packed)
+CVX_HD void eig_pospart(const Eig &e, double *Wp)
+{
+    double w[10];
+    CVX_UNROLL for (int j = 0; j < 10; ++j) {
+        double lp = sqrt(e.n2[j]);
+        double lam = lp - e.sigma;
+        w[j] = lam > 0 ? lam / e.n2[j] : 0.0;
+    }
+    CVX_UNROLL for (int i = 0; i < 10; ++i)
+        CVX_UNROLL for (int k = i; k < 10; ++k) {
+            double acc = 0;
+            CVX_UNROLL for (int j = 0; j < 10; ++j) acc += w[j] * e.G[j][i] * e.G[j][k];
+            Wp[sidx(i, k)] = acc;
+        }
+}
+
+// ---------------------------------------------------------------------------------------
+// SO(3) Newton polish of f(R) = r^T Q r, r = vec_colmajor(R)
+
+CVX_HD void q9_mul(const double *Q9, const double *x, double *y)
+{
+    CVX_UNROLL for (int i = 0; i < 9; ++i) {
+        double acc = 0;
+        CVX_UNROLL for (int j = 0; j < 9; ++j) acc += Q9[qidx(i, j)] * x[j];
+        y[i] = acc;
+    }
+}
+
+// R is row-major 3x3; r[3j+i] = R[i][j]
+CVX_HD void so3_newton(const double *Q9, double *R, int iters)
+{
+    for (int it = 0; it < iters; ++it) {
+        double r[9], Qr[9];
+        CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) r[3 * j + i] = R[i * 3 + j];
+        q9_mul(Q9, r, Qr);
+        // N = R^T M, M = mat(Qr): M[i][j] = Qr[3j+i]
+        double N[9];
+        CVX_UNROLL for (int i = 0; i < 3; ++i)
+            CVX_UNROLL for (int j = 0; j < 3; ++j) N[i * 3 + j] = R[0 * 3 + i] * Qr[3 * j] + R[1 * 3 + i] * Qr[3 * j + 1] + R[2 * 3 + i] * Qr[3 * j + 2];
+        double g[3] = {2 * (N[7] - N[5]), 2 * (N[2] - N[6]), 2 * (N[3] - N[1])};
+        // a_k = vec(R [e_k]x): columns (0, c2, -c1), (-c2, 0, c0), (c1, -c0, 0)
+        double a[3][9], Qa[3][9];
+        CVX_UNROLL for (int i = 0; i < 3; ++i) {
+            double c0 = R[i * 3], c1 = R[i * 3 + 1], c2 = R[i * 3 + 2];
+            a[0][i] = 0;   a[0][3 + i] = c2;  a[0][6 + i] = -c1;
+            a[1][i] = -c2; a[1][3 + i] = 0;   a[1][6 + i] = c0;
+            a[2][i] = c1;  a[2][3 + i] = -c0; a[2][6 + i] = 0;
+        }
+        CVX_UNROLL for (int k = 0; k < 3; ++k) q9_mul(Q9, a[k], Qa[k]);
+        double trN = N[0] + N[4] + N[8];
+        double H[9];
+        CVX_UNROLL for (int k = 0; k < 3; ++k)
+            CVX_UNROLL for (int l = 0; l < 3; ++l) {
+                double acc = 0;
+                CVX_UNROLL for (int i = 0; i < 9; ++i) acc += a[k][i] * Qa[l][i];
+                H[k * 3 + l] = 2 * acc + N[l * 3 + k] + N[k * 3 + l] - (k == l ? 2 * trN : 0.0);
+            }
+        // solve H w = -g; fall back to a scaled gradient step when H is not positive definite
+        double Hi[9], det;
+        inv3(H, Hi, det);
+        bool pd = H[0] > 0 && (H[0] * H[4] - H[1] * H[3]) > 0 && det > 0;
+        double w[3];
+        double hn = fabs(H[0]) + fabs(H[4]) + fabs(H[8]) + 1e-300;
+        CVX_UNROLL for (int k = 0; k < 3; ++k) {
+            double nw = -(Hi[k * 3] * g[0] + Hi[k * 3 + 1] * g[1] + Hi[k * 3 + 2] * g[2]);
+            w[k] = pd ? nw : -g[k] / hn;
+        }
+        double wn = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        double lim = wn > 0.5 ? 0.5 / wn : 1.0;
+        // Cayley retraction R <- R (I - S)^-1 (I + S), S = [w/2]x  = R (I + 2/(1+|s|^2) (S + S^2))
+        double s0 = 0.5 * lim * w[0], s1 = 0.5 * lim * w[1], s2 = 0.5 * lim * w[2];
+        double f = 2.0 / (1.0 + s0 * s0 + s1 * s1 + s2 * s2);
+        double ss = s0 * s0 + s1 * s1 + s2 * s2;
+        double Cm[9] = {1 + f * (s0 * s0 - ss), f * (-s2 + s0 * s1), f * (s1 + s0 * s2),
+                        f * (s2 + s0 * s1), 1 + f * (s1 * s1 - ss), f * (-s0 + s1 * s2),
+                        f * (-s1 + s0 * s2), f * (s0 + s1 * s2), 1 + f * (s2 * s2 - ss)};
+        double Rn[9];
+        CVX_UNROLL for (int i = 0; i < 3; ++i)
+            CVX_UNROLL for (int j = 0; j < 3; ++j) Rn[i * 3 + j] = R[i * 3] * Cm[j] + R[i * 3 + 1] * Cm[3 + j] + R[i * 3 + 2] * Cm[6 + j];
+        CVX_UNROLL for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+    }
+    // one polar step squares any drift from orthogonality
+    double Ri[9], det;
+    inv3(R, Ri, det);
+    double Rn[9];
+    CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) Rn[i * 3 + j] = 0.5 * (R[i * 3 + j] + Ri[j * 3 + i]);
+    CVX_UNROLL for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// dual recovery + certificate
+
+// y[i] = sum_j S[i][j] z[j] for packed symmetric S
+CVX_HD void sym_mul10(const double *S, const double *z, double *y)
+{
+    CVX_UNROLL for (int i = 0; i < 10; ++i) {
+        double acc = 0;
+        CVX_UNROLL for (int j = 0; j < 10; ++j) acc += S[sidx(i, j)] * z[j];
+        y[i] = acc;
+    }
+}
+
+// in-place LDL^T without pivoting of a packed symmetric 10x10; returns the smallest pivot
+CVX_HD double ldl_min_pivot(double *S)
+{
+    double minp = 1e300;
+    CVX_UNROLL for (int k = 0; k < 10; ++k) {
+        double d = S[sidx(k, k)];
+        minp = d < minp ? d : minp;
+        double id = 1.0 / d;
+        CVX_UNROLL for (int i = k + 1; i < 10; ++i) {
+            double l = S[sidx(k, i)] * id;
+            CVX_UNROLL for (int j = i; j < 10; ++j) S[sidx(i, j)] -= l * S[sidx(k, j)];
+        }
+    }
+    return minp;
+}
+
+// Cholesky solve of a full 10x10 SPD system (row-major), in place on M and x.
+CVX_HD bool chol_solve10(double *M, double *x)
+{
+    bool ok = true;
+    CVX_UNROLL for (int j = 0; j < 10; ++j) {
+        double d = M[j * 10 + j];
+        CVX_UNROLL for (int k = 0; k < j; ++k) d -= M[j * 10 + k] * M[j * 10 + k];
+        ok &= d > 0;
+        d = sqrt(d > 0 ? d : 1.0);
+        M[j * 10 + j] = d;
+        double id = 1.0 / d;
+        CVX_UNROLL for (int i = j + 1; i < 10; ++i) {
+            double s = M[i * 10 + j];
+            CVX_UNROLL for (int k = 0; k < j; ++k) s -= M[i * 10 + k] * M[j * 10 + k];
+            M[i * 10 + j] = s * id;
+        }
+    }
+    CVX_UNROLL for (int i = 0; i < 10; ++i) {
+        double s = x[i];
+        CVX_UNROLL for (int k = 0; k < i; ++k) s -= M[i * 10 + k] * x[k];
+        x[i] = s / M[i * 10 + i];
+    }
+    CVX_UNROLL for (int i = 9; i >= 0; --i) {
+        double s = x[i];
+        CVX_UNROLL for (int k = i + 1; k < 10; ++k) s -= M[k * 10 + i] * x[k];
+        x[i] = s / M[i * 10 + i];
+    }
+    return ok;
+}
+
+// P_range(sym(lam z^T)) applied to z, accumulated as the 10x10 Gram matrix
+//   Mz = sum_i (Ahat_i z)(Ahat_i z)^T   over an orthonormal basis Ahat_i of span{A_i}
+CVX_HD void build_Mz(const double *z, double *M)
+{
+    CVX_UNROLL for (int i = 0; i < 100; ++i) M[i] = 0;
+    // off-diagonal triples: pattern has +-1/2 at (i,j),(j,i); |pattern|^2 = 3/2
+    CVX_UNROLL for (int t = 0; t < 15; ++t) {
+        double g[10];
+        CVX_UNROLL for (int i = 0; i < 10; ++i) g[i] = 0;
+        CVX_UNROLL for (int k = 0; k < 3; ++k) {
+            g[tri_i(t, k)] += 0.5 * tri_s(t, k) * z[tri_j(t, k)];
+            g[tri_j(t, k)] += 0.5 * tri_s(t, k) * z[tri_i(t, k)];
+        }
+        CVX_UNROLL for (int a = 0; a < 3; ++a) {
+            CVX_UNROLL for (int b = 0; b < 3; ++b) {
+                // only the six touched indices are non-zero
+                int ia = tri_i(t, a), ja = tri_j(t, a), ib = tri_i(t, b), jb = tri_j(t, b);
+                M[ia * 10 + ib] += (2.0 / 3.0) * g[ia] * g[ib];
+                M[ia * 10 + jb] += (2.0 / 3.0) * g[ia] * g[jb];
+                M[ja * 10 + ib] += (2.0 / 3.0) * g[ja] * g[ib];
+                M[ja * 10 + jb] += (2.0 / 3.0) * g[ja] * g[jb];
+            }
+        }
+    }
+    // diagonal block: projector onto span{row sums, column sums} of D, plus e9 e9^T
+    CVX_UNROLL for (int k = 0; k < 9; ++k)
+        CVX_UNROLL for (int l = 0; l < 9; ++l) {
+            double p = ((k % 3) == (l % 3) ? 1.0 / 3.0 : 0.0) + ((k / 3) == (l / 3) ? 1.0 / 3.0 : 0.0) - 1.0 / 9.0;
+            M[k * 10 + l] += z[k] * p * z[l];
+        }
+    M[99] += z[9] * z[9];
+}
+
+// E <- P_range(E) = E - P_null(E), for E = sym(lam z^T) given implicitly; subtracts the
+// result from S:  S <- S - P_range(sym(lam z^T))
+CVX_HD void sub_range_of_rank2(double *S, const double *lam, const double *z)
+{
+    double E[55];
+    CVX_UNROLL for (int i = 0; i < 10; ++i)
+        CVX_UNROLL for (int j = i; j < 10; ++j) E[sidx(i, j)] = 0.5 * (lam[i] * z[j] + z[i] * lam[j]);
+    double N[55];
+    CVX_UNROLL for (int i = 0; i < 55; ++i) N[i] = E[i];
+    proj_affine(N, true); // N = P_null(E)
+    CVX_UNROLL for (int i = 0; i < 55; ++i) S[i] -= E[i] - N[i];
+}
+
+struct Cert {
+    double R[9];     // polished rotation, row-major
+    double pobj;     // r^T Qs r (trace-normalised units)
+    double zSz;      // z^T S z, |.| ~ 1e-16
+    double min_piv;  // smallest LDL^T pivot of S + delta I
+    double res;      // |S z|_inf
+    bool ok;
+};
+
+// Qs: 45 packed, trace-normalised.  W, Wp: current ADMM iterate and its PSD part.
+// v: unit top eigenvector of Wp (10).  delta: PSD slack.
+CVX_HD void certify(const double *Qs, const double *W, const double *Wp, const double *v, double rho, double delta, Cert &c)
+{
+    c.ok = false;
+    // rank-1 rounding r_c = v[:9] / v[9] (cvxpnpl.py:504-505), then nearest proper rotation
+    double iv = 1.0 / v[9];
+    double M0[9];
+    CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) M0[i * 3 + j] = v[3 * j + i] * iv; // R[i][j] = r[3j+i]
+    double d0 = det3(M0);
+    if (d0 < 0) { CVX_UNROLL for (int i = 0; i < 9; ++i) M0[i] = -M0[i]; } // polish needs SO(3); a reflection cannot certify
+    polar3(M0, c.R, 8);
+    so3_newton(Qs, c.R, 6);
+    double z[10];
+    CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) z[3 * j + i] = c.R[i * 3 + j];
+    z[9] = 1.0;
+    double Qz[9];
+    q9_mul(Qs, z, Qz);
+    c.pobj = 0;
+    CVX_UNROLL for (int i = 0; i < 9; ++i) c.pobj += z[i] * Qz[i];
+    // dual hint S_h = -rho Wm = rho (Wp - W); S1 = S_h - P_null(S_h - Qs)  (in Qs + span A_i)
+    double S[55], T[55];
+    CVX_UNROLL for (int i = 0; i < 55; ++i) { S[i] = rho * (Wp[i] - W[i]); T[i] = S[i]; }
+    CVX_UNROLL for (int i = 0; i < 9; ++i) CVX_UNROLL for (int j = i; j < 9; ++j) T[sidx(i, j)] -= Qs[qidx(i, j)];
+    proj_affine(T, true);
+    CVX_UNROLL for (int i = 0; i < 55; ++i) S[i] -= T[i];
+    // correction: min-norm dS in span A_i with (S - dS) z = 0
+    double rhs[10], Mz[100];
+    sym_mul10(S, z, rhs);
+    build_Mz(z, Mz);
+    // Mz is singular on the 3 tangent directions [vec(R [e_k]x); 0] of SO(3) (|.|^2 = 2):
+    // add their projector so that the system is SPD; rhs has no tangent component at a
+    // stationary point.
+    {
+        double tv[3][10];
+        CVX_UNROLL for (int i = 0; i < 3; ++i) {
+            double c0 = c.R[i * 3], c1 = c.R[i * 3 + 1], c2 = c.R[i * 3 + 2];
+            tv[0][i] = 0;   tv[0][3 + i] = c2;  tv[0][6 + i] = -c1;
+            tv[1][i] = -c2; tv[1][3 + i] = 0;   tv[1][6 + i] = c0;
+            tv[2][i] = c1;  tv[2][3 + i] = -c0; tv[2][6 + i] = 0;
+        }
+        CVX_UNROLL for (int k = 0; k < 3; ++k) {
+            tv[k][9] = 0;
+            CVX_UNROLL for (int i = 0; i < 9; ++i)
+                CVX_UNROLL for (int j = 0; j < 9; ++j) Mz[i * 10 + j] += tv[k][i] * tv[k][j];
+        }
+    }
+    double lam[10];
+    CVX_UNROLL for (int i = 0; i < 10; ++i) lam[i] = rhs[i];
+    bool spd = chol_solve10(Mz, lam);
+    sub_range_of_rank2(S, lam, z);
+    // checks
+    double Sz[10];
+    sym_mul10(S, z, Sz);
+    c.res = 0; c.zSz = 0;
+    CVX_UNROLL for (int i = 0; i < 10; ++i) { c.res = fabs(Sz[i]) > c.res ? fabs(Sz[i]) : c.res; c.zSz += z[i] * Sz[i]; }
+    CVX_UNROLL for (int i = 0; i < 10; ++i) S[sidx(i, i)] += delta;
+    c.min_piv = ldl_min_pivot(S);
+    c.ok = spd && (c.min_piv > 0) && (c.res < 1e-10) && (d0 > 0) && (c.pobj == c.pobj);
+}
+
+// ---------------------------------------------------------------------------------------
+// the solve
+
+struct Solution {
+    double R[9];    // row-major, world -> camera, x_c = R X + t
+    double t[3];
+    double cost;    // ||A r||^2 in the reference's (unnormalised) units
+    double dobj;    // certified lower bound on the SDP optimum (same units); NaN if uncertified
+    int status;
+    int iters;
+    int rank;       // #eig(Z) > 1e-3 at exit (cvxpnpl.py:502)
+    int sweeps;     // total Jacobi sweeps (work counter for the flop model)
+};
+
+// Q9: 45 packed (unnormalised A^T A), B: 3x9.  Zout (optional, 55): final Z in vech order.
+CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution &sol, double *Zout)
+{
+    double tr = 0;
+    CVX_UNROLL for (int i = 0; i < 9; ++i) tr += Q9[qidx(i, i)];
+    sol.sweeps = 0; sol.iters = 0; sol.rank = 0;
+    bool finite = (tr == tr) && (tr > 0) && (tr < 1e300);
+    double Qs[45];
+    double itr = finite ? 1.0 / tr : 0.0;
+    CVX_UNROLL for (int i = 0; i < 45; ++i) { Qs[i] = Q9[i] * itr; finite &= (Qs[i] == Qs[i]); }
+    if (!finite) {
+        CVX_UNROLL for (int i = 0; i < 9; ++i) sol.R[i] = NAN;
+        CVX_UNROLL for (int i = 0; i < 3; ++i) sol.t[i] = NAN;
+        sol.cost = NAN; sol.dobj = NAN; sol.status = ST_NONFINITE;
+        if (Zout) { CVX_UNROLL for (int i = 0; i < 55; ++i) Zout[i] = NAN; }
+        return;
+    }
+    // PSD slack of the certificate: gap <= tr (zSz + 4 delta) <= eps
+    double delta = o.eps / (8.0 * tr);
+    delta = delta < 1e-13 ? 1e-13 : delta;
+    const double irho = 1.0 / o.rho;
+
+    double W[55], Wp[55];
+    CVX_UNROLL for (int i = 0; i < 55; ++i) W[i] = 0;
+    W[sidx(9, 9)] = 1.0;
+    Eig e;
+    Cert c;
+    c.ok = false;
+    int it = 0;
+    bool done = false;
+    double fp_res = 1e300;
+    while (!done) {
+        eig_load(e, W);
+        sol.sweeps += eig_solve(e, o.jacobi_sweeps);
+        eig_pospart(e, Wp);
+        ++it;
+        bool check = (it >= o.first_check) && (((it - o.first_check) % o.check_every) == 0);
+        bool last = (it >= o.max_iters) || (fp_res < o.res_tol);
+        if (check || last) {
+            // top eigenvector of Wp
+            int jm = 0;
+            double best = -1;
+            CVX_UNROLL for (int j = 0; j < 10; ++j) { bool b = e.n2[j] > best; best = b ? e.n2[j] : best; jm = b ? j : jm; }
+            double v[10], il = 1.0 / sqrt(best);
+            CVX_UNROLL for (int i = 0; i < 10; ++i) {
+                double s = 0;
+                CVX_UNROLL for (int j = 0; j < 10; ++j) s = (j == jm) ? e.G[j][i] : s;
+                v[i] = s * il;
+            }
+            certify(Qs, W, Wp, v, o.rho, delta, c);
+            bool gap_ok = c.ok && (tr * (fabs(c.zSz) + 4.0 * delta) <= (o.eps > 8e-13 * tr ? o.eps : 8e-13 * tr));
+            if (gap_ok) {
+                CVX_UNROLL for (int i = 0; i < 9; ++i) sol.R[i] = c.R[i];
+                sol.cost = tr * c.pobj;
+                sol.dobj = tr * (c.pobj - c.zSz - 4.0 * delta);
+                sol.status = ST_CERTIFIED;
+                sol.rank = 1;
+                if (Zout) {
+                    double z[10];
+                    CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) z[3 * j + i] = c.R[i * 3 + j];
+                    z[9] = 1.0;
+                    CVX_UNROLL for (int i = 0; i < 10; ++i) CVX_UNROLL for (int j = i; j < 10; ++j) Zout[sidx(i, j)] = z[i] * z[j];
+                }
+                done = true;
+            } else if (last) {
+                // reference-style recovery from the ADMM iterate Z = Wp (cvxpnpl.py:499-513)
+                int rank = 0;
+                CVX_UNROLL for (int j = 0; j < 10; ++j) rank += (sqrt(e.n2[j]) - e.sigma) > 1e-3;
+                sol.rank = rank;
+                double M0[9], iv = 1.0 / v[9];
+                CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) M0[i * 3 + j] = v[3 * j + i] * iv;
+                polar3(M0, sol.R, 12);
+                double r[9], Qr[9];
+                CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) r[3 * j + i] = sol.R[i * 3 + j];
+                q9_mul(Q9, r, Qr);
+                sol.cost = 0;
+                CVX_UNROLL for (int i = 0; i < 9; ++i) sol.cost += r[i] * Qr[i];
+                sol.dobj = NAN;
+                bool okf = true;
+                CVX_UNROLL for (int i = 0; i < 9; ++i) okf &= (sol.R[i] == sol.R[i]);
+                sol.status = !okf ? ST_NONFINITE : (rank != 1 ? ST_RANK_GT1 : (det3(sol.R) < 0 ? ST_REFLECTION : ST_UNCERTIFIED));
+                if (Zout) { CVX_UNROLL for (int i = 0; i < 55; ++i) Zout[i] = Wp[i]; }
+                done = true;
+            }
+        }
+        if (!done) {
+            // X = Pi_aff(2 Wp - W - Qs / rho);  W <- W + alpha (X - Wp)
+            double X[55];
+            CVX_UNROLL for (int i = 0; i < 55; ++i) X[i] = 2.0 * Wp[i] - W[i];
+            CVX_UNROLL for (int i = 0; i < 9; ++i) CVX_UNROLL for (int j = i; j < 9; ++j) X[sidx(i, j)] -= irho * Qs[qidx(i, j)];
+            proj_affine(X, false);
+            double r2 = 0;
+            CVX_UNROLL for (int i = 0; i < 10; ++i)
+                CVX_UNROLL for (int j = i; j < 10; ++j) {
+                    double d = X[sidx(i, j)] - Wp[sidx(i, j)];
+                    r2 += (i == j ? 1.0 : 2.0) * d * d;
+                    W[sidx(i, j)] += o.alpha * d;
+                }
+            fp_res = sqrt(r2);
+            if (!(fp_res == fp_res)) { // NaN guard
+                CVX_UNROLL for (int i = 0; i < 9; ++i) sol.R[i] = NAN;
+                sol.cost = NAN; sol.dobj = NAN; sol.status = ST_NONFINITE;
+                if (Zout) { CVX_UNROLL for (int i = 0; i < 55; ++i) Zout[i] = NAN; }
+                done = true;
+            }
+        }
+    }
+    sol.iters = it;
+    // t = -B r (cvxpnpl.py:513)
+    {
+        double r[9];
+        CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) r[3 * j + i] = sol.R[i * 3 + j];
+        CVX_UNROLL for (int i = 0; i < 3; ++i) {
+            double acc = 0;
+            CVX_UNROLL for (int j = 0; j < 9; ++j) acc += B[i * 9 + j] * r[j];
+            sol.t[i] = -acc;
+        }
+    }
+}
+
+} // namespace cvx

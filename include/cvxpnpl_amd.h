@@ -1,0 +1,114 @@
+/*
+ * cvxpnpl_amd.h -- C ABI of the MI355X batched absolute-pose SDP solver.
+ *
+ * This is the drop-in boundary for the hot path of SergioRAgostinho/cvxpnpl: everything
+ * cvxpnpl.pnp / pnl / pnpl do between receiving the correspondences and returning poses
+ * (reference cvxpnpl.py:523-627), i.e. constraint assembly (:20-153), translation
+ * elimination (:545-549), the SDP solve the reference delegates to scs.solve (:485-489)
+ * and the pose recovery (:492-520) -- for a whole batch of independent problems in one
+ * launch.  Plain pointers and sizes only; no torch / numpy types.  All device pointers
+ * are HIP device memory on the current device; arrays are contiguous, problem-major,
+ * float64 (the reference computes in float64 throughout).
+ *
+ * The reference has no FFI of its own for this path (it is pure Python calling the scs
+ * C extension); the closest interface is _solve_relaxation(A, B, eps, max_iters, verbose)
+ * (cvxpnpl.py:454-460) and the three public functions.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ */
+#ifndef CVXPNPL_AMD_H
+#define CVXPNPL_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* per-problem outcome, written to status[] (reference behaviour in brackets) */
+enum {
+    CVXPNPL_CERTIFIED = 0,   /* rank-1 pose, certified globally optimal: 0 <= cost - dobj <= eps [no warning] */
+    CVXPNPL_RANK_GT1 = 1,    /* rank(Z) > 1 at the 1e-3 threshold of cvxpnpl.py:502: Z is returned, poses come
+                                from cvxpnpl_recover_multi (cvxpnpl.py:507, 221-343) */
+    CVXPNPL_UNCERTIFIED = 2, /* rank-1 pose, no certificate by max_iters ["not certifiably optimal", :517-519] */
+    CVXPNPL_NONFINITE = 3,   /* degenerate input: NaN pose [NaN sentinel :493-498 / LinAlgError] */
+    CVXPNPL_REFLECTION = 4   /* uncertified and det(U V^T) < 0; returned as is, like the reference (:510-511) */
+};
+
+/* kernel layouts (A/B switch; all produce the same results) */
+enum {
+    CVXPNPL_LAYOUT_AUTO = 0,
+    CVXPNPL_LAYOUT_LANE = 1, /* one problem per lane, 64 problems per wavefront */
+    CVXPNPL_LAYOUT_WAVE = 2  /* one problem per wavefront (cooperative lanes) */
+};
+
+typedef struct {
+    double eps;        /* absolute duality-gap tolerance; reference `eps` (cvxpnpl.py:527), default 1e-9 */
+    int32_t max_iters; /* iteration cap; reference `max_iters` (cvxpnpl.py:528), default 2500 */
+    double rho;        /* ADMM penalty on the trace-normalised cost, default 0.05 */
+    double alpha;      /* over-relaxation, default 1.0 */
+    int32_t first_check; /* first certification attempt after this many iterations, default 5 */
+    int32_t check_every; /* then every this many, default 5 */
+    double res_tol;    /* fixed-point residual at which an uncertifiable problem stops, default 1e-7 */
+    int32_t jacobi_sweeps; /* cap on Jacobi sweeps per PSD projection, default 12 */
+    int32_t layout;    /* CVXPNPL_LAYOUT_* */
+} cvxpnpl_opts_t;
+
+void cvxpnpl_default_opts(cvxpnpl_opts_t *opts);
+
+/*
+ * Solve `batch` independent problems, each with n_p point and n_l line correspondences
+ * (n_l = 0: cvxpnpl.pnp, :523; n_p = 0: cvxpnpl.pnl, :555; both: cvxpnpl.pnpl, :586).
+ *
+ *   d_pts_2d  [batch][n_p][2]      pixels                      (pts_2d,  cvxpnpl.py:524)
+ *   d_pts_3d  [batch][n_p][3]                                  (pts_3d,  cvxpnpl.py:525)
+ *   d_line_2d [batch][n_l][2][2]   (line, sample, xy)          (line_2d, cvxpnpl.py:556)
+ *   d_line_3d [batch][n_l][2][3]   (line, end point, xyz)      (line_3d, cvxpnpl.py:557)
+ *   d_K       [3][3] (K_per_problem = 0) or [batch][3][3]; general, inverted not assumed triangular (:37)
+ * outputs (caller allocated; optional ones may be NULL)
+ *   d_R      [batch][3][3] row-major, world -> camera, x_c = R X + t   (R of cvxpnpl.py:520)
+ *   d_t      [batch][3]                                                 (t of cvxpnpl.py:513)
+ *   d_status [batch] int32   CVXPNPL_*
+ *   d_iters  [batch] int32   iterations used                    (optional)
+ *   d_cost   [batch][2]      ||A r||^2 and the certified lower bound dobj, reference units
+ *                            (the two sides of cvxpnpl.py:517); dobj = NaN if uncertified   (optional)
+ *   d_Z      [batch][55]     vech(Z) in the order of cvxpnpl.py:346-370 -- `results["x"]`
+ *                            of cvxpnpl.py:492                                               (optional)
+ *   d_work   [batch][2] int32 rank at exit, Jacobi sweeps (work counter)                     (optional)
+ * `stream` is a hipStream_t (NULL = default stream).  The call is asynchronous.
+ * Returns 0, or a negative code for launch-level failures only (bad arguments -1,
+ * HIP error -2: see cvxpnpl_last_error); per-problem outcomes are in d_status.
+ */
+int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, const double *d_pts_3d, int32_t n_l,
+                        const double *d_line_2d, const double *d_line_3d, const double *d_K, int32_t K_per_problem,
+                        const cvxpnpl_opts_t *opts, double *d_R, double *d_t, int32_t *d_status, int32_t *d_iters,
+                        double *d_cost, double *d_Z, int32_t *d_work, void *stream);
+
+/*
+ * Host side of the cold path: all poses of a rank > 1 solution (cvxpnpl.py:507 ->
+ * _constraint_ortho_det :221-343 -> _re6q3 :156-218), from Z = vech^-1(x) and B.
+ * Host pointers.  R_out [4][3][3], t_out [4][3].  Returns the number of poses (2 or 4),
+ * 1 for a rank-1 Z, or -1 if rank is 0 / > 4 cannot be handled (reference: NotImplementedError).
+ */
+int cvxpnpl_recover_multi(const double *Z55, const double *B27, double *R_out, double *t_out);
+
+/* Translation maps B (3x9 per problem, t = -B r; cvxpnpl.py:548) for callers that need them
+ * on the host (cvxpnpl_recover_multi).  d_B [batch][27]. */
+int cvxpnpl_assemble_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, const double *d_pts_3d, int32_t n_l,
+                           const double *d_line_2d, const double *d_line_3d, const double *d_K, int32_t K_per_problem,
+                           double *d_B, double *d_Q45, void *stream);
+
+/* HIP-event timing on the launch stream (for bench.py: torch.cuda.Event only sees torch's
+ * current stream).  handles are opaque. */
+void *cvxpnpl_event_create(void);
+int cvxpnpl_event_record(void *event, void *stream);
+int cvxpnpl_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on stop */
+void cvxpnpl_event_destroy(void *event);
+
+const char *cvxpnpl_last_error(void);
+const char *cvxpnpl_version(void);
+int cvxpnpl_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVXPNPL_AMD_H */

@@ -379,15 +379,29 @@ static scs_static_t g_scs;
 static void scs_static_init(void)
 {
     if (g_scs.ready) return;
-    orc_sdp_constraints(g_scs.A, g_scs.b);
-    for (int i = 0; i < NV; ++i)
-        for (int j = 0; j < NV; ++j) {
-            double s = (i == j);
-            for (int r = 0; r < NM; ++r) s += g_scs.A[r * NV + i] * g_scs.A[r * NV + j];
-            g_scs.L[i * NV + j] = s;
+#ifdef _OPENMP
+#pragma omp critical(orc_scs_init)
+#endif
+    {
+        if (!g_scs.ready) {
+            static scs_static_t tmp;
+            orc_sdp_constraints(tmp.A, tmp.b);
+            for (int i = 0; i < NV; ++i)
+                for (int j = 0; j < NV; ++j) {
+                    double s = (i == j);
+                    for (int r = 0; r < NM; ++r) s += tmp.A[r * NV + i] * tmp.A[r * NV + j];
+                    tmp.L[i * NV + j] = s;
+                }
+            chol(NV, tmp.L);
+            memcpy(g_scs.A, tmp.A, sizeof(tmp.A));
+            memcpy(g_scs.b, tmp.b, sizeof(tmp.b));
+            memcpy(g_scs.L, tmp.L, sizeof(tmp.L));
+#ifdef _OPENMP
+#pragma omp flush
+#endif
+            g_scs.ready = 1;
         }
-    chol(NV, g_scs.L);
-    g_scs.ready = 1;
+    }
 }
 
 /* [x;y] = M^-1 [wx; wy],  M = [[I, A^T], [-A, I]]:  x = (I + A^T A)^-1 (wx - A^T wy), y = wy + A x */
@@ -950,6 +964,7 @@ void orc_pnpl_batch(int batch, int n_p, const double *pts_2d, const double *pts_
                     const double *line_3d, const double *K, int K_per_problem, double eps, int max_iters,
                     double *R_out, double *t_out, int *n_poses, int *status, int *iters, double *cost)
 {
+    scs_static_init(); /* before the parallel region */
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 4)
 #endif

@@ -1,0 +1,90 @@
+"""TEST-ONLY host build of the device algorithm (see hostsim.cpp).  Not part of the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libhostsim.so")
+_CSRC = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "cvxpnpl_amd", "csrc")
+_lib = None
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class Opts(C.Structure):
+    _fields_ = [("eps", C.c_double), ("max_iters", C.c_int), ("rho", C.c_double), ("alpha", C.c_double),
+                ("first_check", C.c_int), ("check_every", C.c_int), ("res_tol", C.c_double), ("jacobi_sweeps", C.c_int)]
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, "hostsim.cpp"), os.path.join(_CSRC, "solver_core.h"), os.path.join(_CSRC, "problem_io.h")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off",
+                               "-o", _SO, srcs[0]])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def default_opts(**kw):
+    o = Opts()
+    lib().hs_default_opts(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def solve_batch(pts_2d, pts_3d, line_2d, line_3d, K, opts=None, want_Z=False):
+    a = [np.ascontiguousarray(v, dtype=np.float64) if v is not None else None for v in (pts_2d, pts_3d, line_2d, line_3d)]
+    K = np.ascontiguousarray(K, dtype=np.float64)
+    Bn = len(a[1]) if a[1] is not None else len(a[3])
+    n_p = a[1].shape[1] if a[1] is not None else 0
+    n_l = a[3].shape[1] if a[3] is not None else 0
+    o = opts or default_opts()
+    R, t = np.zeros((Bn, 3, 3)), np.zeros((Bn, 3))
+    st, it, rk, sw = (np.zeros(Bn, np.int32) for _ in range(4))
+    cost = np.zeros((Bn, 2))
+    Z = np.zeros((Bn, 55)) if want_Z else None
+    lib().hs_solve_batch(Bn, n_p, _p(a[0]), _p(a[1]), n_l, _p(a[2]), _p(a[3]), _p(K), int(K.ndim == 3), C.byref(o), _p(R), _p(t),
+                         st.ctypes.data_as(_ip), it.ctypes.data_as(_ip), _p(cost), rk.ctypes.data_as(_ip), sw.ctypes.data_as(_ip), _p(Z))
+    return {"R": R, "t": t, "status": st, "iters": it, "cost": cost, "rank": rk, "sweeps": sw, "Z": Z}
+
+
+def assemble(pts_2d, pts_3d, line_2d, line_3d, K):
+    a = [np.ascontiguousarray(v, dtype=np.float64) if v is not None else None for v in (pts_2d, pts_3d, line_2d, line_3d)]
+    K = np.ascontiguousarray(K, dtype=np.float64)
+    B, Q9 = np.zeros((3, 9)), np.zeros(45)
+    rc = lib().hs_assemble(len(a[1]) if a[1] is not None else 0, _p(a[0]), _p(a[1]), len(a[3]) if a[3] is not None else 0,
+                           _p(a[2]), _p(a[3]), _p(K), _p(B), _p(Q9))
+    Q = np.zeros((9, 9))
+    k = 0
+    for i in range(9):
+        for j in range(i, 9):
+            Q[i, j] = Q[j, i] = Q9[k]
+            k += 1
+    return rc, B, Q
+
+
+def proj_affine(E55, homog):
+    E = np.ascontiguousarray(E55, dtype=np.float64).copy()
+    lib().hs_proj_affine(_p(E), int(homog))
+    return E
+
+
+def pospart(W55):
+    W = np.ascontiguousarray(W55, dtype=np.float64)
+    Wp, lam = np.zeros(55), np.zeros(10)
+    s = lib().hs_pospart(_p(W), _p(Wp), _p(lam))
+    return Wp, lam, s

@@ -1,0 +1,56 @@
+// hostsim.cpp -- TEST-ONLY host build of the device algorithm (cvxpnpl_amd/csrc/solver_core.h).
+// Lets the CPU test-suite step the exact per-lane mathematics of the HIP kernel without a
+// GPU.  Never imported by the cvxpnpl_amd package; built by tests/hostsim/__init__.py.
+#include "../../cvxpnpl_amd/csrc/solver_core.h"
+#include "../../cvxpnpl_amd/csrc/problem_io.h"
+
+extern "C" {
+
+void hs_default_opts(cvx::Opts *o) { *o = cvx::default_opts(); }
+
+// same argument meaning as cvxpnpl_solve_batch (include/cvxpnpl_amd.h), host pointers
+int hs_solve_batch(int batch, int n_p, const double *pts_2d, const double *pts_3d, int n_l, const double *line_2d,
+                   const double *line_3d, const double *K, int K_per_problem, const cvx::Opts *opts,
+                   double *R_out, double *t_out, int *status, int *iters, double *cost, int *rank, int *sweeps, double *Z_out)
+{
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int b = 0; b < batch; ++b) {
+        cvx::ProblemView pv = cvx::make_view(b, n_p, pts_2d, pts_3d, n_l, line_2d, line_3d, K, K_per_problem);
+        cvx::Solution sol;
+        double Z[55];
+        cvx::solve_problem(pv, *opts, sol, Z_out ? Z : nullptr);
+        for (int i = 0; i < 9; ++i) R_out[(size_t)b * 9 + i] = sol.R[i];
+        for (int i = 0; i < 3; ++i) t_out[(size_t)b * 3 + i] = sol.t[i];
+        if (status) status[b] = sol.status;
+        if (iters) iters[b] = sol.iters;
+        if (cost) { cost[2 * (size_t)b] = sol.cost; cost[2 * (size_t)b + 1] = sol.dobj; }
+        if (rank) rank[b] = sol.rank;
+        if (sweeps) sweeps[b] = sol.sweeps;
+        if (Z_out) for (int i = 0; i < 55; ++i) Z_out[(size_t)b * 55 + i] = Z[i];
+    }
+    return 0;
+}
+
+// assembly only: B (27) and Q9 (45 packed)
+int hs_assemble(int n_p, const double *pts_2d, const double *pts_3d, int n_l, const double *line_2d, const double *line_3d,
+                const double *K, double *B, double *Q9)
+{
+    cvx::ProblemView pv = cvx::make_view(0, n_p, pts_2d, pts_3d, n_l, line_2d, line_3d, K, 0);
+    return cvx::assemble(pv, B, Q9) ? 0 : -1;
+}
+
+void hs_proj_affine(double *E, int homog) { cvx::proj_affine(E, homog != 0); }
+
+// eigen test hook: W (55 packed) -> Wp (55), eigenvalues (10)
+int hs_pospart(const double *W, double *Wp, double *lam)
+{
+    cvx::Eig e;
+    cvx::eig_load(e, W);
+    int s = cvx::eig_solve(e, 30);
+    cvx::eig_pospart(e, Wp);
+    for (int j = 0; j < 10; ++j) lam[j] = sqrt(e.n2[j]) - e.sigma;
+    return s;
+}
+
+void hs_polar3(const double *M, double *R, int iters) { cvx::polar3(M, R, iters); }
+}

@@ -1,0 +1,163 @@
+"""The device algorithm (cvxpnpl_amd/csrc/solver_core.h) stepped on the CPU through the
+test-only host build, checked against the oracle and the reference's golden vectors.
+No GPU needed; the GPU parity tests (test_gpu_parity.py) run the same checks through the
+C ABI on the HIP path."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import hostsim  # noqa: E402
+from cvxpnpl_amd import synth  # noqa: E402
+
+# rotation geodesic / relative translation tolerance vs the oracle (float64 path; the oracle's
+# own solve is converged to ~1e-11 residuals)
+TOL_ROT = 1e-6
+TOL_T = 1e-6
+
+
+def unpack55(v):
+    M = np.zeros((10, 10))
+    k = 0
+    for i in range(10):
+        for j in range(i, 10):
+            M[i, j] = M[j, i] = v[k]
+            k += 1
+    return M
+
+
+def pack55(M):
+    return np.array([M[i, j] for i in range(10) for j in range(i, 10)])
+
+
+def test_assembly_matches_reference_g3(golden):
+    """Gram/Schur assembly == the reference's A^T A and B (captured from the reference)."""
+    rc, B, Q = hostsim.assemble(golden["ex_pnp_pts2d"], golden["ex_pnp_pts3d"], None, None, golden["ex_pnp_K"])
+    A = golden["g3_pnp_A"]
+    assert rc == 0
+    np.testing.assert_allclose(B, golden["g3_pnp_B"], atol=1e-11)
+    np.testing.assert_allclose(Q, A.T @ A, atol=1e-13)
+    rc, B, Q = hostsim.assemble(None, None, golden["ex_pnl_line2d"], golden["ex_pnl_line3d"], golden["ex_pnl_K"])
+    A = golden["g3_pnl_A"]
+    np.testing.assert_allclose(B, golden["g3_pnl_B"], atol=1e-11)
+    np.testing.assert_allclose(Q, A.T @ A, atol=1e-13)
+    rc, B, Q = hostsim.assemble(golden["ex_pnpl_pts2d"], golden["ex_pnpl_pts3d"], golden["ex_pnpl_line2d"], golden["ex_pnpl_line3d"],
+                                golden["ex_pnpl_K"])
+    A = golden["g3_pnpl_A"]
+    np.testing.assert_allclose(B, golden["g3_pnpl_B"], atol=1e-11)
+    np.testing.assert_allclose(Q, A.T @ A, atol=1e-13)
+    # the cost vector handed to scs: c = vech(Q, 2) (cvxpnpl.py:486)
+    Q10 = np.zeros((10, 10))
+    Q10[:9, :9] = Q
+    c = np.array([(1 if i == j else 2) * Q10[i, j] for j in range(10) for i in range(j, 10)])
+    np.testing.assert_allclose(c, golden["g3_pnpl_c"], atol=1e-13)
+
+
+def test_affine_projection_matches_reference_constraints(golden):
+    """The closed-form projector == dense projection onto {x : E x = b} built from the
+    reference's own _A, _b (first 22 rows), in the Frobenius geometry of symmetric matrices."""
+    A, b = golden["g4_A"][:22], golden["g4_b"][:22]
+    # reference x = vech (column-major lower) == our packing (row-major upper); weights: off-diagonals count twice
+    wgt = np.array([1.0 if i == j else 2.0 for i in range(10) for j in range(i, 10)])
+    Aw = A / wgt  # <A_i, Z>_F = sum wgt * a_ij z_ij  -> a = A / wgt
+    rs = np.random.RandomState(0)
+    for homog in (False, True):
+        x = rs.normal(size=55)
+        bb = np.zeros(22) if homog else b
+        # minimise sum wgt (y - x)^2 s.t. A y = bb
+        Wi = 1.0 / wgt
+        lam = np.linalg.lstsq(A @ (Wi[:, None] * A.T), A @ x - bb, rcond=None)[0]
+        y = x - Wi * (A.T @ lam)
+        np.testing.assert_allclose(hostsim.proj_affine(x, homog), y, atol=1e-13)
+        np.testing.assert_allclose(A @ hostsim.proj_affine(x, homog), bb, atol=1e-13)
+
+
+def test_psd_projection_matches_numpy():
+    rs = np.random.RandomState(1)
+    for trial in range(20):
+        M = rs.normal(size=(10, 10))
+        M = M + M.T
+        if trial % 4 == 0:  # clustered / rank deficient spectra
+            q, _ = np.linalg.qr(rs.normal(size=(10, 10)))
+            M = (q * np.array([3, 1, 1, 1e-9, 0, 0, -1e-9, -1, -1, -2.0])) @ q.T
+        w, v = np.linalg.eigh(M)
+        Mp = (v * np.maximum(w, 0)) @ v.T
+        Wp, lam, sweeps = hostsim.pospart(pack55(M))
+        np.testing.assert_allclose(unpack55(Wp), Mp, atol=2e-14 * max(1.0, np.abs(w).max()))
+        np.testing.assert_allclose(np.sort(lam), w, atol=2e-14 * max(1.0, np.abs(w).max()))
+        assert sweeps <= 12
+
+
+CASES = [  # (n_p, n_l, sigma, batch)
+    (10, 0, 0.0, 128), (10, 0, 2.0, 128), (5, 5, 0.0, 64), (5, 5, 1.0, 64), (0, 6, 1.0, 48), (6, 0, 1.0, 48),
+]
+
+
+@pytest.mark.parametrize("n_p,n_l,sigma,batch", CASES)
+def test_hostsim_vs_oracle(orc, n_p, n_l, sigma, batch):
+    d = synth.make_pnpl(batch, n_p, n_l, sigma, seed=100 + n_p + 7 * n_l)
+    args = (d["pts_2d"] if n_p else None, d["pts_3d"] if n_p else None, d["line_2d"] if n_l else None, d["line_3d"] if n_l else None)
+    hs = hostsim.solve_batch(*args, d["K"])
+    nb = min(batch, 32)
+    o = orc.pnpl_batch(*(a[:nb] if a is not None else None for a in (args[0], args[2], args[1], args[3])), d["K"],
+                       eps=1e-11, max_iters=200000)
+    ok = (hs["status"][:nb] == 0) & (o["n_poses"] == 1)
+    assert ok.mean() > 0.9
+    geo = synth.geodesic(hs["R"][:nb], o["R"][:, 0])
+    terr = np.linalg.norm(hs["t"][:nb] - o["t"][:, 0], axis=1) / np.linalg.norm(o["t"][:, 0], axis=1)
+    assert geo[ok].max() < TOL_ROT, geo[ok].max()
+    assert terr[ok].max() < TOL_T
+    # certified problems carry a real certificate: 0 <= cost - dobj <= eps
+    c = hs["cost"][hs["status"] == 0]
+    assert (c[:, 0] - c[:, 1] >= -1e-15).all() and (c[:, 0] - c[:, 1] <= 1e-9).all()
+    if sigma == 0.0:
+        assert synth.geodesic(hs["R"], d["R_gt"])[hs["status"] == 0].max() < TOL_ROT
+        assert (hs["status"] == 0).mean() > 0.98
+
+
+def test_examples_known_answer(golden):
+    """examples/pnp.py, pnl.py, pnpl.py through the device algorithm (BASELINE config 1)."""
+    for name, args in (
+        ("pnp", (golden["ex_pnp_pts2d"][None], golden["ex_pnp_pts3d"][None], None, None)),
+        ("pnl", (None, None, golden["ex_pnl_line2d"][None], golden["ex_pnl_line3d"][None])),
+        ("pnpl", (golden["ex_pnpl_pts2d"][None], golden["ex_pnpl_pts3d"][None], golden["ex_pnpl_line2d"][None], golden["ex_pnpl_line3d"][None])),
+    ):
+        hs = hostsim.solve_batch(*args, golden[f"ex_{name}_K"])
+        assert hs["status"][0] == 0
+        assert synth.geodesic(hs["R"][0], golden[f"ex_{name}_R"]) < 1e-6  # literals carry 8 digits
+        tg = golden[f"ex_{name}_t"]
+        assert np.linalg.norm(hs["t"][0] - tg) / np.linalg.norm(tg) < 1e-6
+
+
+def test_certified_Z_satisfies_reference_constraints(golden):
+    """Z returned for certified problems is feasible for the reference's SDP data."""
+    d = synth.make_pnp(16, 10, 1.0, seed=5)
+    hs = hostsim.solve_batch(d["pts_2d"], d["pts_3d"], None, None, d["K"], want_Z=True)
+    A, b = golden["g4_A"][:22], golden["g4_b"][:22]
+    for i in range(16):
+        assert hs["status"][i] == 0
+        np.testing.assert_allclose(A @ hs["Z"][i], b, atol=1e-12)
+        assert np.linalg.eigvalsh(unpack55(hs["Z"][i])).min() > -1e-12
+
+
+def test_uncertifiable_and_degenerate_inputs():
+    # minimal N=4 problems: some are not tight -> rank>1 flagged, never "certified" wrongly
+    d = synth.make_pnp(96, 4, 1.0, seed=9)
+    o = hostsim.default_opts(max_iters=400)
+    hs = hostsim.solve_batch(d["pts_2d"], d["pts_3d"], None, None, d["K"], opts=o, want_Z=True)
+    assert set(np.unique(hs["status"])) <= {0, 1, 2, 4}
+    assert (hs["status"] == 0).mean() > 0.5
+    nz = hs["status"] != 0
+    assert (hs["iters"][nz] <= 400).all()
+    # fewer than the 2 bearings needed for N^T N to be invertible: NaN pose (reference: LinAlgError)
+    d1 = synth.make_pnp(4, 1, 0.0, seed=1)
+    hs = hostsim.solve_batch(d1["pts_2d"], d1["pts_3d"], None, None, d1["K"])
+    assert (hs["status"] == 3).all() and np.isnan(hs["R"]).all() and np.isnan(hs["t"]).all()
+    # NaN input
+    d2 = synth.make_pnp(4, 6, 0.0, seed=2)
+    d2["pts_2d"][1, 0, 0] = np.nan
+    hs = hostsim.solve_batch(d2["pts_2d"], d2["pts_3d"], None, None, d2["K"])
+    assert hs["status"][1] == 3 and np.isnan(hs["R"][1]).all()
+    assert (hs["status"][[0, 2, 3]] == 0).all()
