@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="problems in the CPU baseline sample (0 = auto)")
     ap.add_argument("--layout", type=int, default=0, help="kernel layout (0 auto, 1 lane, 2 wave)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of results when --gpus > 1")
+    ap.add_argument("--opt", action="append", default=[], help="solver option override name=value (diagnostics)")
     args = ap.parse_args()
 
     import torch
@@ -88,7 +89,11 @@ def main():
     iters = torch.empty((batch,), dtype=torch.int32, device=dev)
     cost = torch.empty((batch, 2), dtype=torch.float64, device=dev)
     work = torch.empty((batch, 2), dtype=torch.int32, device=dev)
-    opts = _lib.default_opts(layout=args.layout)
+    over = {}
+    for kv in args.opt:
+        k, v = kv.split("=")
+        over[k] = float(v) if k in ("eps", "rho", "alpha", "res_tol", "jacobi_tol") else int(v)
+    opts = _lib.default_opts(layout=args.layout, **over)
     ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else C.c_void_p(0)  # noqa: E731
     stream = torch.cuda.current_stream(dev)
     sh = C.c_void_p(stream.cuda_stream)

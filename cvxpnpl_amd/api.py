@@ -63,10 +63,10 @@ def pnpl_batch(pts_2d, line_2d, pts_3d, line_3d, K, eps: float = 1e-9, max_iters
     device = torch.device(device)
     p3 = _as_dev(pts_3d, device, (3,)) if pts_3d is not None else None
     l3 = _as_dev(line_3d, device, (2, 3)) if line_3d is not None else None
-    n_p = p3.shape[-2] if p3 is not None and p3.numel() else 0
-    n_l = l3.shape[-3] if l3 is not None and l3.numel() else 0
+    n_p = p3.shape[-2] if p3 is not None and p3.dim() >= 3 else 0
+    n_l = l3.shape[-3] if l3 is not None and l3.dim() >= 4 else 0
     if n_p == 0 and n_l == 0:
-        raise ValueError("need at least one point or line correspondence")
+        raise ValueError("need at least one point or line correspondence ([B,n,3] points / [B,n,2,3] lines)")
     batch = (p3 if n_p else l3).shape[0]
     p2 = _as_dev(pts_2d, device, (2,)).reshape(batch, n_p, 2) if n_p else None
     p3 = p3.reshape(batch, n_p, 3) if n_p else None

@@ -7,6 +7,7 @@
 #include "../../include/cvxpnpl_amd.h"
 #include "problem_io.h"
 #include "solver_core.h"
+#include "wave_kernel.h"
 
 namespace {
 
@@ -69,7 +70,7 @@ cvx::Opts to_core(const cvxpnpl_opts_t *opts)
     if (opts) {
         o.eps = opts->eps; o.max_iters = opts->max_iters; o.rho = opts->rho; o.alpha = opts->alpha;
         o.first_check = opts->first_check; o.check_every = opts->check_every; o.res_tol = opts->res_tol;
-        o.jacobi_sweeps = opts->jacobi_sweeps;
+        o.jacobi_sweeps = opts->jacobi_sweeps; o.jacobi_tol = opts->jacobi_tol;
     }
     return o;
 }
@@ -83,7 +84,7 @@ void cvxpnpl_default_opts(cvxpnpl_opts_t *opts)
     cvx::Opts o = cvx::default_opts();
     opts->eps = o.eps; opts->max_iters = o.max_iters; opts->rho = o.rho; opts->alpha = o.alpha;
     opts->first_check = o.first_check; opts->check_every = o.check_every; opts->res_tol = o.res_tol;
-    opts->jacobi_sweeps = o.jacobi_sweeps; opts->layout = CVXPNPL_LAYOUT_AUTO;
+    opts->jacobi_sweeps = o.jacobi_sweeps; opts->jacobi_tol = o.jacobi_tol; opts->layout = CVXPNPL_LAYOUT_AUTO;
 }
 
 static int check_args(int64_t batch, int32_t n_p, const double *p2, const double *p3, int32_t n_l, const double *l2,
@@ -101,6 +102,7 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
                         const cvxpnpl_opts_t *opts, double *d_R, double *d_t, int32_t *d_status, int32_t *d_iters,
                         double *d_cost, double *d_Z, int32_t *d_work, void *stream)
 {
+    if (batch == 0) return 0; /* empty batch: nothing to do (pointers may be NULL) */
     if (check_args(batch, n_p, d_pts_2d, d_pts_3d, n_l, d_line_2d, d_line_3d, d_K)) return -1;
     if (!d_R || !d_t || !d_status) { snprintf(g_err, sizeof(g_err), "cvxpnpl: R, t and status outputs are required"); return -1; }
     if (opts && (opts->max_iters < 1 || !(opts->rho > 0) || !(opts->eps > 0) || opts->check_every < 1 || opts->first_check < 1)) {
@@ -117,9 +119,21 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
     const int block = 64;
     int64_t grid = (batch + block - 1) / block;
     if (grid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }
-    hipLaunchKernelGGL(solve_lane_kernel, dim3((unsigned)grid), dim3(block), 0, s, a, o);
+    int layout = opts ? opts->layout : CVXPNPL_LAYOUT_AUTO;
+    if (layout == CVXPNPL_LAYOUT_AUTO) layout = CVXPNPL_LAYOUT_WAVE;
+    if (layout == CVXPNPL_LAYOUT_WAVE) {
+        cvxw::WaveArgs w;
+        w.batch = batch; w.n_p = n_p; w.n_l = n_l; w.K_per_problem = K_per_problem;
+        w.p2 = d_pts_2d; w.p3 = d_pts_3d; w.l2 = d_line_2d; w.l3 = d_line_3d; w.K = d_K;
+        w.R = d_R; w.t = d_t; w.cost = d_cost; w.Z = d_Z; w.status = d_status; w.iters = d_iters; w.work = d_work;
+        int64_t wgrid = (batch + cvxw::WPB - 1) / cvxw::WPB;
+        if (wgrid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }
+        hipLaunchKernelGGL(cvxw::solve_wave_kernel, dim3((unsigned)wgrid), dim3(64 * cvxw::WPB), 0, s, w, o);
+    } else {
+        hipLaunchKernelGGL(solve_lane_kernel, dim3((unsigned)grid), dim3(block), 0, s, a, o);
+    }
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return set_err("solve_lane_kernel launch", e);
+    if (e != hipSuccess) return set_err("solve kernel launch", e);
     return 0;
 }
 

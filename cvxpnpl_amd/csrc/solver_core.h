@@ -57,13 +57,14 @@ struct Opts {
     int check_every;   // then every this many
     double res_tol;    // fixed-point residual below which an uncertified solve stops
     int jacobi_sweeps; // cap on Jacobi sweeps per PSD projection
+    double jacobi_tol; // a sweep whose largest |cos(g_p, g_q)| is below this ends the eigen-solve
 };
 
 CVX_HD Opts default_opts()
 {
     Opts o;
     o.eps = 1e-9; o.max_iters = 2500; o.rho = 0.05; o.alpha = 1.0;
-    o.first_check = 5; o.check_every = 5; o.res_tol = 1e-7; o.jacobi_sweeps = 12;
+    o.first_check = 3; o.check_every = 1; o.res_tol = 1e-5; o.jacobi_sweeps = 12; o.jacobi_tol = 3e-2;
     return o;
 }
 
@@ -290,20 +291,50 @@ CVX_HD void eig_norms(Eig &e)
     }
 }
 
-// one rotation of columns p, q; returns true if it was larger than the threshold
-CVX_HD bool eig_rotate(Eig &e, int p, int q, double tol2)
+// Rotation parameters of one one-sided Jacobi step from al = |g_p|^2, be = |g_q|^2,
+// gam = g_p . g_q:  t = tan(theta), c = cos, s = sin with  tan(2 theta) = 2 gam / (be - al).
+// The rotation is exactly orthogonal (c^2 + s^2 = 1 to rounding) for ANY t, so t may be
+// approximate; c is refined to full double precision.  Device build: v_rsq_f64 /
+// v_rcp_f64 seeds + Newton steps instead of the IEEE sqrt / divide expansions.
+CVX_HD void jacobi_cs(double al, double be, double gam, bool rot, double &c, double &s, double &t)
+{
+    const double d = be - al, g2 = 2.0 * gam;
+    const double h2 = d * d + g2 * g2 + 1e-290;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(h2);
+    { double hh = 0.5 * h2 * y; double e = fma(-hh, y, 0.5); y = fma(y, e, y); }
+    const double h = h2 * y;
+    const double den = fabs(d) + h;
+    double r = __builtin_amdgcn_rcp(den);
+    { double e = fma(-den, r, 1.0); r = fma(r, e, r); }
+    double tt = g2 * r;
+#else
+    const double h = sqrt(h2);
+    double tt = g2 / (fabs(d) + h);
+#endif
+    tt = d < 0 ? -tt : tt;
+    t = rot ? tt : 0.0;
+    const double x = 1.0 + t * t;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double z = __builtin_amdgcn_rsq(x);
+    { double hh = 0.5 * x * z; double e = fma(-hh, z, 0.5); z = fma(z, e, z); }
+    { double hh = 0.5 * x * z; double e = fma(-hh, z, 0.5); z = fma(z, e, z); }
+    c = z;
+#else
+    c = 1.0 / sqrt(x);
+#endif
+    s = t * c;
+}
+
+// one rotation of columns p, q; returns gam^2 / (al be), the squared cosine between them
+CVX_HD double eig_rotate(Eig &e, int p, int q)
 {
     double gam = 0;
     CVX_UNROLL for (int i = 0; i < 10; ++i) gam += e.G[p][i] * e.G[q][i];
     double al = e.n2[p], be = e.n2[q];
-    bool big = gam * gam > tol2 * al * be;
-    // tan of the rotation angle from  d = be - al, g2 = 2 gam  (no division by gam)
-    double d = be - al, g2 = 2.0 * gam;
-    double h = sqrt(d * d + g2 * g2);
-    double ad = fabs(d);
-    double t = (big ? g2 : 0.0) / (ad + h + 1e-300);
-    t = d < 0 ? -t : t;
-    double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+    const double g2 = gam * gam, ab = al * be;
+    double c, s, t;
+    jacobi_cs(al, be, gam, g2 > 1e-30 * ab, c, s, t);
     CVX_UNROLL for (int i = 0; i < 10; ++i) {
         double gp = e.G[p][i], gq = e.G[q][i];
         e.G[p][i] = c * gp - s * gq;
@@ -311,20 +342,21 @@ CVX_HD bool eig_rotate(Eig &e, int p, int q, double tol2)
     }
     e.n2[p] = al - t * gam;
     e.n2[q] = be + t * gam;
-    return big;
+    return g2 / ab;
 }
 
-// cyclic sweeps until no rotation exceeds the threshold (or max_sweeps)
-CVX_HD int eig_solve(Eig &e, int max_sweeps)
+// cyclic sweeps until the largest squared cosine met in a sweep is below tol2 (quadratic
+// convergence: the columns are then orthogonal to ~tol2 after that sweep), or max_sweeps
+CVX_HD int eig_solve(Eig &e, int max_sweeps, double tol2)
 {
-    const double tol2 = 1e-30;
     int sweeps = 0;
-    for (; sweeps < max_sweeps; ++sweeps) {
+    for (; sweeps < max_sweeps;) {
         eig_norms(e);
-        bool any = false;
+        double worst = 0;
         CVX_UNROLL for (int p = 0; p < 9; ++p)
-            CVX_UNROLL for (int q = p + 1; q < 10; ++q) any |= eig_rotate(e, p, q, tol2);
-        if (!any) break;
+            CVX_UNROLL for (int q = p + 1; q < 10; ++q) { double r = eig_rotate(e, p, q); worst = r > worst ? r : worst; }
+        ++sweeps;
+        if (!(worst > tol2)) break;
     }
     eig_norms(e);
     return sweeps;
@@ -371,6 +403,8 @@ CVX_HD void so3_newton(const double *Q9, double *R, int iters)
         CVX_UNROLL for (int i = 0; i < 3; ++i)
             CVX_UNROLL for (int j = 0; j < 3; ++j) N[i * 3 + j] = R[0 * 3 + i] * Qr[3 * j] + R[1 * 3 + i] * Qr[3 * j + 1] + R[2 * 3 + i] * Qr[3 * j + 2];
         double g[3] = {2 * (N[7] - N[5]), 2 * (N[2] - N[6]), 2 * (N[3] - N[1])};
+        // converged: projected gradient at rounding level (Q is trace-normalised, |R| = O(1))
+        if (it >= 2 && fabs(g[0]) + fabs(g[1]) + fabs(g[2]) < 1e-15) break;
         // a_k = vec(R [e_k]x): columns (0, c2, -c1), (-c2, 0, c0), (c1, -c0, 0)
         double a[3][9], Qa[3][9];
         CVX_UNROLL for (int i = 0; i < 3; ++i) {
@@ -598,6 +632,10 @@ CVX_HD void certify(const double *Qs, const double *W, const double *Wp, const d
 // ---------------------------------------------------------------------------------------
 // the solve
 
+// certification attempts: at first_check, then spaced check_every * (1 + it / 8) apart --
+// every iteration while most problems finish, sparser for the slow tail.
+CVX_HD int next_check_after(int it, const Opts &o) { return it + o.check_every * (1 + it / 8); }
+
 struct Solution {
     double R[9];    // row-major, world -> camera, x_c = R X + t
     double t[3];
@@ -608,6 +646,28 @@ struct Solution {
     int rank;       // #eig(Z) > 1e-3 at exit (cvxpnpl.py:502)
     int sweeps;     // total Jacobi sweeps (work counter for the flop model)
 };
+
+// reference-style recovery from an uncertified ADMM iterate Z = Wp (cvxpnpl.py:499-513):
+// v is the unit top eigenvector of Z, rank = #eig(Z) > 1e-3.  R = U V^T of the rank-1
+// ratio (no determinant correction, cvxpnpl.py:510-511); rank > 1 is flagged for the host
+// multi-solution recovery.
+CVX_HD void fallback_pose(const double *Qs, double tr, const double *v, int rank, Solution &sol)
+{
+    sol.rank = rank;
+    double M0[9], iv = 1.0 / v[9];
+    CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) M0[i * 3 + j] = v[3 * j + i] * iv;
+    polar3(M0, sol.R, 12);
+    double r[9], Qr[9];
+    CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) r[3 * j + i] = sol.R[i * 3 + j];
+    q9_mul(Qs, r, Qr);
+    double c = 0;
+    CVX_UNROLL for (int i = 0; i < 9; ++i) c += r[i] * Qr[i];
+    sol.cost = tr * c;
+    sol.dobj = NAN;
+    bool okf = true;
+    CVX_UNROLL for (int i = 0; i < 9; ++i) okf &= (sol.R[i] == sol.R[i]);
+    sol.status = !okf ? ST_NONFINITE : (rank != 1 ? ST_RANK_GT1 : (det3(sol.R) < 0 ? ST_REFLECTION : ST_UNCERTIFIED));
+}
 
 // Q9: 45 packed (unnormalised A^T A), B: 3x9.  Zout (optional, 55): final Z in vech order.
 CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution &sol, double *Zout)
@@ -637,15 +697,15 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
     Eig e;
     Cert c;
     c.ok = false;
-    int it = 0;
+    int it = 0, next_check = o.first_check;
     bool done = false;
     double fp_res = 1e300;
     while (!done) {
         eig_load(e, W);
-        sol.sweeps += eig_solve(e, o.jacobi_sweeps);
+        sol.sweeps += eig_solve(e, o.jacobi_sweeps, o.jacobi_tol * o.jacobi_tol);
         eig_pospart(e, Wp);
         ++it;
-        bool check = (it >= o.first_check) && (((it - o.first_check) % o.check_every) == 0);
+        bool check = it >= next_check;
         bool last = (it >= o.max_iters) || (fp_res < o.res_tol);
         if (check || last) {
             // top eigenvector of Wp
@@ -659,6 +719,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                 v[i] = s * il;
             }
             certify(Qs, W, Wp, v, o.rho, delta, c);
+            next_check = next_check_after(it, o);
             bool gap_ok = c.ok && (tr * (fabs(c.zSz) + 4.0 * delta) <= (o.eps > 8e-13 * tr ? o.eps : 8e-13 * tr));
             if (gap_ok) {
                 CVX_UNROLL for (int i = 0; i < 9; ++i) sol.R[i] = c.R[i];
@@ -674,22 +735,9 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                 }
                 done = true;
             } else if (last) {
-                // reference-style recovery from the ADMM iterate Z = Wp (cvxpnpl.py:499-513)
                 int rank = 0;
                 CVX_UNROLL for (int j = 0; j < 10; ++j) rank += (sqrt(e.n2[j]) - e.sigma) > 1e-3;
-                sol.rank = rank;
-                double M0[9], iv = 1.0 / v[9];
-                CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) M0[i * 3 + j] = v[3 * j + i] * iv;
-                polar3(M0, sol.R, 12);
-                double r[9], Qr[9];
-                CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) r[3 * j + i] = sol.R[i * 3 + j];
-                q9_mul(Q9, r, Qr);
-                sol.cost = 0;
-                CVX_UNROLL for (int i = 0; i < 9; ++i) sol.cost += r[i] * Qr[i];
-                sol.dobj = NAN;
-                bool okf = true;
-                CVX_UNROLL for (int i = 0; i < 9; ++i) okf &= (sol.R[i] == sol.R[i]);
-                sol.status = !okf ? ST_NONFINITE : (rank != 1 ? ST_RANK_GT1 : (det3(sol.R) < 0 ? ST_REFLECTION : ST_UNCERTIFIED));
+                fallback_pose(Qs, tr, v, rank, sol);
                 if (Zout) { CVX_UNROLL for (int i = 0; i < 55; ++i) Zout[i] = Wp[i]; }
                 done = true;
             }
@@ -708,6 +756,15 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                     W[sidx(i, j)] += o.alpha * d;
                 }
             fp_res = sqrt(r2);
+#ifdef CVX_TRACE
+            {
+                double lam[10];
+                for (int j = 0; j < 10; ++j) lam[j] = sqrt(e.n2[j]) - e.sigma;
+                for (int a = 0; a < 10; ++a) for (int b = a + 1; b < 10; ++b) if (lam[b] > lam[a]) { double t_ = lam[a]; lam[a] = lam[b]; lam[b] = t_; }
+                if (it <= 30 || it % 50 == 0)
+                    printf("it %4d fp_res %.3e eig+ %.4f %.4f %.4f %.4f  eig- %.2e  cert: ok=%d minpiv %.2e res %.1e pobj %.3e\n", it, fp_res, lam[0], lam[1], lam[2], lam[3], lam[9], (int)c.ok, c.min_piv, c.res, c.pobj);
+            }
+#endif
             if (!(fp_res == fp_res)) { // NaN guard
                 CVX_UNROLL for (int i = 0; i < 9; ++i) sol.R[i] = NAN;
                 sol.cost = NAN; sol.dobj = NAN; sol.status = ST_NONFINITE;

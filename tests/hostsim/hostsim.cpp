@@ -46,7 +46,7 @@ int hs_pospart(const double *W, double *Wp, double *lam)
 {
     cvx::Eig e;
     cvx::eig_load(e, W);
-    int s = cvx::eig_solve(e, 30);
+    int s = cvx::eig_solve(e, 30, 1e-30);
     cvx::eig_pospart(e, Wp);
     for (int j = 0; j < 10; ++j) lam[j] = sqrt(e.n2[j]) - e.sigma;
     return s;

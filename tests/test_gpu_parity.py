@@ -38,14 +38,16 @@ def _solve(gpu, d, n_p, n_l, **kw):
 
 
 CASES = [(10, 0, 0.0, 256), (10, 0, 2.0, 256), (5, 5, 0.0, 128), (5, 5, 1.0, 128), (0, 6, 1.0, 64), (6, 0, 1.0, 64), (4, 0, 1.0, 64)]
+LAYOUTS = {"lane": 1, "wave": 2}  # CVXPNPL_LAYOUT_*
 
 
+@pytest.mark.parametrize("layout", sorted(LAYOUTS))
 @pytest.mark.parametrize("n_p,n_l,sigma,batch", CASES)
-def test_hip_vs_oracle(gpu, orc, n_p, n_l, sigma, batch):
+def test_hip_vs_oracle(gpu, orc, n_p, n_l, sigma, batch, layout):
     from cvxpnpl_amd import synth
 
     d = synth.make_pnpl(batch, n_p, n_l, sigma, seed=200 + n_p + 7 * n_l)
-    r = _solve(gpu, d, n_p, n_l)
+    r = _solve(gpu, d, n_p, n_l, layout=LAYOUTS[layout])
     nb = min(batch, 48)
     o = orc.pnpl_batch(d["pts_2d"][:nb] if n_p else None, d["line_2d"][:nb] if n_l else None, d["pts_3d"][:nb] if n_p else None,
                        d["line_3d"][:nb] if n_l else None, d["K"], eps=1e-11, max_iters=200000)
@@ -72,13 +74,15 @@ def test_hip_equals_host_build_of_device_algorithm(gpu):
     from cvxpnpl_amd import synth
 
     d = synth.make_pnp(512, 10, 1.0, seed=77)
-    r = _solve(gpu, d, 10, 0, want_Z=True)
     hs = hostsim.solve_batch(d["pts_2d"], d["pts_3d"], None, None, d["K"], want_Z=True)
-    assert (r["status"] == hs["status"]).mean() > 0.99
-    same = (r["status"] == 0) & (hs["status"] == 0)
-    assert synth.geodesic(r["R"], hs["R"])[same].max() < 1e-10
-    assert np.abs(r["t"] - hs["t"])[same].max() < 1e-10
-    assert np.abs(r["Z"] - hs["Z"])[same].max() < 1e-9
+    for layout in LAYOUTS.values():
+        r = _solve(gpu, d, 10, 0, want_Z=True, layout=layout)
+        assert (r["status"] == hs["status"]).mean() > 0.99
+        same = (r["status"] == 0) & (hs["status"] == 0)
+        assert synth.geodesic(r["R"], hs["R"])[same].max() < 1e-10
+        assert np.abs(r["t"] - hs["t"])[same].max() < 1e-10
+        assert np.abs(r["Z"] - hs["Z"])[same].max() < 1e-9
+        assert np.abs(r["iters"] - hs["iters"])[same].mean() < 0.1  # same algorithm, same path
 
 
 def test_examples_known_answer_single_problem_api(gpu, golden):
@@ -170,17 +174,18 @@ def test_edge_cases(gpu):
     r = _solve(gpu, d2, 6, 0)
     assert r["status"][64] == 3 and (np.delete(r["status"], 64) == 0).all()
     # ragged batch sizes around the wavefront size, and empty batch
-    for b in (1, 63, 64, 65):
-        d = synth.make_pnp(b, 10, 0.0, seed=b)
-        r = _solve(gpu, d, 10, 0)
-        assert (r["status"] == 0).all() and synth.geodesic(r["R"], d["R_gt"]).max() < TOL_ROT
+    for layout in LAYOUTS.values():
+        for b in (1, 3, 4, 5, 63, 64, 65):
+            d = synth.make_pnp(b, 10, 0.0, seed=b)
+            r = _solve(gpu, d, 10, 0, layout=layout)
+            assert (r["status"] == 0).all() and synth.geodesic(r["R"], d["R_gt"]).max() < TOL_ROT
     res = ca.pnp_batch(torch.zeros((0, 10, 2), device=gpu, dtype=torch.float64), torch.zeros((0, 10, 3), device=gpu, dtype=torch.float64),
                        torch.eye(3, device=gpu, dtype=torch.float64))
     assert res.R.shape == (0, 3, 3)
     # large N (scalability benchmark of the reference goes to 1e4 correspondences)
     d = synth.make_pnp(8, 2000, 1.0, seed=4)
     r = _solve(gpu, d, 2000, 0)
-    assert (r["status"] == 0).all() and synth.geodesic(r["R"], d["R_gt"]).max() < 1e-3
+    assert (r["status"] == 0).all() and synth.geodesic(r["R"], d["R_gt"]).max() < 5e-3  # 1 px noise, statistical
     # invalid arguments are launch-level errors
     with pytest.raises(ValueError):
         ca.pnp_batch(None, None, np.eye(3))
