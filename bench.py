@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--layout", type=int, default=0, help="kernel layout (0 auto, 1 lane, 2 wave)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of results when --gpus > 1")
     ap.add_argument("--opt", action="append", default=[], help="solver option override name=value (diagnostics)")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the steps are issued round-robin on (1 = the contract's "
+                    "back-to-back steps; >1 lets independent batches overlap, reported in config)")
     args = ap.parse_args()
 
     import torch
@@ -98,21 +100,30 @@ def main():
     stream = torch.cuda.current_stream(dev)
     sh = C.c_void_p(stream.cuda_stream)
 
+    from cvxpnpl_amd import dist as cdist
+
     gather = world > 1 and not args.no_gather
-    if gather:
-        packed = torch.empty((batch, 13), dtype=torch.float64, device=dev)
-        gathered = torch.empty((world * batch, 13), dtype=torch.float64, device=dev)
+    gathered = torch.empty((world * batch, cdist.PACK), dtype=torch.float64, device=dev) if gather else None
+    nstreams = max(1, args.streams)
+    streams = [stream] + [torch.cuda.Stream(dev) for _ in range(nstreams - 1)]
+    # one output set per stream so that overlapping steps do not write the same buffers
+    outs = [(R, t, status, iters, cost, work)] + [tuple(torch.empty_like(x) for x in (R, t, status, iters, cost, work))
+                                                   for _ in range(nstreams - 1)]
+    step_no = [0]
 
     def step():
-        rc = L.cvxpnpl_solve_batch(batch, n_p, ptr(p2), ptr(p3), n_l, ptr(l2), ptr(l3), ptr(K), 0, C.byref(opts),
-                                   ptr(R), ptr(t), ptr(status), ptr(iters), ptr(cost), C.c_void_p(0), ptr(work), sh)
-        if rc != 0:
-            raise RuntimeError(_lib.last_error())
-        if gather:  # north-star config 4: results of every shard on every rank
-            packed[:, :9] = R.view(batch, 9)
-            packed[:, 9:12] = t
-            packed[:, 12] = status.double()
-            dist.all_gather_into_tensor(gathered, packed)
+        k = step_no[0] % nstreams
+        step_no[0] += 1
+        sR, st_, sst, sit, sco, swk = outs[k]
+        with torch.cuda.stream(streams[k]):
+            rc = L.cvxpnpl_solve_batch(batch, n_p, ptr(p2), ptr(p3), n_l, ptr(l2), ptr(l3), ptr(K), 0, C.byref(opts),
+                                       ptr(sR), ptr(st_), ptr(sst), ptr(sit), ptr(sco), C.c_void_p(0), ptr(swk),
+                                       C.c_void_p(streams[k].cuda_stream))
+            if rc != 0:
+                raise RuntimeError(_lib.last_error())
+            if gather:  # north-star config 4: results of every shard on every rank (RCCL over xGMI)
+                cdist.gather_results(cdist.pack_results(sR, st_, sst), world * batch, out=gathered)
+        return k
 
     def barrier():
         if world > 1:
@@ -127,15 +138,19 @@ def main():
     t0 = time.perf_counter()
     L.cvxpnpl_event_record(ev[0], sh)
     for k in range(args.steps):
-        step()
-        L.cvxpnpl_event_record(ev[k + 1], sh)
+        ks = step()
+        L.cvxpnpl_event_record(ev[k + 1], C.c_void_p(streams[ks].cuda_stream))
     barrier()
     elapsed = time.perf_counter() - t0
     ms = C.c_float()
     launch_ms = []
-    for k in range(args.steps):
-        L.cvxpnpl_event_elapsed_ms(ev[k], ev[k + 1], C.byref(ms))
-        launch_ms.append(ms.value)
+    if nstreams == 1:
+        for k in range(args.steps):
+            L.cvxpnpl_event_elapsed_ms(ev[k], ev[k + 1], C.byref(ms))
+            launch_ms.append(ms.value)
+    else:  # overlapping launches: only the aggregate span is meaningful
+        L.cvxpnpl_event_elapsed_ms(ev[0], ev[args.steps], C.byref(ms))
+        launch_ms = [ms.value / args.steps]
     for e in ev:
         L.cvxpnpl_event_destroy(e)
     if world > 1:
@@ -157,15 +172,22 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": args.workload, "n_points": n_p, "n_lines": n_l, "problems_per_gpu_per_step": batch,
                    "pixel_noise_sigma": sigma, "eps": opts.eps, "max_iters": opts.max_iters,
+                   "streams": nstreams,
                    "parallelism": f"batch-sharded x{world}" + (", RCCL all_gather of results" if gather else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                     "traffic": None, "kernel": "solve_lane_kernel", "mean_launch_ms": 1e3 * mean_launch_s,
+                     "traffic": None, "kernel": "solve_wave_kernel" if opts.layout in (0, 2) else "solve_lane_kernel", "mean_launch_ms": 1e3 * mean_launch_s,
                      "algorithmic_bytes_per_problem": algorithmic_bytes(n_p, n_l),
                      "note": "VALU/latency-bound by construction (~500 B and ~1e5-1e6 flop per pose), see DESIGN.md"},
         "solver": {"certified_frac": float((st == 0).mean()), "status_hist": np.bincount(st, minlength=5).tolist(),
                    "mean_iters": float(it.mean()), "max_iters_seen": int(it.max()),
                    "mean_jacobi_sweeps": float(wk[:, 1].mean())},
     }
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):  # HBM bytes per launch from the rocprofv3 --pmc passes (profiles/README.md)
+        pmc = json.load(open(pmc_path)).get(f"{args.workload}:{batch}")
+        if pmc:
+            out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = pmc["source"]
     if sigma == 0.0:
         geo = synth.geodesic(R.cpu().numpy(), d["R_gt"])
         out["solver"]["max_rot_err_vs_gt_rad"] = float(geo[st == 0].max())

@@ -24,7 +24,7 @@
 
 namespace cvxw {
 
-constexpr int WPB = 4; // waves (= problems) per 256-thread block
+constexpr int WPB = 1; // waves (= problems) per block: 1, so a finished problem frees its SIMD slot at once
 
 // LDS slice per wave, in doubles (all offsets even => 16-byte aligned)
 constexpr int L_P = 0;      // 64   per-lane products for 10-lane reductions

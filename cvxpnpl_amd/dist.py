@@ -1,0 +1,92 @@
+"""Multi-GPU: shard the batch across the ranks of one node, gather the poses over RCCL.
+
+The path partitions trivially -- problems are independent, the only shared data are
+read-only constants -- so every rank solves a contiguous slice with no data-path
+collective; the one exchange step is the gather of the results (north-star config 4:
+"1M PnP problems sharded across 8 MI355X, RCCL gather over xGMI"): 13 doubles per pose
+(R, t, status).  One process per GPU, `torch.distributed` backend "nccl" (= RCCL on ROCm);
+the same code runs on "gloo" for the CPU tests.
+"""
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+PACK = 13  # R (9) + t (3) + status (1)
+
+
+def shard_range(batch: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced slice [lo, hi) of `batch` problems owned by `rank`."""
+    base, rem = divmod(batch, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_results(R: torch.Tensor, t: torch.Tensor, status: torch.Tensor) -> torch.Tensor:
+    n = R.shape[0]
+    out = torch.empty((n, PACK), dtype=torch.float64, device=R.device)
+    out[:, :9] = R.reshape(n, 9)
+    out[:, 9:12] = t
+    out[:, 12] = status.to(torch.float64)
+    return out
+
+
+def unpack_results(packed: torch.Tensor):
+    n = packed.shape[0]
+    return packed[:, :9].reshape(n, 3, 3), packed[:, 9:12], packed[:, 12].to(torch.int32)
+
+
+def gather_results(packed_local: torch.Tensor, batch: int, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """All-gather the per-rank [n_r, 13] slices into the full [batch, 13] on every rank.
+
+    Equal slices use one all_gather_into_tensor (a single RCCL collective; 13 MB per rank
+    for config 4 -- a direct exchange over the 7 xGMI links, far below a millisecond);
+    ragged slices are padded to the largest one.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    sizes = [shard_range(batch, r, world)[1] - shard_range(batch, r, world)[0] for r in range(world)]
+    assert packed_local.shape[0] == sizes[rank], (packed_local.shape, sizes, rank)
+    nmax = max(sizes)
+    dev = packed_local.device
+    if out is None:
+        out = torch.empty((batch, PACK), dtype=torch.float64, device=dev)
+    if all(s == nmax for s in sizes):
+        if dist.get_backend(group) == "nccl":
+            dist.all_gather_into_tensor(out, packed_local.contiguous(), group=group)
+        else:
+            chunks = list(out.split(nmax))
+            dist.all_gather(chunks, packed_local.contiguous(), group=group)
+        return out
+    buf = torch.zeros((nmax, PACK), dtype=torch.float64, device=dev)
+    buf[: sizes[rank]] = packed_local
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf, group=group)
+    lo = 0
+    for r in range(world):
+        out[lo:lo + sizes[r]] = parts[r][: sizes[r]]
+        lo += sizes[r]
+    return out
+
+
+def solve_sharded(pts_2d, line_2d, pts_3d, line_3d, K, group=None, solver: Optional[Callable] = None, **kw):
+    """Every rank holds (or can index) the full inputs; it solves its own slice and all ranks
+    end with the full R [B,3,3], t [B,3], status [B].  `solver` defaults to
+    cvxpnpl_amd.pnpl_batch (HIP); tests inject a CPU stand-in to exercise the sharding and
+    the collective on gloo."""
+    if solver is None:
+        from .api import pnpl_batch as solver
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    ref = pts_3d if pts_3d is not None else line_3d
+    batch = ref.shape[0]
+    lo, hi = shard_range(batch, rank, world)
+
+    def sl(x):
+        return None if x is None else x[lo:hi]
+
+    Kl = K[lo:hi] if getattr(K, "ndim", 2) == 3 else K
+    res = solver(sl(pts_2d), sl(line_2d), sl(pts_3d), sl(line_3d), Kl, **kw)
+    packed = pack_results(torch.as_tensor(res["R"]), torch.as_tensor(res["t"]), torch.as_tensor(res["status"]))
+    full = gather_results(packed, batch, group=group)
+    return unpack_results(full)
