@@ -95,11 +95,38 @@ CVX_HD constexpr double tri_s(int t, int k) { return (t >= 6 && k >= 1) ? -1.0 :
 // ---------------------------------------------------------------------------------------
 // tiny helpers
 
+// reciprocal and reciprocal square root: on the device the hardware seed (v_rcp_f64 /
+// v_rsq_f64) plus two Newton steps (<= 1-2 ulp) instead of the IEEE expansion; every use
+// below is either self-correcting (Newton iterations) or followed by an explicit check.
+CVX_HD double rcp(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+#else
+    return 1.0 / x;
+#endif
+}
+CVX_HD double rsqrt_(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(x);
+    { double h = 0.5 * x * y; double e = fma(-h, y, 0.5); y = fma(y, e, y); }
+    { double h = 0.5 * x * y; double e = fma(-h, y, 0.5); y = fma(y, e, y); }
+    return y;
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
+
 CVX_HD void inv3(const double *M, double *Mi, double &det)
 {
     double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
     det = M[0] * c00 + M[1] * c01 + M[2] * c02;
-    double id = 1.0 / det;
+    double id = rcp(det);
     Mi[0] = c00 * id; Mi[1] = (M[2] * M[7] - M[1] * M[8]) * id; Mi[2] = (M[1] * M[5] - M[2] * M[4]) * id;
     Mi[3] = c01 * id; Mi[4] = (M[0] * M[8] - M[2] * M[6]) * id; Mi[5] = (M[2] * M[3] - M[0] * M[5]) * id;
     Mi[6] = c02 * id; Mi[7] = (M[1] * M[6] - M[0] * M[7]) * id; Mi[8] = (M[0] * M[4] - M[1] * M[3]) * id;
@@ -115,16 +142,21 @@ CVX_HD void polar3(const double *M, double *R, int iters)
     for (int it = 0; it < iters; ++it) {
         double Xi[9], det;
         inv3(X, Xi, det);
-        // Frobenius scaling g = (|X^-1|_F / |X|_F)^(1/2) for the first iterations
+        // Frobenius scaling g = (|X^-1|_F / |X|_F)^(1/2) while X is far from orthogonal
         double nx = 0, ni = 0;
         CVX_UNROLL for (int i = 0; i < 9; ++i) { nx += X[i] * X[i]; ni += Xi[i] * Xi[i]; }
-        double g = (it < 4) ? sqrt(sqrt(ni / nx)) : 1.0;
-        double ig = 1.0 / g;
+        const bool far = (it < 4) && (fabs(nx - 3.0) > 0.3 || fabs(ni - 3.0) > 0.3);
+        double g = 1.0, ig = 1.0;
+        if (far) { ig = sqrt(sqrt(nx * rcp(ni))); g = rcp(ig); }
         // X^-T = transpose(Xi)
-        double Y[9];
+        double Y[9], dl = 0;
         CVX_UNROLL for (int i = 0; i < 3; ++i)
-            CVX_UNROLL for (int j = 0; j < 3; ++j) Y[i * 3 + j] = 0.5 * (g * X[i * 3 + j] + ig * Xi[j * 3 + i]);
+            CVX_UNROLL for (int j = 0; j < 3; ++j) {
+                Y[i * 3 + j] = 0.5 * (g * X[i * 3 + j] + ig * Xi[j * 3 + i]);
+                dl += (Y[i * 3 + j] - X[i * 3 + j]) * (Y[i * 3 + j] - X[i * 3 + j]);
+            }
         CVX_UNROLL for (int i = 0; i < 9; ++i) X[i] = Y[i];
+        if (dl < 1e-30) break; // converged (quadratic: the next step would not change X)
     }
     CVX_UNROLL for (int i = 0; i < 9; ++i) R[i] = X[i];
 }
@@ -188,7 +220,7 @@ CVX_HD void gram_add_line(Gram &g, const double *Ki, const double *l2 /*u0 v0 u1
     bearing(Ki, l2[0], l2[1], a);
     bearing(Ki, l2[2], l2[3], b);
     double n[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
-    double inv = 1.0 / sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    double inv = rsqrt_(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
     n[0] *= inv; n[1] *= inv; n[2] *= inv;
     double T[6] = {n[0] * n[0], n[0] * n[1], n[0] * n[2], n[1] * n[1], n[1] * n[2], n[2] * n[2]};
     gram_add(g, T, l3[0], l3[1], l3[2]);
@@ -299,29 +331,27 @@ CVX_HD void eig_norms(Eig &e)
 CVX_HD void jacobi_cs(double al, double be, double gam, bool rot, double &c, double &s, double &t)
 {
     const double d = be - al, g2 = 2.0 * gam;
-    const double h2 = d * d + g2 * g2 + 1e-290;
 #if defined(__HIP_DEVICE_COMPILE__)
-    double y = __builtin_amdgcn_rsq(h2);
-    { double hh = 0.5 * h2 * y; double e = fma(-hh, y, 0.5); y = fma(y, e, y); }
-    const double h = h2 * y;
-    const double den = fabs(d) + h;
-    double r = __builtin_amdgcn_rcp(den);
-    { double e = fma(-den, r, 1.0); r = fma(r, e, r); }
-    double tt = g2 * r;
-#else
-    const double h = sqrt(h2);
-    double tt = g2 / (fabs(d) + h);
-#endif
-    tt = d < 0 ? -tt : tt;
-    t = rot ? tt : 0.0;
+    // tan(theta) in single precision (one v_rsq_f32 + one v_rcp_f32): an angle that is right to
+    // ~1e-7 still annihilates g_p . g_q to 1e-7 of its size per rotation, far below the
+    // sweep tolerance.  cos(theta) then comes from a float seed refined by one double Newton
+    // step (|c^2 + s^2 - 1| ~ 1e-14), so the accumulated rotation stays orthogonal.
+    const float df = (float)d, gf = (float)g2;
+    const float h2 = df * df + gf * gf + 1e-37f;
+    const float hf = h2 * __builtin_amdgcn_rsqf(h2);
+    float tf = gf * __builtin_amdgcn_rcpf(fabsf(df) + hf);
+    tf = df < 0.0f ? -tf : tf;
+    t = rot ? (double)tf : 0.0;
     const double x = 1.0 + t * t;
-#if defined(__HIP_DEVICE_COMPILE__)
-    double z = __builtin_amdgcn_rsq(x);
-    { double hh = 0.5 * x * z; double e = fma(-hh, z, 0.5); z = fma(z, e, z); }
+    double z = (double)__builtin_amdgcn_rsqf((float)x);
     { double hh = 0.5 * x * z; double e = fma(-hh, z, 0.5); z = fma(z, e, z); }
     c = z;
 #else
-    c = 1.0 / sqrt(x);
+    const double h = sqrt(d * d + g2 * g2 + 1e-290);
+    double tt = g2 / (fabs(d) + h);
+    tt = d < 0 ? -tt : tt;
+    t = rot ? tt : 0.0;
+    c = 1.0 / sqrt(1.0 + t * t);
 #endif
     s = t * c;
 }
@@ -430,13 +460,13 @@ CVX_HD void so3_newton(const double *Q9, double *R, int iters)
         double hn = fabs(H[0]) + fabs(H[4]) + fabs(H[8]) + 1e-300;
         CVX_UNROLL for (int k = 0; k < 3; ++k) {
             double nw = -(Hi[k * 3] * g[0] + Hi[k * 3 + 1] * g[1] + Hi[k * 3 + 2] * g[2]);
-            w[k] = pd ? nw : -g[k] / hn;
+            w[k] = pd ? nw : -g[k] * rcp(hn);
         }
         double wn = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-        double lim = wn > 0.5 ? 0.5 / wn : 1.0;
+        double lim = wn > 0.5 ? 0.5 * rcp(wn) : 1.0;
         // Cayley retraction R <- R (I - S)^-1 (I + S), S = [w/2]x  = R (I + 2/(1+|s|^2) (S + S^2))
         double s0 = 0.5 * lim * w[0], s1 = 0.5 * lim * w[1], s2 = 0.5 * lim * w[2];
-        double f = 2.0 / (1.0 + s0 * s0 + s1 * s1 + s2 * s2);
+        double f = 2.0 * rcp(1.0 + s0 * s0 + s1 * s1 + s2 * s2);
         double ss = s0 * s0 + s1 * s1 + s2 * s2;
         double Cm[9] = {1 + f * (s0 * s0 - ss), f * (-s2 + s0 * s1), f * (s1 + s0 * s2),
                         f * (s2 + s0 * s1), 1 + f * (s1 * s1 - ss), f * (-s0 + s1 * s2),
@@ -474,7 +504,7 @@ CVX_HD double ldl_min_pivot(double *S)
     CVX_UNROLL for (int k = 0; k < 10; ++k) {
         double d = S[sidx(k, k)];
         minp = d < minp ? d : minp;
-        double id = 1.0 / d;
+        double id = rcp(d);
         CVX_UNROLL for (int i = k + 1; i < 10; ++i) {
             double l = S[sidx(k, i)] * id;
             CVX_UNROLL for (int j = i; j < 10; ++j) S[sidx(i, j)] -= l * S[sidx(k, j)];
@@ -493,7 +523,7 @@ CVX_HD bool chol_solve10(double *M, double *x)
         ok &= d > 0;
         d = sqrt(d > 0 ? d : 1.0);
         M[j * 10 + j] = d;
-        double id = 1.0 / d;
+        double id = rcp(d);
         CVX_UNROLL for (int i = j + 1; i < 10; ++i) {
             double s = M[i * 10 + j];
             CVX_UNROLL for (int k = 0; k < j; ++k) s -= M[i * 10 + k] * M[j * 10 + k];
@@ -503,12 +533,12 @@ CVX_HD bool chol_solve10(double *M, double *x)
     CVX_UNROLL for (int i = 0; i < 10; ++i) {
         double s = x[i];
         CVX_UNROLL for (int k = 0; k < i; ++k) s -= M[i * 10 + k] * x[k];
-        x[i] = s / M[i * 10 + i];
+        x[i] = s * rcp(M[i * 10 + i]);
     }
     CVX_UNROLL for (int i = 9; i >= 0; --i) {
         double s = x[i];
         CVX_UNROLL for (int k = i + 1; k < 10; ++k) s -= M[k * 10 + i] * x[k];
-        x[i] = s / M[i * 10 + i];
+        x[i] = s * rcp(M[i * 10 + i]);
     }
     return ok;
 }
@@ -574,7 +604,7 @@ CVX_HD void certify(const double *Qs, const double *W, const double *Wp, const d
 {
     c.ok = false;
     // rank-1 rounding r_c = v[:9] / v[9] (cvxpnpl.py:504-505), then nearest proper rotation
-    double iv = 1.0 / v[9];
+    double iv = rcp(v[9]);
     double M0[9];
     CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) M0[i * 3 + j] = v[3 * j + i] * iv; // R[i][j] = r[3j+i]
     double d0 = det3(M0);
@@ -697,7 +727,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
     Eig e;
     Cert c;
     c.ok = false;
-    int it = 0, next_check = o.first_check;
+    int it = 0, next_check = o.first_check, late_fails = 0;
     bool done = false;
     double fp_res = 1e300;
     while (!done) {
@@ -708,19 +738,35 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
         bool check = it >= next_check;
         bool last = (it >= o.max_iters) || (fp_res < o.res_tol);
         if (check || last) {
-            // top eigenvector of Wp
-            int jm = 0;
-            double best = -1;
-            CVX_UNROLL for (int j = 0; j < 10; ++j) { bool b = e.n2[j] > best; best = b ? e.n2[j] : best; jm = b ? j : jm; }
-            double v[10], il = 1.0 / sqrt(best);
+            // top eigenvector of Wp (and the runner-up, see below)
+            int jm = 0, j2 = 0;
+            double best = -1, second = -1;
+            CVX_UNROLL for (int j = 0; j < 10; ++j) {
+                const double n2 = e.n2[j];
+                const bool b1 = n2 > best, b2 = !b1 && n2 > second;
+                second = b1 ? best : (b2 ? n2 : second);
+                j2 = b1 ? jm : (b2 ? j : j2);
+                best = b1 ? n2 : best;
+                jm = b1 ? j : jm;
+            }
+            // Two-fold ambiguous problems (two poses 180 degrees apart with nearly equal cost) make
+            // Z hover at the average of both: eigenvalues (~2, ~2), and the top eigenvector may be the
+            // non-optimal pose for hundreds of iterations.  From iteration 8 on, failed checks with a
+            // comparable second eigenvalue alternate between the top and the second eigenvector.
+            const bool two = it >= 8 && (sqrt(second) - e.sigma) > 0.25 * (sqrt(best) - e.sigma);
+            const bool use2 = two && (late_fails & 1);
+            const int jc = use2 ? j2 : jm;
+            double v[10], vt[10], il = rsqrt_(use2 ? second : best), il1 = rsqrt_(best);
             CVX_UNROLL for (int i = 0; i < 10; ++i) {
-                double s = 0;
-                CVX_UNROLL for (int j = 0; j < 10; ++j) s = (j == jm) ? e.G[j][i] : s;
+                double s = 0, st = 0;
+                CVX_UNROLL for (int j = 0; j < 10; ++j) { s = (j == jc) ? e.G[j][i] : s; st = (j == jm) ? e.G[j][i] : st; }
                 v[i] = s * il;
+                vt[i] = st * il1;
             }
             certify(Qs, W, Wp, v, o.rho, delta, c);
             next_check = next_check_after(it, o);
             bool gap_ok = c.ok && (tr * (fabs(c.zSz) + 4.0 * delta) <= (o.eps > 8e-13 * tr ? o.eps : 8e-13 * tr));
+            if (!gap_ok && it >= 8) ++late_fails;
             if (gap_ok) {
                 CVX_UNROLL for (int i = 0; i < 9; ++i) sol.R[i] = c.R[i];
                 sol.cost = tr * c.pobj;
@@ -737,7 +783,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
             } else if (last) {
                 int rank = 0;
                 CVX_UNROLL for (int j = 0; j < 10; ++j) rank += (sqrt(e.n2[j]) - e.sigma) > 1e-3;
-                fallback_pose(Qs, tr, v, rank, sol);
+                fallback_pose(Qs, tr, vt, rank, sol);
                 if (Zout) { CVX_UNROLL for (int i = 0; i < 55; ++i) Zout[i] = Wp[i]; }
                 done = true;
             }

@@ -34,7 +34,8 @@ constexpr int L_X = 520;    // 64   entry scratch (affine projection gathers)
 constexpr int L_G = 584;    // 100  full 10x10
 constexpr int L_B = 684;    // 28   translation map B (27)
 constexpr int L_M = 712;    // 40   misc scalars / results of lane 0
-constexpr int LDSW = 752;
+constexpr int L_V = 752;    // 20   candidate eigenvectors (top, runner-up)
+constexpr int LDSW = 772;
 
 struct LaneTab {
     signed char ei[64], ej[64], p1[64], p2[64], s0[64], s1[64], s2[64], diag[64];
@@ -77,6 +78,326 @@ __device__ __forceinline__ double wave_sum(double x)
     return x;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// cooperative certificate: constant tables
+
+// M = sum_i (Ahat_i z)(Ahat_i z)^T over an orthonormal basis of span{A_i} (solver_core.h
+// build_Mz), entry (a, b) as a short list of terms  coef * z[p] * z[q].
+struct MTab {
+    signed char p[64][10], q[64][10];
+    double c[64][10];
+};
+
+constexpr MTab make_mtab()
+{
+    MTab t{};
+    int e = 0;
+    for (int a = 0; a < 10; ++a)
+        for (int b = a; b < 10; ++b) {
+            int n = 0;
+            for (int tr = 0; tr < 15; ++tr) {
+                double ca = 0, cb = 0;
+                int pa = 0, pb = 0;
+                for (int k = 0; k < 3; ++k) {
+                    const int i = cvx::tri_i(tr, k), j = cvx::tri_j(tr, k);
+                    const double sg = cvx::tri_s(tr, k);
+                    if (i == a) { ca = 0.5 * sg; pa = j; }
+                    if (j == a) { ca = 0.5 * sg; pa = i; }
+                    if (i == b) { cb = 0.5 * sg; pb = j; }
+                    if (j == b) { cb = 0.5 * sg; pb = i; }
+                }
+                if (ca != 0 && cb != 0) { t.p[e][n] = (signed char)pa; t.q[e][n] = (signed char)pb; t.c[e][n] = (2.0 / 3.0) * ca * cb; ++n; }
+            }
+            if (b < 9) {
+                const double P = ((a % 3) == (b % 3) ? 1.0 / 3.0 : 0.0) + ((a / 3) == (b / 3) ? 1.0 / 3.0 : 0.0) - 1.0 / 9.0;
+                t.p[e][n] = (signed char)a; t.q[e][n] = (signed char)b; t.c[e][n] = P; ++n;
+            }
+            if (a == 9 && b == 9) { t.p[e][n] = 9; t.q[e][n] = 9; t.c[e][n] = 1.0; ++n; }
+            ++e;
+        }
+    for (int l = 55; l < 64; ++l)
+        for (int n = 0; n < 10; ++n) { t.p[l][n] = t.p[l - 55][n]; t.q[l][n] = t.q[l - 55][n]; t.c[l][n] = t.c[l - 55][n]; }
+    return t;
+}
+
+__device__ const MTab kMTab = make_mtab();
+
+// element i (0..9) of x-vector v (0: z = [vec(R); 1]; 1..3: [vec(R [e_k]x); 0]) as sign * R[src]
+struct XTab { signed char src[40]; signed char sgn[40]; };
+constexpr XTab make_xtab()
+{
+    XTab t{};
+    for (int v = 0; v < 4; ++v)
+        for (int i = 0; i < 10; ++i) {
+            int src = 0, sg = 0;
+            if (i < 9) {
+                const int row = i % 3, c = i / 3;
+                if (v == 0) { src = row * 3 + c; sg = 1; }
+                else {
+                    const int k = v - 1; // (R [e_k]x)[row][c] : column c of [e_k]x
+                    if (k == 0) { if (c == 1) { src = row * 3 + 2; sg = 1; } if (c == 2) { src = row * 3 + 1; sg = -1; } }
+                    if (k == 1) { if (c == 0) { src = row * 3 + 2; sg = -1; } if (c == 2) { src = row * 3 + 0; sg = 1; } }
+                    if (k == 2) { if (c == 0) { src = row * 3 + 1; sg = 1; } if (c == 1) { src = row * 3 + 0; sg = -1; } }
+                }
+            }
+            t.src[v * 10 + i] = (signed char)src;
+            t.sgn[v * 10 + i] = (signed char)sg;
+        }
+    return t;
+}
+__device__ const XTab kXTab = make_xtab();
+
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+
+__device__ __forceinline__ double dot10(const double2 *a, const double2 *b)
+{
+    const double2 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4];
+    const double2 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4];
+    return ((a0.x * b0.x + a0.y * b0.y) + (a1.x * b1.x + a1.y * b1.y)) + ((a2.x * b2.x + a2.y * b2.y) + (a3.x * b3.x + a3.y * b3.y)) +
+           (a4.x * b4.x + a4.y * b4.y);
+}
+
+struct Roles {
+    int lane, el, ei, ej, p1, p2;
+    bool is_diag;
+    double s0, s1, s2;
+};
+
+// projection of the symmetric matrix held one entry per lane onto { <A_i, Z> = b_i }
+// (tgt = 1) or its direction space (tgt = 0); same closed form as cvx::proj_affine.
+__device__ __forceinline__ double coop_proj(double *L, const Roles &r, double X, double tgt)
+{
+    L[L_X + r.el] = X;
+    CVXW_SYNC();
+    double d[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) d[k] = L[L_X + cvx::sidx(k, k)];
+    const double r0 = d[0] + d[3] + d[6] - tgt, r1 = d[1] + d[4] + d[7] - tgt, r2 = d[2] + d[5] + d[8] - tgt;
+    const double c0 = d[0] + d[1] + d[2] - tgt, c1 = d[3] + d[4] + d[5] - tgt, c2 = d[6] + d[7] + d[8] - tgt;
+    const double tot = r0 + r1 + r2;
+    const int ri = r.ei % 3, ci = r.ei / 3; // diagonal entry (ei, ei), ei < 9, is D[ri][ci]
+    const double rr = ri == 0 ? r0 : (ri == 1 ? r1 : r2), cc = ci == 0 ? c0 : (ci == 1 ? c1 : c2);
+    const double xdiag = (r.ei == 9) ? tgt : X - (rr + cc) * (1.0 / 3.0) + tot * (1.0 / 9.0);
+    const double m = (r.s0 * X + r.s1 * L[L_X + r.p1] + r.s2 * L[L_X + r.p2]) * (1.0 / 3.0);
+    CVXW_SYNC();
+    return r.is_diag ? xdiag : X - r.s0 * m;
+}
+
+// LDS map of the certificate (regions that are dead while it runs)
+constexpr int C_QF = L_EX;          // 90   full 9x9 Qs, row stride 10
+constexpr int C_XV = L_EX + 90;     // 40   x-vectors z, a_0, a_1, a_2 (stride 10)
+constexpr int C_YV = L_EX + 130;    // 40   Qs x
+constexpr int C_H1 = L_EX + 170;    // 10   a_k . Q a_l
+constexpr int C_RL = L_EX + 180;    // 10   R (row-major)
+constexpr int C_ROW = L_EX + 190;   // 12   pivot row (+ rhs entry) of the elimination
+constexpr int C_LAM = L_EX + 202;   // 10   multipliers of the dual correction
+constexpr int C_SF = L_G;           // 100  full 10x10 S
+constexpr int C_UF = L_Y;           // 100  upper factor of M
+
+// In-place LDL^T elimination of the SPD matrix held one entry (a <= b) per lane, through
+// LDS row broadcasts; optionally carries a right-hand side (lanes 0..9) along.  Returns
+// the smallest pivot.  On exit the entry lanes hold U = D L^T.
+template <bool RHS>
+__device__ __forceinline__ double coop_ldl(double *L, const Roles &r, double &Me, double &y)
+{
+    double minp = 1e300;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        if (r.ei == k && r.lane < 55) L[C_ROW + r.ej] = Me;
+        if (RHS && r.lane == k) L[C_ROW + 10] = y;
+        CVXW_SYNC();
+        const double d = L[C_ROW + k];
+        minp = d < minp ? d : minp;
+        const double id = fast_rcp(d);
+        const double ra = L[C_ROW + r.ei], rb = L[C_ROW + r.ej];
+        if (r.ei > k) Me -= ra * id * rb;
+        if (RHS) {
+            const int a = r.lane < 10 ? r.lane : 0;
+            const double rv = L[C_ROW + a] * id * L[C_ROW + 10];
+            if (r.lane < 10 && r.lane > k) y -= rv;
+        }
+        CVXW_SYNC();
+    }
+    return minp;
+}
+
+// Cooperative version of cvx::certify (solver_core.h): identical mathematics, all 64 lanes.
+// Inputs: entry-lane values Qs, W, Wp; unit top eigenvector v (10, LDS pointer); outputs R
+// (row-major, every lane), pobj, zSz.  Returns the wave-uniform verdict c.ok of cvx::certify.
+__device__ __forceinline__ bool coop_certify(double *L, const Roles &r, double Qs, double W, double Wp, const double *v,
+                                             double rho, double delta, double *R, double &pobj, double &zSz)
+{
+    double2 *L2 = reinterpret_cast<double2 *>(L);
+    const int lane = r.lane;
+    // ---- rank-1 rounding (cvxpnpl.py:504-505) and projection to SO(3)
+    const double iv = cvx::rcp(v[9]);
+    double X[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) X[i * 3 + j] = v[3 * j + i] * iv;
+    const double d0 = cvx::det3(X);
+    if (d0 < 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) X[i] = -X[i];
+    }
+    cvx::polar3(X, R, 8);
+    // full Qs (row stride 10) for the matrix-vector products
+    if (r.ej < 9 && lane < 55) { L[C_QF + r.ei * 10 + r.ej] = Qs; L[C_QF + r.ej * 10 + r.ei] = Qs; }
+    if (lane < 9) L[C_QF + lane * 10 + 9] = 0.0;
+    const int xsrc = kXTab.src[lane < 40 ? lane : 0];
+    const double xsgn = (double)kXTab.sgn[lane < 40 ? lane : 0];
+    // ---- Newton on SO(3) for f(R) = r^T Qs r (cvx::so3_newton)
+    for (int it = 0; it < 6; ++it) {
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) L[C_RL + i] = R[i];
+        }
+        CVXW_SYNC();
+        if (lane < 40) L[C_XV + lane] = (lane == 9) ? 1.0 : xsgn * L[C_RL + xsrc];
+        CVXW_SYNC();
+        if (lane < 36) {
+            const int vv = lane / 9, i = lane % 9;
+            L[C_YV + vv * 10 + i] = dot10(L2 + (C_QF + i * 10) / 2, L2 + (C_XV + vv * 10) / 2);
+        }
+        if (lane >= 36 && lane < 40) L[C_YV + (lane - 36) * 10 + 9] = 0.0;
+        CVXW_SYNC();
+        if (lane < 9) {
+            const int k = lane / 3, l = lane % 3;
+            L[C_H1 + lane] = dot10(L2 + (C_XV + (1 + k) * 10) / 2, L2 + (C_YV + (1 + l) * 10) / 2);
+        }
+        CVXW_SYNC();
+        double Qr[9], H1[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { Qr[i] = L[C_YV + i]; H1[i] = L[C_H1 + i]; }
+        double N[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) N[i * 3 + j] = R[0 * 3 + i] * Qr[3 * j] + R[1 * 3 + i] * Qr[3 * j + 1] + R[2 * 3 + i] * Qr[3 * j + 2];
+        const double g[3] = {2 * (N[7] - N[5]), 2 * (N[2] - N[6]), 2 * (N[3] - N[1])};
+        CVXW_SYNC();
+        if (it >= 2 && fabs(g[0]) + fabs(g[1]) + fabs(g[2]) < 1e-15) break; // wave-uniform
+        const double trN = N[0] + N[4] + N[8];
+        double H[9];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) H[k * 3 + l] = 2 * H1[k * 3 + l] + N[l * 3 + k] + N[k * 3 + l] - (k == l ? 2 * trN : 0.0);
+        double Hi[9], det;
+        cvx::inv3(H, Hi, det);
+        const bool pd = H[0] > 0 && (H[0] * H[4] - H[1] * H[3]) > 0 && det > 0;
+        const double hn = fabs(H[0]) + fabs(H[4]) + fabs(H[8]) + 1e-300;
+        double w[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double nw = -(Hi[k * 3] * g[0] + Hi[k * 3 + 1] * g[1] + Hi[k * 3 + 2] * g[2]);
+            w[k] = pd ? nw : -g[k] * cvx::rcp(hn);
+        }
+        const double wn = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        const double lim = wn > 0.5 ? 0.5 * cvx::rcp(wn) : 1.0;
+        const double q0 = 0.5 * lim * w[0], q1 = 0.5 * lim * w[1], q2 = 0.5 * lim * w[2];
+        const double ss = q0 * q0 + q1 * q1 + q2 * q2;
+        const double f = 2.0 * cvx::rcp(1.0 + ss);
+        const double Cm[9] = {1 + f * (q0 * q0 - ss), f * (-q2 + q0 * q1), f * (q1 + q0 * q2),
+                              f * (q2 + q0 * q1), 1 + f * (q1 * q1 - ss), f * (-q0 + q1 * q2),
+                              f * (-q1 + q0 * q2), f * (q0 + q1 * q2), 1 + f * (q2 * q2 - ss)};
+        double Rn[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Rn[i * 3 + j] = R[i * 3] * Cm[j] + R[i * 3 + 1] * Cm[3 + j] + R[i * 3 + 2] * Cm[6 + j];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+    }
+    { // one polar step squares any drift from orthogonality
+        double Ri[9], det, Rn[9];
+        cvx::inv3(R, Ri, det);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Rn[i * 3 + j] = 0.5 * (R[i * 3 + j] + Ri[j * 3 + i]);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+    }
+    // ---- z and the x-vectors of the final R; pobj = z^T Qs z
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) L[C_RL + i] = R[i];
+    }
+    CVXW_SYNC();
+    if (lane < 40) L[C_XV + lane] = (lane == 9) ? 1.0 : xsgn * L[C_RL + xsrc];
+    CVXW_SYNC();
+    {
+        double part = 0.0;
+        if (lane < 9) part = L[C_XV + lane] * dot10(L2 + (C_QF + lane * 10) / 2, L2 + C_XV / 2);
+        pobj = wave_sum(part);
+    }
+    // ---- dual hint S_h = rho (Wp - W); S1 = S_h - P_null(S_h - Qs)
+    const double Sh = rho * (Wp - W);
+    double S = Sh - coop_proj(L, r, Sh - (r.ej < 9 ? Qs : 0.0), 0.0);
+    if (lane < 55) { L[C_SF + r.ei * 10 + r.ej] = S; L[C_SF + r.ej * 10 + r.ei] = S; }
+    CVXW_SYNC();
+    // rhs = S z on lanes 0..9
+    double y = 0.0;
+    {
+        const int a = lane < 10 ? lane : 0;
+        y = dot10(L2 + (C_SF + a * 10) / 2, L2 + C_XV / 2);
+    }
+    // ---- M = Ghat Ghat^T + T T^T (entry lanes), LDL^T solve M lam = rhs
+    double Me = 0.0;
+#pragma unroll
+    for (int t = 0; t < 10; ++t) Me += kMTab.c[lane][t] * L[C_XV + kMTab.p[lane][t]] * L[C_XV + kMTab.q[lane][t]];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Me += L[C_XV + (1 + k) * 10 + r.ei] * L[C_XV + (1 + k) * 10 + r.ej];
+    CVXW_SYNC();
+    const double minpM = coop_ldl<true>(L, r, Me, y);
+    if (lane < 55) L[C_UF + r.ei * 10 + r.ej] = Me; // U[a][b], a <= b
+    CVXW_SYNC();
+    // back substitution: lam_k = y_k / U_kk; y_a -= U[a][k] lam_k (a < k)
+#pragma unroll
+    for (int k = 9; k >= 0; --k) {
+        const double lk_local = y * fast_rcp(L[C_UF + k * 10 + k]);
+        const double lk = __shfl(lk_local, k, 64);
+        if (lane == 0) L[C_LAM + k] = lk;
+        const int a = lane < 10 ? lane : 0;
+        const double u = L[C_UF + a * 10 + k];
+        if (lane < k) y -= u * lk;
+    }
+    CVXW_SYNC();
+    // ---- S2 = S1 - P_range(sym(lam z^T))
+    {
+        const double E = 0.5 * (L[C_LAM + r.ei] * L[C_XV + r.ej] + L[C_XV + r.ei] * L[C_LAM + r.ej]);
+        const double Nn = coop_proj(L, r, E, 0.0);
+        S -= E - Nn;
+    }
+    if (lane < 55) { L[C_SF + r.ei * 10 + r.ej] = S; L[C_SF + r.ej * 10 + r.ei] = S; }
+    CVXW_SYNC();
+    double res;
+    {
+        const int a = lane < 10 ? lane : 0;
+        const double sz = dot10(L2 + (C_SF + a * 10) / 2, L2 + C_XV / 2);
+        double m = lane < 10 ? fabs(sz) : 0.0;
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) { const double o2 = __shfl_xor(m, sh, 64); m = o2 > m ? o2 : m; }
+        res = m;
+        zSz = wave_sum(lane < 10 ? L[C_XV + a] * sz : 0.0);
+    }
+    CVXW_SYNC();
+    // ---- LDL^T of S2 + delta I: all pivots positive  <=>  lambda_min(S2) > -delta
+    double Se = S + (r.is_diag ? delta : 0.0), dummy = 0.0;
+    const double minp = coop_ldl<false>(L, r, Se, dummy);
+    return (minpM > 0) && (minp > 0) && (res < 1e-10) && (d0 > 0) && (pobj == pobj);
+}
+
 struct WaveArgs {
     int64_t batch;
     int n_p, n_l, K_per_problem;
@@ -85,7 +406,7 @@ struct WaveArgs {
     int32_t *status, *iters, *work;
 };
 
-__global__ void __launch_bounds__(64 * WPB) solve_wave_kernel(WaveArgs a, cvx::Opts o)
+__global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx::Opts o)
 {
     __shared__ __attribute__((aligned(16))) double lds_all[WPB][LDSW];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -101,6 +422,9 @@ __global__ void __launch_bounds__(64 * WPB) solve_wave_kernel(WaveArgs a, cvx::O
     const bool is_diag = kLaneTab.diag[lane] != 0;
     const int p1 = kLaneTab.p1[lane], p2 = kLaneTab.p2[lane];
     const double s0 = kLaneTab.s0[lane], s1 = kLaneTab.s1[lane], s2 = kLaneTab.s2[lane];
+    Roles roles;
+    roles.lane = lane; roles.el = el; roles.ei = ei; roles.ej = ej; roles.p1 = p1; roles.p2 = p2;
+    roles.is_diag = is_diag; roles.s0 = s0; roles.s1 = s1; roles.s2 = s2;
     const int jl = lane < 50 ? lane : lane - 50;      // jacobi lane (50..63 alias 0..13)
     const int ji = jl % 10, jk = jl / 10;
 
@@ -151,7 +475,7 @@ __global__ void __launch_bounds__(64 * WPB) solve_wave_kernel(WaveArgs a, cvx::O
                 cvx::bearing(Ki, l2[0], l2[1], u);
                 cvx::bearing(Ki, l2[2], l2[3], v);
                 double n[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
-                double inv = 1.0 / sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                double inv = cvx::rsqrt_(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
                 n[0] *= inv; n[1] *= inv; n[2] *= inv;
                 T[0] = n[0] * n[0]; T[1] = n[0] * n[1]; T[2] = n[0] * n[2]; T[3] = n[1] * n[1]; T[4] = n[1] * n[2]; T[5] = n[2] * n[2];
                 P[0] = l3[0]; P[1] = l3[1]; P[2] = l3[2];
@@ -208,7 +532,7 @@ __global__ void __launch_bounds__(64 * WPB) solve_wave_kernel(WaveArgs a, cvx::O
     for (int k = 0; k < 9; ++k) tr += L[L_X + cvx::sidx(k, k)];
     bool finite = okK && okG && (tr == tr) && tr > 0 && tr < 1e300;
     finite = !__any(!(finite && (Qe == Qe)));
-    const double itr = finite ? 1.0 / tr : 0.0;
+    const double itr = finite ? cvx::rcp(tr) : 0.0;
     const double Qs = Qe * itr;
 
     // ---------------------------------------------------------------- ADMM
@@ -216,7 +540,7 @@ __global__ void __launch_bounds__(64 * WPB) solve_wave_kernel(WaveArgs a, cvx::O
     delta = delta < 1e-13 ? 1e-13 : delta;
     const double irho = 1.0 / o.rho;
     double W = (lane == 54) ? 1.0 : 0.0, Wp = 0.0;
-    int it = 0, total_sweeps = 0, next_check = o.first_check;
+    int it = 0, total_sweeps = 0, next_check = o.first_check, late_fails = 0;
     double fp_res = 1e300;
     int status = cvx::ST_NONFINITE, rank_out = 0;
     bool done = !finite;
@@ -288,7 +612,7 @@ __global__ void __launch_bounds__(64 * WPB) solve_wave_kernel(WaveArgs a, cvx::O
         // ---- Wp = sum_{lam > 0} lam v v^T, from (g, w g) with w = lam / lam'^2
         const double lpa = sqrt(al), lpb = sqrt(be);
         const double lama = lpa - sigma, lamb = lpb - sigma;
-        const double wa = lama > 0 ? lama / al : 0.0, wb = lamb > 0 ? lamb / be : 0.0;
+        const double wa = lama > 0 ? lama * cvx::rcp(al) : 0.0, wb = lamb > 0 ? lamb * cvx::rcp(be) : 0.0;
         L2[(L_Y + 2 * ((2 * jk) * 10 + ji)) / 2] = make_double2(ca, wa * ca);
         L2[(L_Y + 2 * ((2 * jk + 1) * 10 + ji)) / 2] = make_double2(cb, wb * cb);
         if (ji == 0) { // slot eigenvalue data for the top-eigenvector / rank decisions
@@ -310,52 +634,86 @@ __global__ void __launch_bounds__(64 * WPB) solve_wave_kernel(WaveArgs a, cvx::O
         const bool check = it >= next_check;
         const bool last = (it >= o.max_iters) || (fp_res < o.res_tol);
         if (check || last) {
-            // top eigenvector slot (wave-uniform) and its unit vector
-            int smax = 0;
-            double best = -1.0;
+            // top eigenvector slot and the runner-up (wave-uniform)
+            int smax = 0, s2nd = 0;
+            double best = -1.0, second = -1.0;
 #pragma unroll
-            for (int s = 0; s < 10; ++s) { const double n2 = L[L_M + s]; const bool bt = n2 > best; best = bt ? n2 : best; smax = bt ? s : smax; }
+            for (int s = 0; s < 10; ++s) {
+                const double n2 = L[L_M + s];
+                const bool b1 = n2 > best, b2 = !b1 && n2 > second;
+                second = b1 ? best : (b2 ? n2 : second);
+                s2nd = b1 ? smax : (b2 ? s : s2nd);
+                best = b1 ? n2 : best;
+                smax = b1 ? s : smax;
+            }
             int rank = 0;
 #pragma unroll
             for (int s = 0; s < 10; ++s) rank += (sqrt(L[L_M + s]) - sigma) > 1e-3;
-            // gather Qs, W, Wp for lane 0
-            L[L_EX + el] = W;
-            L[L_EX + 56 + el] = Wp;
-            L[L_EX + 112 + el] = Qs;
-            CVXW_SYNC();
-            if (lane == 0) {
-                double q45[45], w55[55], wp55[55], v[10];
-                const double il = 1.0 / sqrt(best);
-#pragma unroll
-                for (int i = 0; i < 55; ++i) { w55[i] = L[L_EX + i]; wp55[i] = L[L_EX + 56 + i]; }
-#pragma unroll
-                for (int i = 0; i < 9; ++i)
-#pragma unroll
-                    for (int j = i; j < 9; ++j) q45[cvx::qidx(i, j)] = L[L_EX + 112 + cvx::sidx(i, j)];
-#pragma unroll
-                for (int i = 0; i < 10; ++i) v[i] = L[L_Y + 2 * (smax * 10 + i)] * il;
-                cvx::Cert c;
-                cvx::certify(q45, w55, wp55, v, o.rho, delta, c);
-                const bool gap_ok = c.ok && (tr * (fabs(c.zSz) + 4.0 * delta) <= (o.eps > 8e-13 * tr ? o.eps : 8e-13 * tr));
-                cvx::Solution sol;
-                if (gap_ok) {
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) sol.R[i] = c.R[i];
-                    sol.cost = tr * c.pobj;
-                    sol.dobj = tr * (c.pobj - c.zSz - 4.0 * delta);
-                    sol.status = cvx::ST_CERTIFIED;
-                    sol.rank = 1;
-                } else if (last) {
-                    cvx::fallback_pose(q45, tr, v, rank, sol);
+            // candidates: the top eigenvector; for a late failed check with a comparable second
+            // eigenvalue (two-fold ambiguous problems, see solver_core.h) also the second one
+            const bool two = it >= 8 && (sqrt(second) - sigma) > 0.25 * (sqrt(best) - sigma);
+            double Rc[9], pobj = 0, zSz = 0;
+            // the candidate of this check: top eigenvector, or -- alternating on late failed checks
+            // of two-fold ambiguous problems -- the runner-up.  Saved to LDS first: the certificate
+            // reuses the L_Y region.
+            const bool use2 = two && (late_fails & 1);
+            {
+                const int sl = use2 ? s2nd : smax;
+                const double il = cvx::rsqrt_(use2 ? second : best), il1 = cvx::rsqrt_(best);
+                if (lane < 10) {
+                    L[L_V + lane] = L[L_Y + 2 * (sl * 10 + lane)] * il;
+                    L[L_V + 10 + lane] = L[L_Y + 2 * (smax * 10 + lane)] * il1; // top one, for the fallback
                 }
-                if (gap_ok || last) {
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) L[L_M + 16 + i] = sol.R[i];
-                    L[L_M + 25] = sol.cost; L[L_M + 26] = sol.dobj;
-                    L[L_M + 27] = (double)sol.status; L[L_M + 28] = (double)sol.rank;
-                }
-                L[L_M + 15] = gap_ok ? 1.0 : 0.0;
             }
+            CVXW_SYNC();
+            double vloc[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) vloc[i] = L[L_V + i];
+            const bool cok = coop_certify(L, roles, Qs, W, Wp, vloc, o.rho, delta, Rc, pobj, zSz);
+            const bool gap_ok = cok && (tr * (fabs(zSz) + 4.0 * delta) <= (o.eps > 8e-13 * tr ? o.eps : 8e-13 * tr));
+            if (!gap_ok && it >= 8) ++late_fails;
+            CVXW_SYNC();
+            if (gap_ok) {
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) L[L_M + 16 + i] = Rc[i];
+                    L[L_M + 25] = tr * pobj; L[L_M + 26] = tr * (pobj - zSz - 4.0 * delta);
+                    L[L_M + 27] = (double)cvx::ST_CERTIFIED; L[L_M + 28] = 1.0;
+                }
+            } else if (last) {
+                // cold path: the reference's recovery from the uncertified iterate (cvx::fallback_pose):
+                // R = U V^T of the rank-1 ratio (no determinant fix), cost = r^T Q r via the LDS copy of Qs
+                double M0[9], Rf[9];
+                const double iv = cvx::rcp(L[L_V + 19]);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) M0[i * 3 + j] = L[L_V + 10 + 3 * j + i] * iv;
+                cvx::polar3(M0, Rf, 12);
+                if (lane < 10) L[C_XV + lane] = lane == 9 ? 1.0 : Rf[0]; // placeholder, overwritten below
+                CVXW_SYNC();
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) L[C_XV + 3 * j + i] = Rf[i * 3 + j];
+                }
+                CVXW_SYNC();
+                double part = 0.0;
+                if (lane < 9) part = L[C_XV + lane] * dot10(reinterpret_cast<double2 *>(L) + (C_QF + lane * 10) / 2, reinterpret_cast<double2 *>(L) + C_XV / 2);
+                const double fc = wave_sum(part);
+                bool okf = true;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) okf &= (Rf[i] == Rf[i]);
+                const int fst = !okf ? cvx::ST_NONFINITE : (rank != 1 ? cvx::ST_RANK_GT1 : (cvx::det3(Rf) < 0 ? cvx::ST_REFLECTION : cvx::ST_UNCERTIFIED));
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) L[L_M + 16 + i] = Rf[i];
+                    L[L_M + 25] = tr * fc; L[L_M + 26] = NAN;
+                    L[L_M + 27] = (double)fst; L[L_M + 28] = (double)rank;
+                }
+            }
+            if (lane == 0) L[L_M + 15] = gap_ok ? 1.0 : 0.0;
             CVXW_SYNC();
             certified = L[L_M + 15] != 0.0;
             next_check = cvx::next_check_after(it, o);
@@ -367,23 +725,7 @@ __global__ void __launch_bounds__(64 * WPB) solve_wave_kernel(WaveArgs a, cvx::O
         }
         if (!done) {
             // X = Pi_aff(2 Wp - W - Qs / rho);  W <- W + alpha (X - Wp)
-            double X = 2.0 * Wp - W - irho * Qs;
-            L[L_X + el] = X;
-            CVXW_SYNC();
-            double Xn;
-            {
-                double d[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) d[k] = L[L_X + cvx::sidx(k, k)];
-                const double r0 = d[0] + d[3] + d[6] - 1.0, r1 = d[1] + d[4] + d[7] - 1.0, r2 = d[2] + d[5] + d[8] - 1.0;
-                const double c0 = d[0] + d[1] + d[2] - 1.0, c1 = d[3] + d[4] + d[5] - 1.0, c2 = d[6] + d[7] + d[8] - 1.0;
-                const double tot = r0 + r1 + r2;
-                const int ri = ei % 3, ci = ei / 3; // diagonal entry (ei, ei), ei < 9: D[ri][ci]
-                const double rr = ri == 0 ? r0 : (ri == 1 ? r1 : r2), cc = ci == 0 ? c0 : (ci == 1 ? c1 : c2);
-                const double xdiag = (ei == 9) ? 1.0 : X - (rr + cc) * (1.0 / 3.0) + tot * (1.0 / 9.0);
-                const double m = (s0 * X + s1 * L[L_X + p1] + s2 * L[L_X + p2]) * (1.0 / 3.0);
-                Xn = is_diag ? xdiag : X - s0 * m;
-            }
+            const double Xn = coop_proj(L, roles, 2.0 * Wp - W - irho * Qs, 1.0);
             const double dd = Xn - Wp;
             W += o.alpha * dd;
             fp_res = sqrt(wave_sum(wgt * dd * dd));
