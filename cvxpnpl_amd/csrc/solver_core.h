@@ -58,13 +58,14 @@ struct Opts {
     double res_tol;    // fixed-point residual below which an uncertified solve stops
     int jacobi_sweeps; // cap on Jacobi sweeps per PSD projection
     double jacobi_tol; // a sweep whose largest |cos(g_p, g_q)| is below this ends the eigen-solve
+    int warm_start;    // 1: start each eigen-solve from the previous iteration's eigenvectors
 };
 
 CVX_HD Opts default_opts()
 {
     Opts o;
-    o.eps = 1e-9; o.max_iters = 2500; o.rho = 0.05; o.alpha = 1.0;
-    o.first_check = 3; o.check_every = 1; o.res_tol = 1e-5; o.jacobi_sweeps = 12; o.jacobi_tol = 3e-2;
+    o.eps = 1e-9; o.max_iters = 2500; o.rho = 0.1; o.alpha = 1.4;
+    o.first_check = 3; o.check_every = 1; o.res_tol = 1e-5; o.jacobi_sweeps = 12; o.jacobi_tol = 3e-2; o.warm_start = 1;
     return o;
 }
 
@@ -312,6 +313,23 @@ CVX_HD void eig_load(Eig &e, const double *W)
     e.sigma = 1.5 * sqrt(fro) + 1e-300;
     CVX_UNROLL for (int j = 0; j < 10; ++j)
         CVX_UNROLL for (int i = 0; i < 10; ++i) e.G[j][i] = W[sidx(i, j)] + (i == j ? e.sigma : 0.0);
+}
+
+// warm start: G = (W + sigma I) V with V the (unit) eigenvectors of the previous iterate --
+// nearly orthogonal columns when W moved little, so the Jacobi sweeps converge at once.
+// Vn[j][i]: unit column j.  One-sided Jacobi on G then yields (W + sigma I) (V J).
+CVX_HD void eig_load_warm(Eig &e, const double *W, const double (*Vn)[10])
+{
+    double fro = 0;
+    CVX_UNROLL for (int i = 0; i < 10; ++i)
+        CVX_UNROLL for (int j = i; j < 10; ++j) fro += (i == j ? 1.0 : 2.0) * W[sidx(i, j)] * W[sidx(i, j)];
+    e.sigma = 1.5 * sqrt(fro) + 1e-300;
+    CVX_UNROLL for (int j = 0; j < 10; ++j)
+        CVX_UNROLL for (int i = 0; i < 10; ++i) {
+            double acc = e.sigma * Vn[j][i];
+            CVX_UNROLL for (int m = 0; m < 10; ++m) acc += W[sidx(i, m)] * Vn[j][m];
+            e.G[j][i] = acc;
+        }
 }
 
 CVX_HD void eig_norms(Eig &e)
@@ -730,9 +748,17 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
     int it = 0, next_check = o.first_check, late_fails = 0;
     bool done = false;
     double fp_res = 1e300;
+    double Vn[10][10];
     while (!done) {
-        eig_load(e, W);
+        if (o.warm_start && it > 0) eig_load_warm(e, W, Vn);
+        else eig_load(e, W);
         sol.sweeps += eig_solve(e, o.jacobi_sweeps, o.jacobi_tol * o.jacobi_tol);
+        if (o.warm_start) {
+            CVX_UNROLL for (int j = 0; j < 10; ++j) {
+                const double il_ = rsqrt_(e.n2[j]);
+                CVX_UNROLL for (int i = 0; i < 10; ++i) Vn[j][i] = e.G[j][i] * il_;
+            }
+        }
         eig_pospart(e, Wp);
         ++it;
         bool check = it >= next_check;

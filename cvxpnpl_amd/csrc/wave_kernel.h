@@ -35,7 +35,8 @@ constexpr int L_G = 584;    // 100  full 10x10
 constexpr int L_B = 684;    // 28   translation map B (27)
 constexpr int L_M = 712;    // 40   misc scalars / results of lane 0
 constexpr int L_V = 752;    // 20   candidate eigenvectors (top, runner-up)
-constexpr int LDSW = 772;
+constexpr int L_VN = 772;   // 100  unit eigenvectors of the previous iterate [position][row] (warm start)
+constexpr int LDSW = 872;
 
 struct LaneTab {
     signed char ei[64], ej[64], p1[64], p2[64], s0[64], s1[64], s2[64], diag[64];
@@ -556,20 +557,31 @@ __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx
             L[L_G + ej * 10 + ei] = g;
         }
         CVXW_SYNC();
-        // columns 2k, 2k+1 of the symmetric G are its rows: contiguous in L_G
+        constexpr int CA = L_EX, CB = L_EX + 64, NA = L_EX + 128, NB = L_EX + 136;
         double ca, cb, al, be, gam;
-        {
+        if (o.warm_start && it > 0) {
+            // warm start: G = (W + sigma I) V_prev -- columns already nearly orthogonal when W moved
+            // little.  Row ji of the two columns at position jk, then the full columns via LDS.
+            const double2 *wr = L2 + (L_G + ji * 10) / 2;
+            ca = dot10(wr, L2 + (L_VN + (2 * jk) * 10) / 2);
+            cb = dot10(wr, L2 + (L_VN + (2 * jk + 1) * 10) / 2);
+            L[CA + jl] = ca;
+            L[CB + jl] = cb;
+            CVXW_SYNC();
+            const double2 *ra = L2 + (CA + jk * 10) / 2, *rb = L2 + (CB + jk * 10) / 2;
+            al = dot10(ra, ra);
+            be = dot10(rb, rb);
+            gam = dot10(ra, rb);
+            CVXW_SYNC();
+        } else {
+            // columns 2k, 2k+1 of the symmetric G are its rows: contiguous in L_G
             const double2 *ra = L2 + (L_G + (2 * jk) * 10) / 2, *rb = L2 + (L_G + (2 * jk + 1) * 10) / 2;
-            const double2 a0 = ra[0], a1 = ra[1], a2 = ra[2], a3 = ra[3], a4 = ra[4];
-            const double2 b0 = rb[0], b1 = rb[1], b2 = rb[2], b3 = rb[3], b4 = rb[4];
-            al = ((a0.x * a0.x + a0.y * a0.y) + (a1.x * a1.x + a1.y * a1.y)) + ((a2.x * a2.x + a2.y * a2.y) + (a3.x * a3.x + a3.y * a3.y)) + (a4.x * a4.x + a4.y * a4.y);
-            be = ((b0.x * b0.x + b0.y * b0.y) + (b1.x * b1.x + b1.y * b1.y)) + ((b2.x * b2.x + b2.y * b2.y) + (b3.x * b3.x + b3.y * b3.y)) + (b4.x * b4.x + b4.y * b4.y);
-            gam = ((a0.x * b0.x + a0.y * b0.y) + (a1.x * b1.x + a1.y * b1.y)) + ((a2.x * b2.x + a2.y * b2.y) + (a3.x * b3.x + a3.y * b3.y)) + (a4.x * b4.x + a4.y * b4.y);
+            al = dot10(ra, ra);
+            be = dot10(rb, rb);
+            gam = dot10(ra, rb);
             ca = L[L_G + (2 * jk) * 10 + ji];
             cb = L[L_G + (2 * jk + 1) * 10 + ji];
         }
-        // exchange buffers: first / second column of every pair, and their squared norms
-        constexpr int CA = L_EX, CB = L_EX + 64, NA = L_EX + 128, NB = L_EX + 136;
         // after the rotation position 0 keeps its first column and every other column moves one
         // place along the ring a1 > a2 > a3 > a4 > b4 > b3 > b2 > b1 > b0 > a1 (circle method)
         const int src_a = jk == 0 ? CA : (jk == 1 ? CB : CA + (jk - 1) * 10);
@@ -613,6 +625,10 @@ __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx
         const double lpa = sqrt(al), lpb = sqrt(be);
         const double lama = lpa - sigma, lamb = lpb - sigma;
         const double wa = lama > 0 ? lama * cvx::rcp(al) : 0.0, wb = lamb > 0 ? lamb * cvx::rcp(be) : 0.0;
+        if (o.warm_start) {
+            L[L_VN + (2 * jk) * 10 + ji] = ca * cvx::rsqrt_(al);
+            L[L_VN + (2 * jk + 1) * 10 + ji] = cb * cvx::rsqrt_(be);
+        }
         L2[(L_Y + 2 * ((2 * jk) * 10 + ji)) / 2] = make_double2(ca, wa * ca);
         L2[(L_Y + 2 * ((2 * jk + 1) * 10 + ji)) / 2] = make_double2(cb, wb * cb);
         if (ji == 0) { // slot eigenvalue data for the top-eigenvector / rank decisions

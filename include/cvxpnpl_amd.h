@@ -44,13 +44,14 @@ enum {
 typedef struct {
     double eps;        /* absolute duality-gap tolerance; reference `eps` (cvxpnpl.py:527), default 1e-9 */
     int32_t max_iters; /* iteration cap; reference `max_iters` (cvxpnpl.py:528), default 2500 */
-    double rho;        /* ADMM penalty on the trace-normalised cost, default 0.05 */
-    double alpha;      /* over-relaxation, default 1.0 */
+    double rho;        /* ADMM penalty on the trace-normalised cost, default 0.1 */
+    double alpha;      /* over-relaxation, default 1.4 */
     int32_t first_check; /* first certification attempt after this many iterations, default 3 */
     int32_t check_every; /* then every this many, default 1 */
     double res_tol;    /* fixed-point residual at which an uncertifiable problem stops, default 1e-5 */
     int32_t jacobi_sweeps; /* cap on Jacobi sweeps per PSD projection, default 12 */
     double jacobi_tol; /* eigen-solve ends after a sweep whose largest column cosine is below this, default 3e-2 */
+    int32_t warm_start; /* 1 (default): each eigen-solve starts from the previous iteration's eigenvectors */
     int32_t layout;    /* CVXPNPL_LAYOUT_* */
 } cvxpnpl_opts_t;
 
