@@ -680,9 +680,9 @@ CVX_HD void certify(const double *Qs, const double *W, const double *Wp, const d
 // ---------------------------------------------------------------------------------------
 // the solve
 
-// certification attempts: at first_check, then spaced check_every * (1 + it / 8) apart --
+// certification attempts: at first_check, then spaced check_every * (1 + it / 16) apart --
 // every iteration while most problems finish, sparser for the slow tail.
-CVX_HD int next_check_after(int it, const Opts &o) { return it + o.check_every * (1 + it / 8); }
+CVX_HD int next_check_after(int it, const Opts &o) { return it + o.check_every * (1 + it / 16); }
 
 struct Solution {
     double R[9];    // row-major, world -> camera, x_c = R X + t
@@ -750,16 +750,23 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
     double fp_res = 1e300;
     double Vn[10][10];
     while (!done) {
-        if (o.warm_start && it > 0) eig_load_warm(e, W, Vn);
-        else eig_load(e, W);
-        sol.sweeps += eig_solve(e, o.jacobi_sweeps, o.jacobi_tol * o.jacobi_tol);
-        if (o.warm_start) {
-            CVX_UNROLL for (int j = 0; j < 10; ++j) {
-                const double il_ = rsqrt_(e.n2[j]);
-                CVX_UNROLL for (int i = 0; i < 10; ++i) Vn[j][i] = e.G[j][i] * il_;
+        if (it == 0 && o.first_check > 1 && o.max_iters > 1) {
+            // the initial iterate W0 = e9 e9^T is diagonal and PSD: its projection is itself and its
+            // eigenvectors are the unit vectors -- the first iteration needs no eigen-solve
+            CVX_UNROLL for (int i = 0; i < 55; ++i) Wp[i] = W[i];
+            CVX_UNROLL for (int j = 0; j < 10; ++j) CVX_UNROLL for (int i = 0; i < 10; ++i) Vn[j][i] = (i == j) ? 1.0 : 0.0;
+        } else {
+            if (o.warm_start && it > 0) eig_load_warm(e, W, Vn);
+            else eig_load(e, W);
+            sol.sweeps += eig_solve(e, o.jacobi_sweeps, o.jacobi_tol * o.jacobi_tol);
+            if (o.warm_start) {
+                CVX_UNROLL for (int j = 0; j < 10; ++j) {
+                    const double il_ = rsqrt_(e.n2[j]);
+                    CVX_UNROLL for (int i = 0; i < 10; ++i) Vn[j][i] = e.G[j][i] * il_;
+                }
             }
+            eig_pospart(e, Wp);
         }
-        eig_pospart(e, Wp);
         ++it;
         bool check = it >= next_check;
         bool last = (it >= o.max_iters) || (fp_res < o.res_tol);
@@ -777,10 +784,10 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
             }
             // Two-fold ambiguous problems (two poses 180 degrees apart with nearly equal cost) make
             // Z hover at the average of both: eigenvalues (~2, ~2), and the top eigenvector may be the
-            // non-optimal pose for hundreds of iterations.  From iteration 8 on, failed checks with a
+            // non-optimal pose for hundreds of iterations.  From iteration 12 on, failed checks with a
             // comparable second eigenvalue alternate between the top and the second eigenvector.
-            const bool two = it >= 8 && (sqrt(second) - e.sigma) > 0.25 * (sqrt(best) - e.sigma);
-            const bool use2 = two && (late_fails & 1);
+            const bool two = it >= 12 && (sqrt(second) - e.sigma) > 0.5 * (sqrt(best) - e.sigma);
+            const bool use2 = two && (late_fails % 3 == 2);
             const int jc = use2 ? j2 : jm;
             double v[10], vt[10], il = rsqrt_(use2 ? second : best), il1 = rsqrt_(best);
             CVX_UNROLL for (int i = 0; i < 10; ++i) {
@@ -792,7 +799,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
             certify(Qs, W, Wp, v, o.rho, delta, c);
             next_check = next_check_after(it, o);
             bool gap_ok = c.ok && (tr * (fabs(c.zSz) + 4.0 * delta) <= (o.eps > 8e-13 * tr ? o.eps : 8e-13 * tr));
-            if (!gap_ok && it >= 8) ++late_fails;
+            if (!gap_ok && it >= 12) ++late_fails;
             if (gap_ok) {
                 CVX_UNROLL for (int i = 0; i < 9; ++i) sol.R[i] = c.R[i];
                 sol.cost = tr * c.pobj;

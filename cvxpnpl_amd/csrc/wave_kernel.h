@@ -548,9 +548,17 @@ __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx
     bool certified = false;
 
     while (!done) {
+        double sigma = 0.0;
+        if (it == 0 && o.first_check > 1 && o.max_iters > 1) {
+            // W0 = e9 e9^T is diagonal and PSD: Wp = W0, eigenvectors = unit vectors, no eigen-solve
+            Wp = W;
+            L[L_VN + (2 * jk) * 10 + ji] = (ji == 2 * jk) ? 1.0 : 0.0;
+            L[L_VN + (2 * jk + 1) * 10 + ji] = (ji == 2 * jk + 1) ? 1.0 : 0.0;
+            CVXW_SYNC();
+        } else {
         // ---- eigendecomposition of W: one-sided Jacobi on G = W + sigma I
         const double fro2 = wave_sum(wgt * W * W);
-        const double sigma = 1.5 * sqrt(fro2) + 1e-300;
+        sigma = 1.5 * sqrt(fro2) + 1e-300;
         {
             const double g = W + (is_diag ? sigma : 0.0);
             L[L_G + ei * 10 + ej] = g;
@@ -646,6 +654,7 @@ __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx
                 Wp += yi.y * yj.x;
             }
         }
+        }
         ++it;
         const bool check = it >= next_check;
         const bool last = (it >= o.max_iters) || (fp_res < o.res_tol);
@@ -667,12 +676,12 @@ __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx
             for (int s = 0; s < 10; ++s) rank += (sqrt(L[L_M + s]) - sigma) > 1e-3;
             // candidates: the top eigenvector; for a late failed check with a comparable second
             // eigenvalue (two-fold ambiguous problems, see solver_core.h) also the second one
-            const bool two = it >= 8 && (sqrt(second) - sigma) > 0.25 * (sqrt(best) - sigma);
+            const bool two = it >= 12 && (sqrt(second) - sigma) > 0.5 * (sqrt(best) - sigma);
             double Rc[9], pobj = 0, zSz = 0;
             // the candidate of this check: top eigenvector, or -- alternating on late failed checks
             // of two-fold ambiguous problems -- the runner-up.  Saved to LDS first: the certificate
             // reuses the L_Y region.
-            const bool use2 = two && (late_fails & 1);
+            const bool use2 = two && (late_fails % 3 == 2);
             {
                 const int sl = use2 ? s2nd : smax;
                 const double il = cvx::rsqrt_(use2 ? second : best), il1 = cvx::rsqrt_(best);
@@ -687,7 +696,7 @@ __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx
             for (int i = 0; i < 10; ++i) vloc[i] = L[L_V + i];
             const bool cok = coop_certify(L, roles, Qs, W, Wp, vloc, o.rho, delta, Rc, pobj, zSz);
             const bool gap_ok = cok && (tr * (fabs(zSz) + 4.0 * delta) <= (o.eps > 8e-13 * tr ? o.eps : 8e-13 * tr));
-            if (!gap_ok && it >= 8) ++late_fails;
+            if (!gap_ok && it >= 12) ++late_fails;
             CVXW_SYNC();
             if (gap_ok) {
                 if (lane == 0) {
