@@ -224,7 +224,7 @@ def main():
 
         oracle.build()
         nthreads = oracle.num_threads()
-        sample = args.cpu_sample or max(nthreads * 8, 64)
+        sample = args.cpu_sample or max(nthreads * 64, 512)  # ~10 s of CPU work on this box
         sample = min(sample, batch)
         sl = slice(0, sample)
         t0 = time.perf_counter()
