@@ -70,7 +70,7 @@ cvx::Opts to_core(const cvxpnpl_opts_t *opts)
     if (opts) {
         o.eps = opts->eps; o.max_iters = opts->max_iters; o.rho = opts->rho; o.alpha = opts->alpha;
         o.first_check = opts->first_check; o.check_every = opts->check_every; o.res_tol = opts->res_tol;
-        o.jacobi_sweeps = opts->jacobi_sweeps; o.jacobi_tol = opts->jacobi_tol; o.warm_start = opts->warm_start;
+        o.jacobi_sweeps = opts->jacobi_sweeps; o.jacobi_tol = opts->jacobi_tol; o.warm_start = opts->warm_start; o.rho_tail = opts->rho_tail; o.tail_from = opts->tail_from;
     }
     return o;
 }
@@ -84,7 +84,7 @@ void cvxpnpl_default_opts(cvxpnpl_opts_t *opts)
     cvx::Opts o = cvx::default_opts();
     opts->eps = o.eps; opts->max_iters = o.max_iters; opts->rho = o.rho; opts->alpha = o.alpha;
     opts->first_check = o.first_check; opts->check_every = o.check_every; opts->res_tol = o.res_tol;
-    opts->jacobi_sweeps = o.jacobi_sweeps; opts->jacobi_tol = o.jacobi_tol; opts->warm_start = o.warm_start; opts->layout = CVXPNPL_LAYOUT_AUTO;
+    opts->jacobi_sweeps = o.jacobi_sweeps; opts->jacobi_tol = o.jacobi_tol; opts->warm_start = o.warm_start; opts->rho_tail = o.rho_tail; opts->tail_from = o.tail_from; opts->layout = CVXPNPL_LAYOUT_AUTO;
 }
 
 static int check_args(int64_t batch, int32_t n_p, const double *p2, const double *p3, int32_t n_l, const double *l2,

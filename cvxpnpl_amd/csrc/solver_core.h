@@ -59,13 +59,15 @@ struct Opts {
     int jacobi_sweeps; // cap on Jacobi sweeps per PSD projection
     double jacobi_tol; // a sweep whose largest |cos(g_p, g_q)| is below this ends the eigen-solve
     int warm_start;    // 1: start each eigen-solve from the previous iteration's eigenvectors
+    double rho_tail;   // penalty used from iteration tail_from on (the dual is rescaled at the switch)
+    int tail_from;     // <= 0: never switch
 };
 
 CVX_HD Opts default_opts()
 {
     Opts o;
     o.eps = 1e-9; o.max_iters = 2500; o.rho = 0.1; o.alpha = 1.4;
-    o.first_check = 3; o.check_every = 1; o.res_tol = 1e-5; o.jacobi_sweeps = 12; o.jacobi_tol = 3e-2; o.warm_start = 1;
+    o.first_check = 3; o.check_every = 1; o.res_tol = 1e-5; o.jacobi_sweeps = 12; o.jacobi_tol = 3e-2; o.warm_start = 1; o.rho_tail = 0.05; o.tail_from = 4;
     return o;
 }
 
@@ -737,7 +739,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
     // PSD slack of the certificate: gap <= tr (zSz + 4 delta) <= eps
     double delta = o.eps / (8.0 * tr);
     delta = delta < 1e-13 ? 1e-13 : delta;
-    const double irho = 1.0 / o.rho;
+    double rho = o.rho, irho = 1.0 / o.rho;
 
     double W[55], Wp[55];
     CVX_UNROLL for (int i = 0; i < 55; ++i) W[i] = 0;
@@ -796,7 +798,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                 v[i] = s * il;
                 vt[i] = st * il1;
             }
-            certify(Qs, W, Wp, v, o.rho, delta, c);
+            certify(Qs, W, Wp, v, rho, delta, c);
             next_check = next_check_after(it, o);
             bool gap_ok = c.ok && (tr * (fabs(c.zSz) + 4.0 * delta) <= (o.eps > 8e-13 * tr ? o.eps : 8e-13 * tr));
             if (!gap_ok && it >= 12) ++late_fails;
@@ -820,6 +822,14 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                 if (Zout) { CVX_UNROLL for (int i = 0; i < 55; ++i) Zout[i] = Wp[i]; }
                 done = true;
             }
+        }
+        if (!done && it == o.tail_from) {
+            // the few problems still running get a smaller penalty (measured: shorter tail); W = Wp + Wm
+            // with Wm = -S / rho, so keeping the dual S means rescaling Wm by rho / rho_tail
+            const double sc = rho / o.rho_tail;
+            CVX_UNROLL for (int i = 0; i < 55; ++i) W[i] = Wp[i] + (W[i] - Wp[i]) * sc;
+            rho = o.rho_tail;
+            irho = 1.0 / rho;
         }
         if (!done) {
             // X = Pi_aff(2 Wp - W - Qs / rho);  W <- W + alpha (X - Wp)

@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx
     // ---------------------------------------------------------------- ADMM
     double delta = o.eps / (8.0 * tr);
     delta = delta < 1e-13 ? 1e-13 : delta;
-    const double irho = 1.0 / o.rho;
+    double rho = o.rho, irho = 1.0 / o.rho;
     double W = (lane == 54) ? 1.0 : 0.0, Wp = 0.0;
     int it = 0, total_sweeps = 0, next_check = o.first_check, late_fails = 0;
     double fp_res = 1e300;
@@ -694,7 +694,7 @@ __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx
             double vloc[10];
 #pragma unroll
             for (int i = 0; i < 10; ++i) vloc[i] = L[L_V + i];
-            const bool cok = coop_certify(L, roles, Qs, W, Wp, vloc, o.rho, delta, Rc, pobj, zSz);
+            const bool cok = coop_certify(L, roles, Qs, W, Wp, vloc, rho, delta, Rc, pobj, zSz);
             const bool gap_ok = cok && (tr * (fabs(zSz) + 4.0 * delta) <= (o.eps > 8e-13 * tr ? o.eps : 8e-13 * tr));
             if (!gap_ok && it >= 12) ++late_fails;
             CVXW_SYNC();
@@ -747,6 +747,11 @@ __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx
                 rank_out = (int)L[L_M + 28];
                 done = true;
             }
+        }
+        if (!done && it == o.tail_from) { // smaller penalty for the slow tail; keeps the dual: Wm scales by rho / rho_tail
+            W = Wp + (W - Wp) * (rho / o.rho_tail);
+            rho = o.rho_tail;
+            irho = 1.0 / rho;
         }
         if (!done) {
             // X = Pi_aff(2 Wp - W - Qs / rho);  W <- W + alpha (X - Wp)

@@ -52,6 +52,8 @@ typedef struct {
     int32_t jacobi_sweeps; /* cap on Jacobi sweeps per PSD projection, default 12 */
     double jacobi_tol; /* eigen-solve ends after a sweep whose largest column cosine is below this, default 3e-2 */
     int32_t warm_start; /* 1 (default): each eigen-solve starts from the previous iteration's eigenvectors */
+    double rho_tail;    /* penalty from iteration tail_from on (dual rescaled at the switch), default 0.05 */
+    int32_t tail_from;  /* default 4; <= 0 never */
     int32_t layout;    /* CVXPNPL_LAYOUT_* */
 } cvxpnpl_opts_t;
 
