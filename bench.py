@@ -111,6 +111,7 @@ def main():
     outs = [(R, t, status, iters, cost, work)] + [tuple(torch.empty_like(x) for x in (R, t, status, iters, cost, work))
                                                    for _ in range(nstreams - 1)]
     step_no = [0]
+    pending = []  # (work, packed) of the gather in flight: overlapped with the next batch's solve
 
     def step():
         k = step_no[0] % nstreams
@@ -123,10 +124,16 @@ def main():
             if rc != 0:
                 raise RuntimeError(_lib.last_error())
             if gather:  # north-star config 4: results of every shard on every rank (RCCL over xGMI)
-                cdist.gather_results(cdist.pack_results(sR, st_, sst), world * batch, out=gathered)
+                while pending:  # at most one gather in flight; it ran while this batch was being solved
+                    pending.pop()[0].wait()
+                packed = cdist.pack_results(sR, st_, sst)
+                _, work_h = cdist.gather_results(packed, world * batch, out=gathered, async_op=True)
+                pending.append((work_h, packed))
         return k
 
     def barrier():
+        while pending:
+            pending.pop()[0].wait()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -200,7 +207,7 @@ def main():
                    "streams": nstreams,
                    "parallelism": f"batch-sharded x{world}" + (", RCCL all_gather of results" if gather else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                     "traffic": None, "kernel": "solve_wave_kernel" if opts.layout in (0, 2) else "solve_lane_kernel", "mean_launch_ms": 1e3 * mean_launch_s,
+                     "traffic": None, "kernel": "solve_wave_kernel" if (opts.layout == 2 or (opts.layout == 0 and batch < 98304)) else "solve_lane_kernel", "mean_launch_ms": 1e3 * mean_launch_s,
                      "algorithmic_bytes_per_problem": algorithmic_bytes(n_p, n_l),
                      "note": "VALU/latency-bound by construction (~500 B and ~1e5-1e6 flop per pose), see DESIGN.md"},
         "solver": {"certified_frac": float((st == 0).mean()), "status_hist": np.bincount(st, minlength=5).tolist(),

@@ -120,7 +120,10 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
     int64_t grid = (batch + block - 1) / block;
     if (grid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }
     int layout = opts ? opts->layout : CVXPNPL_LAYOUT_AUTO;
-    if (layout == CVXPNPL_LAYOUT_AUTO) layout = CVXPNPL_LAYOUT_WAVE;
+    // AUTO: a wavefront per problem keeps every SIMD busy and finishes each problem fast -- best up
+    // to ~1e5 problems; beyond that 64 problems per wavefront (lane layout) fill the chip on their
+    // own and win on instruction count (measured: 125 k problems 40 M/s vs 29 M/s; 10 k: 9 vs 19 M/s)
+    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch >= 98304 ? CVXPNPL_LAYOUT_LANE : CVXPNPL_LAYOUT_WAVE;
     if (layout == CVXPNPL_LAYOUT_WAVE) {
         cvxw::WaveArgs w;
         w.batch = batch; w.n_p = n_p; w.n_l = n_l; w.K_per_problem = K_per_problem;

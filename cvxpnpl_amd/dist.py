@@ -36,12 +36,15 @@ def unpack_results(packed: torch.Tensor):
     return packed[:, :9].reshape(n, 3, 3), packed[:, 9:12], packed[:, 12].to(torch.int32)
 
 
-def gather_results(packed_local: torch.Tensor, batch: int, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def gather_results(packed_local: torch.Tensor, batch: int, group=None, out: Optional[torch.Tensor] = None,
+                   async_op: bool = False):
     """All-gather the per-rank [n_r, 13] slices into the full [batch, 13] on every rank.
 
     Equal slices use one all_gather_into_tensor (a single RCCL collective; 13 MB per rank
     for config 4 -- a direct exchange over the 7 xGMI links, far below a millisecond);
-    ragged slices are padded to the largest one.
+    ragged slices are padded to the largest one.  With async_op=True (equal slices only) the
+    collective is only enqueued and (out, work) is returned: the caller overlaps it with the next
+    batch's solve and calls work.wait() before reading `out` (keep `packed_local` alive until then).
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -53,11 +56,12 @@ def gather_results(packed_local: torch.Tensor, batch: int, group=None, out: Opti
         out = torch.empty((batch, PACK), dtype=torch.float64, device=dev)
     if all(s == nmax for s in sizes):
         if dist.get_backend(group) == "nccl":
-            dist.all_gather_into_tensor(out, packed_local.contiguous(), group=group)
+            work = dist.all_gather_into_tensor(out, packed_local.contiguous(), group=group, async_op=async_op)
         else:
             chunks = list(out.split(nmax))
-            dist.all_gather(chunks, packed_local.contiguous(), group=group)
-        return out
+            work = dist.all_gather(chunks, packed_local.contiguous(), group=group, async_op=async_op)
+        return (out, work) if async_op else out
+    assert not async_op, "async gather needs equal shards"
     buf = torch.zeros((nmax, PACK), dtype=torch.float64, device=dev)
     buf[: sizes[rank]] = packed_local
     parts = [torch.empty_like(buf) for _ in range(world)]

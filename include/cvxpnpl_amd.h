@@ -36,7 +36,7 @@ enum {
 
 /* kernel layouts (A/B switch; all produce the same results) */
 enum {
-    CVXPNPL_LAYOUT_AUTO = 0,
+    CVXPNPL_LAYOUT_AUTO = 0, /* wave below 98304 problems per launch, lane above */
     CVXPNPL_LAYOUT_LANE = 1, /* one problem per lane, 64 problems per wavefront */
     CVXPNPL_LAYOUT_WAVE = 2  /* one problem per wavefront (cooperative lanes) */
 };

@@ -35,6 +35,13 @@ def _worker(rank, world, port, batch, out_dir):
     d = synth.make_pnp(batch, 8, 1.0, seed=5)
     R, t, st = cd.solve_sharded(torch.as_tensor(d["pts_2d"]), None, torch.as_tensor(d["pts_3d"]), None, d["K"], solver=_cpu_solver)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), R=R.numpy(), t=t.numpy(), st=st.numpy())
+    if batch % world == 0:  # the overlapped (async) gather bench.py uses, equal shards
+        lo, hi = cd.shard_range(batch, rank, world)
+        packed = cd.pack_results(R[lo:hi], t[lo:hi], st[lo:hi])
+        out, work = cd.gather_results(packed, batch, async_op=True)
+        work.wait()
+        R2, t2, st2 = cd.unpack_results(out)
+        assert torch.equal(R2, R) and torch.equal(t2, t) and torch.equal(st2, st)
     dist.barrier()
     dist.destroy_process_group()
 
