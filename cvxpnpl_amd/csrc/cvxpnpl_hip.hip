@@ -4,6 +4,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "../../include/cvxpnpl_amd.h"
 #include "problem_io.h"
 #include "solver_core.h"
@@ -24,14 +28,22 @@ struct BatchArgs {
 // ---------------------------------------------------------------------------------------
 // lane-per-problem: each lane owns one problem end to end (assembly -> ADMM -> certificate
 // -> pose); 64 independent problems per wavefront, no cross-lane traffic, no LDS.
-__global__ void __launch_bounds__(64) solve_lane_kernel(BatchArgs a, cvx::Opts o)
+// handoff_at > 0: hybrid schedule -- a lane that is not finished after handoff_at iterations parks
+// its iterate in ws[b] and queues b for resume_wave_kernel, so that one slow problem cannot hold
+// the other 63 lanes (and the whole launch) for hundreds of lane-serial iterations.
+__global__ void __launch_bounds__(64) solve_lane_kernel(BatchArgs a, cvx::Opts o, int handoff_at, int32_t *queue, double *ws)
 {
     int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= a.batch) return;
     cvx::ProblemView pv = cvx::make_view(b, a.n_p, a.p2, a.p3, a.n_l, a.l2, a.l3, a.K, a.K_per_problem);
     cvx::Solution sol;
     double Z[55];
-    cvx::solve_problem(pv, o, sol, a.Z ? Z : nullptr);
+    cvx::solve_problem(pv, o, sol, a.Z ? Z : nullptr, handoff_at, handoff_at > 0 ? ws + b * 56 : nullptr);
+    if (sol.status == -1) {
+        const int q = atomicAdd(&queue[0], 1);
+        queue[1 + q] = (int32_t)b;
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 9; ++i) a.R[b * 9 + i] = sol.R[i];
 #pragma unroll
@@ -56,6 +68,27 @@ __global__ void __launch_bounds__(64) assemble_kernel(BatchArgs a, double *Bout,
     for (int i = 0; i < 27; ++i) Bout[b * 27 + i] = ok ? B[i] : NAN;
     if (Qout)
         for (int i = 0; i < 45; ++i) Qout[b * 45 + i] = ok ? Q9[i] : NAN;
+}
+
+// grow-only scratch for the hybrid schedule, one per (device, stream): queue [1 + batch] int32 and
+// parked iterates [batch][56] doubles (only the slots of handed-off problems are touched)
+struct Workspace { void *ptr = nullptr; size_t bytes = 0; };
+std::mutex g_ws_mutex;
+std::map<std::pair<int, void *>, Workspace> g_ws;
+
+void *get_workspace(size_t bytes, void *stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    Workspace &w = g_ws[std::make_pair(dev, stream)];
+    if (w.bytes < bytes) {
+        if (w.ptr) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(w.ptr); }
+        w.ptr = nullptr; w.bytes = 0;
+        if (hipMalloc(&w.ptr, bytes) != hipSuccess) return nullptr;
+        w.bytes = bytes;
+    }
+    return w.ptr;
 }
 
 int set_err(const char *what, hipError_t e)
@@ -84,7 +117,7 @@ void cvxpnpl_default_opts(cvxpnpl_opts_t *opts)
     cvx::Opts o = cvx::default_opts();
     opts->eps = o.eps; opts->max_iters = o.max_iters; opts->rho = o.rho; opts->alpha = o.alpha;
     opts->first_check = o.first_check; opts->check_every = o.check_every; opts->res_tol = o.res_tol;
-    opts->jacobi_sweeps = o.jacobi_sweeps; opts->jacobi_tol = o.jacobi_tol; opts->warm_start = o.warm_start; opts->rho_tail = o.rho_tail; opts->tail_from = o.tail_from; opts->layout = CVXPNPL_LAYOUT_AUTO;
+    opts->jacobi_sweeps = o.jacobi_sweeps; opts->jacobi_tol = o.jacobi_tol; opts->warm_start = o.warm_start; opts->rho_tail = o.rho_tail; opts->tail_from = o.tail_from; opts->lane_iters = 10; opts->layout = CVXPNPL_LAYOUT_AUTO;
 }
 
 static int check_args(int64_t batch, int32_t n_p, const double *p2, const double *p3, int32_t n_l, const double *l2,
@@ -133,7 +166,26 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
         if (wgrid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }
         hipLaunchKernelGGL(cvxw::solve_wave_kernel, dim3((unsigned)wgrid), dim3(64 * cvxw::WPB), 0, s, w, o);
     } else {
-        hipLaunchKernelGGL(solve_lane_kernel, dim3((unsigned)grid), dim3(block), 0, s, a, o);
+        const int lane_iters = opts ? opts->lane_iters : 10;
+        if (lane_iters > 0 && o.max_iters > lane_iters) {
+            // hybrid: lanes for the first lane_iters iterations, survivors resumed one per wavefront
+            const size_t qbytes = ((size_t)(batch + 1) * sizeof(int32_t) + 255) & ~(size_t)255;
+            char *wsp = (char *)get_workspace(qbytes + (size_t)batch * 56 * sizeof(double), stream);
+            if (!wsp) { snprintf(g_err, sizeof(g_err), "cvxpnpl: workspace allocation failed"); return -2; }
+            int32_t *queue = (int32_t *)wsp;
+            double *ws = (double *)(wsp + qbytes);
+            hipError_t me = hipMemsetAsync(queue, 0, sizeof(int32_t), s);
+            if (me != hipSuccess) return set_err("hipMemsetAsync", me);
+            hipLaunchKernelGGL(solve_lane_kernel, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, queue, ws);
+            cvxw::WaveArgs w;
+            w.batch = batch; w.n_p = n_p; w.n_l = n_l; w.K_per_problem = K_per_problem;
+            w.p2 = d_pts_2d; w.p3 = d_pts_3d; w.l2 = d_line_2d; w.l3 = d_line_3d; w.K = d_K;
+            w.R = d_R; w.t = d_t; w.cost = d_cost; w.Z = d_Z; w.status = d_status; w.iters = d_iters; w.work = d_work;
+            const int64_t rgrid = batch < 8192 ? batch : 8192;
+            hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64 * cvxw::WPB), 0, s, w, o, queue, ws);
+        } else {
+            hipLaunchKernelGGL(solve_lane_kernel, dim3((unsigned)grid), dim3(block), 0, s, a, o, 0, nullptr, nullptr);
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err("solve kernel launch", e);

@@ -42,7 +42,8 @@ CVX_HD bool assemble(const ProblemView &v, double *B, double *Q9)
     return ok && (det == det) && det != 0.0;
 }
 
-CVX_HD void solve_problem(const ProblemView &v, const Opts &o, Solution &sol, double *Zout)
+CVX_HD void solve_problem(const ProblemView &v, const Opts &o, Solution &sol, double *Zout, int handoff_at = 0,
+                          double *handoff = nullptr)
 {
     double B[27], Q9[45];
     bool ok = assemble(v, B, Q9);
@@ -50,7 +51,7 @@ CVX_HD void solve_problem(const ProblemView &v, const Opts &o, Solution &sol, do
         CVX_UNROLL for (int i = 0; i < 45; ++i) Q9[i] = NAN;
         CVX_UNROLL for (int i = 0; i < 27; ++i) B[i] = NAN;
     }
-    solve_sdp(Q9, B, o, sol, Zout);
+    solve_sdp(Q9, B, o, sol, Zout, handoff_at, handoff);
     if (!ok) { CVX_UNROLL for (int i = 0; i < 3; ++i) sol.t[i] = NAN; }
 }
 

@@ -720,7 +720,11 @@ CVX_HD void fallback_pose(const double *Qs, double tr, const double *v, int rank
 }
 
 // Q9: 45 packed (unnormalised A^T A), B: 3x9.  Zout (optional, 55): final Z in vech order.
-CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution &sol, double *Zout)
+// handoff (optional, 56 doubles) with handoff_at > 0: a solve that is not finished after handoff_at
+// iterations stores W and the iteration count there, sets status = -1 and returns (hybrid
+// schedule: the wave-per-problem kernel resumes it).
+CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution &sol, double *Zout, int handoff_at = 0,
+                      double *handoff = nullptr)
 {
     double tr = 0;
     CVX_UNROLL for (int i = 0; i < 9; ++i) tr += Q9[qidx(i, i)];
@@ -752,6 +756,13 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
     double fp_res = 1e300;
     double Vn[10][10];
     while (!done) {
+        if (handoff_at > 0 && it >= handoff_at) { // W is the iterate after `it` completed iterations
+            CVX_UNROLL for (int i = 0; i < 55; ++i) handoff[i] = W[i];
+            handoff[55] = (double)it;
+            sol.status = -1;
+            sol.iters = it;
+            return;
+        }
         if (it == 0 && o.first_check > 1 && o.max_iters > 1) {
             // the initial iterate W0 = e9 e9^T is diagonal and PSD: its projection is itself and its
             // eigenvectors are the unit vectors -- the first iteration needs no eigen-solve

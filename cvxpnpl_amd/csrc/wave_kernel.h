@@ -407,13 +407,12 @@ struct WaveArgs {
     int32_t *status, *iters, *work;
 };
 
-__global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx::Opts o)
+// Solve problem b with the wavefront that calls this.  resume (optional): 56 doubles written by
+// the lane-layout kernel for a problem it handed off -- W (55, vech order) and the iteration
+// count -- the solve then continues from that iterate instead of starting at e9 e9^T.
+__device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opts &o, const int64_t b, double *L, const double *resume)
 {
-    __shared__ __attribute__((aligned(16))) double lds_all[WPB][LDSW];
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const int64_t b = (int64_t)blockIdx.x * WPB + wib;
-    if (b >= a.batch) return; // wave-uniform
-    double *L = lds_all[wib];
+    const int lane = threadIdx.x & 63;
     double2 *L2 = reinterpret_cast<double2 *>(L);
 
     // ---------------------------------------------------------------- lane roles
@@ -542,6 +541,14 @@ __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx
     double rho = o.rho, irho = 1.0 / o.rho;
     double W = (lane == 54) ? 1.0 : 0.0, Wp = 0.0;
     int it = 0, total_sweeps = 0, next_check = o.first_check, late_fails = 0;
+    bool cold = false; // resumed solves have no previous eigenvectors for their first eigen-solve
+    if (resume) {
+        W = resume[el];
+        it = (int)resume[55];
+        next_check = it + 1;
+        cold = true;
+        if (o.tail_from > 0 && it >= o.tail_from) { rho = o.rho_tail; irho = 1.0 / rho; }
+    }
     double fp_res = 1e300;
     int status = cvx::ST_NONFINITE, rank_out = 0;
     bool done = !finite;
@@ -549,7 +556,7 @@ __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx
 
     while (!done) {
         double sigma = 0.0;
-        if (it == 0 && o.first_check > 1 && o.max_iters > 1) {
+        if (it == 0 && !resume && o.first_check > 1 && o.max_iters > 1) {
             // W0 = e9 e9^T is diagonal and PSD: Wp = W0, eigenvectors = unit vectors, no eigen-solve
             Wp = W;
             L[L_VN + (2 * jk) * 10 + ji] = (ji == 2 * jk) ? 1.0 : 0.0;
@@ -567,7 +574,7 @@ __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx
         CVXW_SYNC();
         constexpr int CA = L_EX, CB = L_EX + 64, NA = L_EX + 128, NB = L_EX + 136;
         double ca, cb, al, be, gam;
-        if (o.warm_start && it > 0) {
+        if (o.warm_start && it > 0 && !cold) {
             // warm start: G = (W + sigma I) V_prev -- columns already nearly orthogonal when W moved
             // little.  Row ji of the two columns at position jk, then the full columns via LDS.
             const double2 *wr = L2 + (L_G + ji * 10) / 2;
@@ -629,6 +636,7 @@ __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx
             more = __any(coarse) && sweeps < o.jacobi_sweeps;
         } while (more);
         total_sweeps += sweeps;
+        cold = false;
         // ---- Wp = sum_{lam > 0} lam v v^T, from (g, w g) with w = lam / lam'^2
         const double lpa = sqrt(al), lpb = sqrt(be);
         const double lama = lpa - sigma, lamb = lpb - sigma;
@@ -790,6 +798,29 @@ __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx
             zv = zi * zj;
         } else zv = Wp;
         a.Z[b * 55 + lane] = zv;
+    }
+}
+
+__global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx::Opts o)
+{
+    __shared__ __attribute__((aligned(16))) double lds_all[WPB][LDSW];
+    const int wib = threadIdx.x >> 6;
+    const int64_t b = (int64_t)blockIdx.x * WPB + wib;
+    if (b >= a.batch) return; // wave-uniform
+    solve_one_wave(a, o, b, lds_all[wib], nullptr);
+}
+
+// Second phase of the hybrid schedule: the problems the lane-layout kernel did not finish within
+// its iteration cap, listed in queue[1 .. queue[0]], each resumed by one wavefront.
+__global__ void __launch_bounds__(64 * WPB, 2) resume_wave_kernel(WaveArgs a, cvx::Opts o, const int32_t *queue, const double *ws)
+{
+    __shared__ __attribute__((aligned(16))) double lds_all[WPB][LDSW];
+    const int wib = threadIdx.x >> 6;
+    const int count = queue[0];
+    for (int q = blockIdx.x * WPB + wib; q < count; q += gridDim.x * WPB) { // wave-uniform
+        const int64_t b = queue[1 + q];
+        solve_one_wave(a, o, b, lds_all[wib], ws + b * 56);
+        CVXW_SYNC();
     }
 }
 

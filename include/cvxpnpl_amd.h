@@ -54,6 +54,8 @@ typedef struct {
     int32_t warm_start; /* 1 (default): each eigen-solve starts from the previous iteration's eigenvectors */
     double rho_tail;    /* penalty from iteration tail_from on (dual rescaled at the switch), default 0.05 */
     int32_t tail_from;  /* default 4; <= 0 never */
+    int32_t lane_iters; /* lane layout: iterations before unfinished problems are handed to one wavefront
+                           each (hybrid schedule), default 10; 0 = never */
     int32_t layout;    /* CVXPNPL_LAYOUT_* */
 } cvxpnpl_opts_t;
 
