@@ -117,7 +117,7 @@ void cvxpnpl_default_opts(cvxpnpl_opts_t *opts)
     cvx::Opts o = cvx::default_opts();
     opts->eps = o.eps; opts->max_iters = o.max_iters; opts->rho = o.rho; opts->alpha = o.alpha;
     opts->first_check = o.first_check; opts->check_every = o.check_every; opts->res_tol = o.res_tol;
-    opts->jacobi_sweeps = o.jacobi_sweeps; opts->jacobi_tol = o.jacobi_tol; opts->warm_start = o.warm_start; opts->rho_tail = o.rho_tail; opts->tail_from = o.tail_from; opts->lane_iters = 5; opts->layout = CVXPNPL_LAYOUT_AUTO;
+    opts->jacobi_sweeps = o.jacobi_sweeps; opts->jacobi_tol = o.jacobi_tol; opts->warm_start = o.warm_start; opts->rho_tail = o.rho_tail; opts->tail_from = o.tail_from; opts->lane_iters = -1; opts->layout = CVXPNPL_LAYOUT_AUTO;
 }
 
 static int check_args(int64_t batch, int32_t n_p, const double *p2, const double *p3, int32_t n_l, const double *l2,
@@ -154,11 +154,11 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
     if (grid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }
     int layout = opts ? opts->layout : CVXPNPL_LAYOUT_AUTO;
     // AUTO: a wavefront per problem finishes each problem fast and keeps every SIMD busy at small
-    // batches; from ~12 k problems the hybrid schedule (64 problems per wavefront for the first
-    // lane_iters iterations, the unfinished ~20 % resumed one per wavefront) wins on instruction
-    // count.  Measured, one MI355X: 10 k problems 18.5 (wave) vs 16.9 (hybrid) M poses/s; 16 k:
-    // 22 vs 26; 49 k: 27 vs 54; 1 M: 30 vs 78.
-    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch >= 12288 ? CVXPNPL_LAYOUT_LANE : CVXPNPL_LAYOUT_WAVE;
+    // batches; from ~8 k problems the hybrid schedule (64 problems per wavefront for the first
+    // lane_iters iterations, the unfinished ones resumed one per wavefront) wins on instruction
+    // count.  Measured, one MI355X (M poses/s, wave vs hybrid): 4 k: 12.8 vs 9.5; 10 k: 18.5 vs 19.7;
+    // 16 k: 22 vs 28; 49 k: 27 vs 54; 1 M: 30 vs 78.
+    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch >= 8192 ? CVXPNPL_LAYOUT_LANE : CVXPNPL_LAYOUT_WAVE;
     if (layout == CVXPNPL_LAYOUT_WAVE) {
         cvxw::WaveArgs w;
         w.batch = batch; w.n_p = n_p; w.n_l = n_l; w.K_per_problem = K_per_problem;
@@ -168,7 +168,11 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
         if (wgrid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }
         hipLaunchKernelGGL(cvxw::solve_wave_kernel, dim3((unsigned)wgrid), dim3(64 * cvxw::WPB), 0, s, w, o);
     } else {
-        const int lane_iters = opts ? opts->lane_iters : 5;
+        // hand-off point of the hybrid schedule (-1 = by batch size): small launches leave spare SIMDs, so
+        // the lanes hand over early (3 iterations: one check) and the waves do more; big launches keep the
+        // cheap lane layout for 5 iterations.  Measured optimum: 10 k -> 3, 16 k -> 4, >= 32 k -> 5.
+        int lane_iters = opts ? opts->lane_iters : -1;
+        if (lane_iters < 0) lane_iters = batch < 12288 ? 3 : (batch < 24576 ? 4 : 5);
         if (lane_iters > 0 && o.max_iters > lane_iters) {
             // hybrid: lanes for the first lane_iters iterations, survivors resumed one per wavefront
             const size_t qbytes = ((size_t)(batch + 1) * sizeof(int32_t) + 255) & ~(size_t)255;

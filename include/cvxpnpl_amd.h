@@ -36,7 +36,7 @@ enum {
 
 /* kernel layouts (A/B switch; all produce the same results) */
 enum {
-    CVXPNPL_LAYOUT_AUTO = 0, /* wave below 12288 problems per launch, lane (hybrid) from there */
+    CVXPNPL_LAYOUT_AUTO = 0, /* wave below 8192 problems per launch, lane (hybrid) from there */
     CVXPNPL_LAYOUT_LANE = 1, /* one problem per lane, 64 per wavefront, for the first lane_iters iterations;
                                 unfinished problems are then resumed one per wavefront (hybrid schedule) */
     CVXPNPL_LAYOUT_WAVE = 2  /* one problem per wavefront (cooperative lanes) */
@@ -56,7 +56,7 @@ typedef struct {
     double rho_tail;    /* penalty from iteration tail_from on (dual rescaled at the switch), default 0.05 */
     int32_t tail_from;  /* default 4; <= 0 never */
     int32_t lane_iters; /* lane layout: iterations before unfinished problems are handed to one wavefront
-                           each (hybrid schedule), default 5; 0 = never */
+                           each (hybrid schedule); default -1 = by batch size (3, 4 or 5); 0 = never */
     int32_t layout;    /* CVXPNPL_LAYOUT_* */
 } cvxpnpl_opts_t;
 
