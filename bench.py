@@ -207,7 +207,7 @@ def main():
                    "streams": nstreams,
                    "parallelism": f"batch-sharded x{world}" + (", RCCL all_gather of results" if gather else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                     "traffic": None, "kernel": "solve_wave_kernel" if (opts.layout == 2 or (opts.layout == 0 and batch < 8192)) else "solve_lane_kernel + resume_wave_kernel", "mean_launch_ms": 1e3 * mean_launch_s,
+                     "traffic": None, "kernel": "solve_wave_kernel" if (opts.layout == 2 or (opts.layout == 0 and batch < 12288)) else "solve_lane_kernel + resume_wave_kernel", "mean_launch_ms": 1e3 * mean_launch_s,
                      "algorithmic_bytes_per_problem": algorithmic_bytes(n_p, n_l),
                      "note": "VALU/latency-bound by construction (~500 B and ~1e5-1e6 flop per pose), see DESIGN.md"},
         "solver": {"certified_frac": float((st == 0).mean()), "status_hist": np.bincount(st, minlength=5).tolist(),

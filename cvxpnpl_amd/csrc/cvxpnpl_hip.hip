@@ -154,11 +154,12 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
     if (grid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }
     int layout = opts ? opts->layout : CVXPNPL_LAYOUT_AUTO;
     // AUTO: a wavefront per problem finishes each problem fast and keeps every SIMD busy at small
-    // batches; from ~8 k problems the hybrid schedule (64 problems per wavefront for the first
+    // batches; from ~12 k problems the hybrid schedule (64 problems per wavefront for the first
     // lane_iters iterations, the unfinished ones resumed one per wavefront) wins on instruction
     // count.  Measured, one MI355X (M poses/s, wave vs hybrid): 4 k: 12.8 vs 9.5; 10 k: 18.5 vs 19.7;
-    // 16 k: 22 vs 28; 49 k: 27 vs 54; 1 M: 30 vs 78.
-    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch >= 8192 ? CVXPNPL_LAYOUT_LANE : CVXPNPL_LAYOUT_WAVE;
+    // 16 k: 22 vs 28; 49 k: 27 vs 54; 1 M: 30 vs 78.  At 10 k the two are within 6 %; the wave layout is
+    // kept there because it moves 7x less memory (no scratch spills: 16 MB vs 112 MB per launch).
+    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch >= 12288 ? CVXPNPL_LAYOUT_LANE : CVXPNPL_LAYOUT_WAVE;
     if (layout == CVXPNPL_LAYOUT_WAVE) {
         cvxw::WaveArgs w;
         w.batch = batch; w.n_p = n_p; w.n_l = n_l; w.K_per_problem = K_per_problem;

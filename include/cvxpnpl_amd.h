@@ -36,7 +36,7 @@ enum {
 
 /* kernel layouts (A/B switch; all produce the same results) */
 enum {
-    CVXPNPL_LAYOUT_AUTO = 0, /* wave below 8192 problems per launch, lane (hybrid) from there */
+    CVXPNPL_LAYOUT_AUTO = 0, /* wave below 12288 problems per launch, lane (hybrid) from there */
     CVXPNPL_LAYOUT_LANE = 1, /* one problem per lane, 64 per wavefront, for the first lane_iters iterations;
                                 unfinished problems are then resumed one per wavefront (hybrid schedule) */
     CVXPNPL_LAYOUT_WAVE = 2  /* one problem per wavefront (cooperative lanes) */
