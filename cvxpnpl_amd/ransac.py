@@ -1,0 +1,66 @@
+"""RANSAC on top of the batched solver (BASELINE config 5).
+
+The reference has no RANSAC; this is the natural consumer of tens of thousands of minimal
+hypotheses per frame: sample 4-subsets, solve them all in one launch, score every hypothesis by
+reprojection inliers over the whole scene, refit the best consensus set with one more (N = #inliers)
+solve.  Sampling and scoring are plain torch ops on the device (bandwidth-shaped, a few ms);
+the solves are the HIP path.
+"""
+from typing import Optional
+
+import torch
+
+from .api import pnp_batch
+
+
+def reprojection_inliers(R: torch.Tensor, t: torch.Tensor, K: torch.Tensor, pts_3d: torch.Tensor, pts_2d: torch.Tensor,
+                         thresh: float = 2.0, chunk: int = 8192) -> torch.Tensor:
+    """[H, M] bool: correspondence m is an inlier of hypothesis h (reprojection error < thresh px, in front
+    of the camera).  R [H,3,3], t [H,3], scene pts_3d [M,3], pts_2d [M,2]."""
+    outs = []
+    for lo in range(0, R.shape[0], chunk):
+        Rc, tc = R[lo:lo + chunk], t[lo:lo + chunk]
+        Xc = torch.einsum("hij,mj->hmi", Rc, pts_3d) + tc[:, None, :]
+        uv = torch.einsum("ij,hmj->hmi", K, Xc)
+        uv = uv[..., :2] / uv[..., 2:3]
+        err = torch.linalg.norm(uv - pts_2d[None], dim=-1)
+        outs.append((err < thresh) & (Xc[..., 2] > 0))
+    return torch.cat(outs)
+
+
+def ransac_pnp(pts_2d, pts_3d, K, n_hyp: int = 4096, thresh: float = 2.0, max_iters: int = 100, eps: float = 1e-6,
+               seed: Optional[int] = 0, refit: bool = True, device=None):
+    """Robust PnP for one scene with outliers.
+
+    pts_2d [M,2], pts_3d [M,3] (numpy or torch), K [3,3].  Returns dict with R [3,3], t [3],
+    inliers [M] bool, n_inliers, status of the final solve, n_certified hypotheses.
+    """
+    device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
+    x = torch.as_tensor(pts_2d, dtype=torch.float64, device=device)
+    X = torch.as_tensor(pts_3d, dtype=torch.float64, device=device)
+    Kd = torch.as_tensor(K, dtype=torch.float64, device=device)
+    M = X.shape[0]
+    g = torch.Generator(device=device)
+    if seed is not None:
+        g.manual_seed(seed)
+    # n_hyp random 4-subsets without replacement: top-4 of random keys per row
+    idx = torch.rand((n_hyp, M), generator=g, device=device).topk(4, dim=1).indices
+    res = pnp_batch(x[idx], X[idx], Kd, eps=eps, max_iters=max_iters)
+    usable = (res.status == 0) | (res.status == 2)
+    inl = reprojection_inliers(torch.nan_to_num(res.R), torch.nan_to_num(res.t), Kd, X, x, thresh)
+    score = torch.where(usable, inl.sum(1), torch.zeros_like(inl[:, 0], dtype=torch.long))
+    best = int(torch.argmax(score))
+    R, t, mask = res.R[best], res.t[best], inl[best]
+    final_status = int(res.status[best])
+    if refit and int(mask.sum()) >= 4:
+        for _ in range(2):  # refit on the consensus set, re-evaluate it once
+            fit = pnp_batch(x[mask][None], X[mask][None], Kd, eps=1e-9, max_iters=2500)
+            if int(fit.status[0]) not in (0, 2):
+                break
+            R, t, final_status = fit.R[0], fit.t[0], int(fit.status[0])
+            new = reprojection_inliers(R[None], t[None], Kd, X, x, thresh)[0]
+            if int(new.sum()) <= int(mask.sum()):
+                break
+            mask = new
+    return {"R": R, "t": t, "inliers": mask, "n_inliers": int(mask.sum()), "status": final_status,
+            "n_certified": int((res.status == 0).sum()), "n_hyp": n_hyp}

@@ -54,7 +54,7 @@ typedef struct {
     double jacobi_tol; /* eigen-solve ends after a sweep whose largest column cosine is below this, default 3e-2 */
     int32_t warm_start; /* 1 (default): each eigen-solve starts from the previous iteration's eigenvectors */
     double rho_tail;    /* penalty from iteration tail_from on (dual rescaled at the switch), default 0.05 */
-    int32_t tail_from;  /* default 4; <= 0 never */
+    int32_t tail_from;  /* default 3; <= 0 never */
     int32_t lane_iters; /* lane layout: iterations before unfinished problems are handed to one wavefront
                            each (hybrid schedule); default -1 = by batch size (3, 4 or 5); 0 = never */
     int32_t layout;    /* CVXPNPL_LAYOUT_* */

@@ -242,3 +242,19 @@ def test_minimal_problems_rank_gt1_flagged_and_recovered(gpu, orc):
             warnings.simplefilter("ignore")
             poses = ca.pnp(d["pts_2d"][i], d["pts_3d"][i], d["K"], max_iters=600)
         assert len(poses) in (2, 4)
+
+
+def test_ransac_wrapper_config5(gpu):
+    """BASELINE config 5 flavour: one scene, 30 % outliers, minimal hypotheses, consensus + refit."""
+    import torch
+
+    from cvxpnpl_amd import synth
+    from cvxpnpl_amd.ransac import ransac_pnp
+
+    d = synth.make_ransac(1, n_corr=100, outlier_frac=0.3, sigma=0.5, seed=46)
+    out = ransac_pnp(d["scene_2d"], d["scene_3d"], d["K"], n_hyp=2048, thresh=2.0, device=gpu)
+    truth = torch.as_tensor(d["inlier"], device=gpu)
+    assert out["n_inliers"] >= 0.95 * int(truth.sum())
+    assert int((out["inliers"] & ~truth).sum()) <= 2  # clutter does not sneak in
+    assert synth.geodesic(out["R"].cpu().numpy(), d["R_gt"]) < 2e-3  # 0.5 px noise on 70 inliers
+    assert out["status"] == 0
