@@ -59,7 +59,7 @@ def lib():
     L.cvxpnpl_assemble_batch.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cvxpnpl_assemble_batch.restype = C.c_int
-    L.cvxpnpl_recover_multi.argtypes = [_dp, _dp, _dp, _dp]
+    L.cvxpnpl_recover_multi.argtypes = [_dp, _dp, _dp, _dp, _dp]
     L.cvxpnpl_recover_multi.restype = C.c_int
     L.cvxpnpl_event_create.restype = C.c_void_p
     L.cvxpnpl_event_record.argtypes = [C.c_void_p, C.c_void_p]

@@ -107,14 +107,16 @@ def pnl_batch(line_2d, line_3d, K, eps: float = 1e-9, max_iters: int = 2500, **k
     return pnpl_batch(None, line_2d, None, line_3d, K, eps=eps, max_iters=max_iters, **kw)
 
 
-def recover_multi(Z55: np.ndarray, B27: np.ndarray) -> List[Tuple[np.ndarray, np.ndarray]]:
-    """All poses of a rank > 1 SDP solution (cvxpnpl.py:507 -> :221-343), host side."""
+def recover_multi(Z55: np.ndarray, B27: np.ndarray, Q45: Optional[np.ndarray] = None) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """All poses of a rank > 1 SDP solution (cvxpnpl.py:507 -> :221-343), host side.  With Q45 (packed
+    A^T A) every pose is Newton-polished on SO(3)."""
     L = _lib.lib()
     Z55 = np.ascontiguousarray(Z55, dtype=np.float64)
     B27 = np.ascontiguousarray(B27, dtype=np.float64)
     R, t = np.zeros((4, 3, 3)), np.zeros((4, 3))
     dp = C.POINTER(C.c_double)
-    n = L.cvxpnpl_recover_multi(Z55.ctypes.data_as(dp), B27.ctypes.data_as(dp), R.ctypes.data_as(dp), t.ctypes.data_as(dp))
+    q = np.ascontiguousarray(Q45, dtype=np.float64).ctypes.data_as(dp) if Q45 is not None else None
+    n = L.cvxpnpl_recover_multi(Z55.ctypes.data_as(dp), B27.ctypes.data_as(dp), q, R.ctypes.data_as(dp), t.ctypes.data_as(dp))
     if n < 0:
         raise NotImplementedError  # cvxpnpl.py:340-341
     return [(R[i].copy(), t[i].copy()) for i in range(n)]
@@ -137,8 +139,8 @@ def _single(pts_2d, line_2d, pts_3d, line_3d, K, eps, max_iters, verbose) -> Lis
             warnings.warn("The SDP solver did not return a valid solution. Increasing max_iters might solve the issue.")
         return [(np.full((3, 3), np.nan), np.full(3, np.nan))]
     if status == 1:  # rank > 1: cvxpnpl.py:507
-        Bt = _translation_map(p2, l2, p3, l3, Kn)
-        poses = recover_multi(res.Z[0].cpu().numpy(), Bt)
+        Bt, Qt = _translation_map(p2, l2, p3, l3, Kn)
+        poses = recover_multi(res.Z[0].cpu().numpy(), Bt, Qt)
         warnings.warn("The solution is not certifiably optimal.")
         return poses
     if status != 0:  # cvxpnpl.py:517-519
@@ -155,13 +157,14 @@ def _translation_map(p2, l2, p3, l3, Kn):
     a = [torch.as_tensor(x, device=dev).contiguous() if x is not None else None for x in (p2, p3, l2, l3)]
     Kd = torch.as_tensor(Kn, device=dev).contiguous()
     Bt = torch.empty((1, 27), dtype=torch.float64, device=dev)
+    Qt = torch.empty((1, 45), dtype=torch.float64, device=dev)
     n_p = a[1].shape[1] if a[1] is not None else 0
     n_l = a[3].shape[1] if a[3] is not None else 0
     rc = L.cvxpnpl_assemble_batch(1, n_p, _ptr(a[0]), _ptr(a[1]), n_l, _ptr(a[2]), _ptr(a[3]), _ptr(Kd), 0, _ptr(Bt),
-                                  C.c_void_p(0), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+                                  _ptr(Qt), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     if rc != 0:
         raise RuntimeError(_lib.last_error())
-    return Bt[0].cpu().numpy()
+    return Bt[0].cpu().numpy(), Qt[0].cpu().numpy()
 
 
 def pnp(pts_2d: np.ndarray, pts_3d: np.ndarray, K: np.ndarray, eps: float = 1e-9, max_iters: int = 2500,

@@ -205,7 +205,7 @@ int e6q3(const double (*A)[10], int rows, double *a_out, double *b_out, double *
 
 } // namespace
 
-extern "C" int cvxpnpl_recover_multi(const double *Z55, const double *B27, double *R_out, double *t_out)
+extern "C" int cvxpnpl_recover_multi(const double *Z55, const double *B27, const double *Q45, double *R_out, double *t_out)
 {
     for (int i = 0; i < 55; ++i) if (!(Z55[i] == Z55[i])) return -1;
     double w[10], V[10][10];
@@ -222,11 +222,19 @@ extern "C" int cvxpnpl_recover_multi(const double *Z55, const double *B27, doubl
         if (k != 2 && k != 4) return -1;
         // marginalised basis Vt (10 x k): last column v0 = top eigenvector / its last entry,
         // the others have their last entry eliminated (cvxpnpl.py:234-236)
+        // Deviation from the reference for robustness: v0 is built from the eigenvector (among the k
+        // used) with the largest last entry, not blindly from the top one -- for an exact two-fold
+        // ambiguity the eigenvalues are equal, the basis of the eigenspace is arbitrary and the top
+        // vector's last entry can be ~0 (the reference divides by it and returns NaN poses).
+        int piv = 9;
+        for (int c = 10 - k; c < 10; ++c) if (std::fabs(V[9][c]) > std::fabs(V[9][piv])) piv = c;
         double Vt[10][4];
-        for (int i = 0; i < 10; ++i) Vt[i][k - 1] = V[i][9] / V[9][9];
-        for (int a = 0; a < k - 1; ++a) {
-            int col = 10 - k + a;
+        for (int i = 0; i < 10; ++i) Vt[i][k - 1] = V[i][piv] / V[9][piv];
+        int a = 0;
+        for (int col = 10 - k; col < 10; ++col) {
+            if (col == piv) continue;
             for (int i = 0; i < 10; ++i) Vt[i][a] = V[i][col] - V[9][col] * Vt[i][k - 1];
+            ++a;
         }
         double P[21][4][4] = {};
         for (int q = 0; q < 21; ++q) {
@@ -272,6 +280,21 @@ extern "C" int cvxpnpl_recover_multi(const double *Z55, const double *B27, doubl
         double M0[9], R[9], r[9];
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) M0[i * 3 + j] = rc[s][3 * j + i];
         cvx::polar3(M0, R, 40);
+        // optional: Newton-polish r^T Q r on SO(3) from this candidate (each pose of an ambiguous problem is
+        // a local minimiser; Z from a first-order solver only locates it to ~1e-5)
+        if (Q45 && cvx::det3(R) > 0) {
+            double tr = 0, Qs[45];
+            for (int i = 0; i < 9; ++i) tr += Q45[cvx::qidx(i, i)];
+            if (tr > 0) {
+                for (int i = 0; i < 45; ++i) Qs[i] = Q45[i] / tr;
+                double Rp[9];
+                for (int i = 0; i < 9; ++i) Rp[i] = R[i];
+                cvx::so3_newton(Qs, Rp, 8);
+                bool fin = true;
+                for (int i = 0; i < 9; ++i) fin &= (Rp[i] == Rp[i]);
+                if (fin) for (int i = 0; i < 9; ++i) R[i] = Rp[i];
+            }
+        }
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r[3 * j + i] = R[i * 3 + j];
         for (int i = 0; i < 9; ++i) R_out[9 * s + i] = R[i];
         for (int i = 0; i < 3; ++i) {

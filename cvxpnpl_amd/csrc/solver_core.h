@@ -395,16 +395,35 @@ CVX_HD double eig_rotate(Eig &e, int p, int q)
     return g2 / ab;
 }
 
-// cyclic sweeps until the largest squared cosine met in a sweep is below tol2 (quadratic
-// convergence: the columns are then orthogonal to ~tol2 after that sweep), or max_sweeps
+// Round-robin (circle method) pairing: 9 steps of 5 disjoint pairs cover all 45 pairs.  Positions
+// a0..a4 / b0..b4 start as columns 2k / 2k+1; after every step a0 stays and the others move one
+// place along the ring a1 > a2 > a3 > a4 > b4 > b3 > b2 > b1 > b0 > a1 -- the same schedule the
+// wave-per-problem kernel runs across lanes.  The 5 rotations of a step touch disjoint columns, so
+// in the scalar (lane-per-problem) build they are independent instruction streams.
+CVX_HD constexpr int rr_col(int step, int pos /* 0..4 = a_k, 5..9 = b_k */)
+{
+    int a[5] = {0, 2, 4, 6, 8}, b[5] = {1, 3, 5, 7, 9};
+    for (int s = 0; s < step; ++s) {
+        const int na1 = b[0], nb4 = a[4];
+        a[4] = a[3]; a[3] = a[2]; a[2] = a[1]; a[1] = na1;
+        b[0] = b[1]; b[1] = b[2]; b[2] = b[3]; b[3] = b[4]; b[4] = nb4;
+    }
+    return pos < 5 ? a[pos] : b[pos - 5];
+}
+
+// sweeps until the largest squared cosine met in a sweep is below tol2 (quadratic convergence:
+// the columns are then orthogonal to ~tol2 after that sweep), or max_sweeps
 CVX_HD int eig_solve(Eig &e, int max_sweeps, double tol2)
 {
     int sweeps = 0;
     for (; sweeps < max_sweeps;) {
         eig_norms(e);
         double worst = 0;
-        CVX_UNROLL for (int p = 0; p < 9; ++p)
-            CVX_UNROLL for (int q = p + 1; q < 10; ++q) { double r = eig_rotate(e, p, q); worst = r > worst ? r : worst; }
+        CVX_UNROLL for (int st = 0; st < 9; ++st)
+            CVX_UNROLL for (int k = 0; k < 5; ++k) {
+                double r = eig_rotate(e, rr_col(st, k), rr_col(st, 5 + k));
+                worst = r > worst ? r : worst;
+            }
         ++sweeps;
         if (!(worst > tol2)) break;
     }
@@ -716,7 +735,10 @@ CVX_HD void fallback_pose(const double *Qs, double tr, const double *v, int rank
     sol.dobj = NAN;
     bool okf = true;
     CVX_UNROLL for (int i = 0; i < 9; ++i) okf &= (sol.R[i] == sol.R[i]);
-    sol.status = !okf ? ST_NONFINITE : (rank != 1 ? ST_RANK_GT1 : (det3(sol.R) < 0 ? ST_REFLECTION : ST_UNCERTIFIED));
+    // rank > 1 first: the rank-1 ratio is meaningless then (for an exact two-fold ambiguity the top
+    // eigenvector is z1 - z2 with last entry 0, so R above is NaN) -- the poses come from Z through the
+    // multi-solution recovery, like the reference's branch at cvxpnpl.py:506-507
+    sol.status = rank > 1 ? ST_RANK_GT1 : (!okf ? ST_NONFINITE : (rank != 1 ? ST_RANK_GT1 : (det3(sol.R) < 0 ? ST_REFLECTION : ST_UNCERTIFIED)));
 }
 
 // Q9: 45 packed (unnormalised A^T A), B: 3x9.  Zout (optional, 55): final Z in vech order.

@@ -738,7 +738,8 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
                 bool okf = true;
 #pragma unroll
                 for (int i = 0; i < 9; ++i) okf &= (Rf[i] == Rf[i]);
-                const int fst = !okf ? cvx::ST_NONFINITE : (rank != 1 ? cvx::ST_RANK_GT1 : (cvx::det3(Rf) < 0 ? cvx::ST_REFLECTION : cvx::ST_UNCERTIFIED));
+                const int fst = rank > 1 ? cvx::ST_RANK_GT1
+                                         : (!okf ? cvx::ST_NONFINITE : (rank != 1 ? cvx::ST_RANK_GT1 : (cvx::det3(Rf) < 0 ? cvx::ST_REFLECTION : cvx::ST_UNCERTIFIED)));
                 if (lane == 0) {
 #pragma unroll
                     for (int i = 0; i < 9; ++i) L[L_M + 16 + i] = Rf[i];

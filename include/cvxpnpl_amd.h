@@ -93,10 +93,12 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
 /*
  * Host side of the cold path: all poses of a rank > 1 solution (cvxpnpl.py:507 ->
  * _constraint_ortho_det :221-343 -> _re6q3 :156-218), from Z = vech^-1(x) and B.
- * Host pointers.  R_out [4][3][3], t_out [4][3].  Returns the number of poses (2 or 4),
- * 1 for a rank-1 Z, or -1 if rank is 0 / > 4 cannot be handled (reference: NotImplementedError).
+ * Host pointers.  R_out [4][3][3], t_out [4][3].  Q45 (optional, may be NULL): the packed 9x9 cost
+ * A^T A from cvxpnpl_assemble_batch; when given, every recovered pose is Newton-polished on SO(3)
+ * (the reference does not polish).  Returns the number of poses (2 or 4), 1 for a rank-1 Z, or -1
+ * if rank is 0 / Z is not finite (reference: NotImplementedError / NaN sentinel).
  */
-int cvxpnpl_recover_multi(const double *Z55, const double *B27, double *R_out, double *t_out);
+int cvxpnpl_recover_multi(const double *Z55, const double *B27, const double *Q45, double *R_out, double *t_out);
 
 /* Translation maps B (3x9 per problem, t = -B r; cvxpnpl.py:548) for callers that need them
  * on the host (cvxpnpl_recover_multi).  d_B [batch][27]. */

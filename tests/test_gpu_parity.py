@@ -258,3 +258,22 @@ def test_ransac_wrapper_config5(gpu):
     assert int((out["inliers"] & ~truth).sum()) <= 2  # clutter does not sneak in
     assert synth.geodesic(out["R"].cpu().numpy(), d["R_gt"]) < 2e-3  # 0.5 px noise on 70 inliers
     assert out["status"] == 0
+
+
+def test_planar_scene_returns_both_poses_through_dropin_api(gpu):
+    """A planar scene through cvxpnpl_amd.pnp: two poses, like the reference's rank-2 branch, the true
+    one among them."""
+    import warnings
+
+    import cvxpnpl_amd as ca
+    from cvxpnpl_amd import synth
+
+    d = synth.make_pnp(4, 8, 0.0, seed=3)
+    d["pts_3d"][:, :, 2] = 0.0
+    d["pts_2d"] = synth.project(d["pts_3d"], d["K"], d["R_gt"], d["t_gt"])
+    for i in range(4):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            poses = ca.pnp(d["pts_2d"][i], d["pts_3d"][i], d["K"])
+        assert len(poses) == 2
+        assert min(synth.geodesic(R, d["R_gt"][i]) + np.linalg.norm(t - d["t_gt"][i]) for R, t in poses) < 1e-9
