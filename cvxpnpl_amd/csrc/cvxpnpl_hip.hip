@@ -31,6 +31,7 @@ struct BatchArgs {
 // handoff_at > 0: hybrid schedule -- a lane that is not finished after handoff_at iterations parks
 // its iterate in ws[b] and queues b for resume_wave_kernel, so that one slow problem cannot hold
 // the other 63 lanes (and the whole launch) for hundreds of lane-serial iterations.
+template <bool TWIN>
 __global__ void __launch_bounds__(64) solve_lane_kernel(BatchArgs a, cvx::Opts o, int handoff_at, int32_t *queue, double *ws)
 {
     int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -38,7 +39,7 @@ __global__ void __launch_bounds__(64) solve_lane_kernel(BatchArgs a, cvx::Opts o
     cvx::ProblemView pv = cvx::make_view(b, a.n_p, a.p2, a.p3, a.n_l, a.l2, a.l3, a.K, a.K_per_problem);
     cvx::Solution sol;
     double Z[55];
-    cvx::solve_problem(pv, o, sol, a.Z ? Z : nullptr, handoff_at, handoff_at > 0 ? ws + b * 56 : nullptr);
+    cvx::solve_problem<TWIN>(pv, o, sol, a.Z ? Z : nullptr, handoff_at, handoff_at > 0 ? ws + b * 56 : nullptr);
     if (sol.status == -1) {
         const int q = atomicAdd(&queue[0], 1);
         queue[1 + q] = (int32_t)b;
@@ -183,7 +184,8 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
             double *ws = (double *)(wsp + qbytes);
             hipError_t me = hipMemsetAsync(queue, 0, sizeof(int32_t), s);
             if (me != hipSuccess) return set_err("hipMemsetAsync", me);
-            hipLaunchKernelGGL(solve_lane_kernel, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, queue, ws);
+            if (lane_iters < 6) hipLaunchKernelGGL(solve_lane_kernel<false>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, queue, ws);
+            else hipLaunchKernelGGL(solve_lane_kernel<true>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, queue, ws);
             cvxw::WaveArgs w;
             w.batch = batch; w.n_p = n_p; w.n_l = n_l; w.K_per_problem = K_per_problem;
             w.p2 = d_pts_2d; w.p3 = d_pts_3d; w.l2 = d_line_2d; w.l3 = d_line_3d; w.K = d_K;
@@ -191,7 +193,7 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
             const int64_t rgrid = batch < 8192 ? batch : 8192;
             hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64 * cvxw::WPB), 0, s, w, o, queue, ws);
         } else {
-            hipLaunchKernelGGL(solve_lane_kernel, dim3((unsigned)grid), dim3(block), 0, s, a, o, 0, nullptr, nullptr);
+            hipLaunchKernelGGL(solve_lane_kernel<true>, dim3((unsigned)grid), dim3(block), 0, s, a, o, 0, nullptr, nullptr);
         }
     }
     hipError_t e = hipGetLastError();

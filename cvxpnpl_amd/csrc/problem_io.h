@@ -42,6 +42,7 @@ CVX_HD bool assemble(const ProblemView &v, double *B, double *Q9)
     return ok && (det == det) && det != 0.0;
 }
 
+template <bool TWIN = true>
 CVX_HD void solve_problem(const ProblemView &v, const Opts &o, Solution &sol, double *Zout, int handoff_at = 0,
                           double *handoff = nullptr)
 {
@@ -51,7 +52,7 @@ CVX_HD void solve_problem(const ProblemView &v, const Opts &o, Solution &sol, do
         CVX_UNROLL for (int i = 0; i < 45; ++i) Q9[i] = NAN;
         CVX_UNROLL for (int i = 0; i < 27; ++i) B[i] = NAN;
     }
-    solve_sdp(Q9, B, o, sol, Zout, handoff_at, handoff);
+    solve_sdp<TWIN>(Q9, B, o, sol, Zout, handoff_at, handoff);
     if (!ok) { CVX_UNROLL for (int i = 0; i < 3; ++i) sol.t[i] = NAN; }
 }
 

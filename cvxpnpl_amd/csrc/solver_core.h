@@ -637,26 +637,50 @@ struct Cert {
     bool ok;
 };
 
-// Qs: 45 packed, trace-normalised.  W, Wp: current ADMM iterate and its PSD part.
-// v: unit top eigenvector of Wp (10).  delta: PSD slack.
-CVX_HD void certify(const double *Qs, const double *W, const double *Wp, const double *v, double rho, double delta, Cert &c)
+// Primal half of a certification attempt: round the candidate v (any multiple of [r; 1]) to a rotation
+// (cvxpnpl.py:504-505 + nearest proper rotation), Newton-polish r^T Qs r on SO(3).  Returns det of the
+// rounded matrix (<= 0: the candidate was a reflection and cannot certify) and pobj = r^T Qs r.
+CVX_HD double polish_candidate(const double *Qs, const double *v, double *R, double &pobj)
 {
-    c.ok = false;
-    // rank-1 rounding r_c = v[:9] / v[9] (cvxpnpl.py:504-505), then nearest proper rotation
     double iv = rcp(v[9]);
     double M0[9];
     CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) M0[i * 3 + j] = v[3 * j + i] * iv; // R[i][j] = r[3j+i]
     double d0 = det3(M0);
     if (d0 < 0) { CVX_UNROLL for (int i = 0; i < 9; ++i) M0[i] = -M0[i]; } // polish needs SO(3); a reflection cannot certify
-    polar3(M0, c.R, 8);
-    so3_newton(Qs, c.R, 6);
+    polar3(M0, R, 8);
+    so3_newton(Qs, R, 6);
+    double z[9], Qz[9];
+    CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) z[3 * j + i] = R[i * 3 + j];
+    q9_mul(Qs, z, Qz);
+    pobj = 0;
+    CVX_UNROLL for (int i = 0; i < 9; ++i) pobj += z[i] * Qz[i];
+    return d0;
+}
+
+// The two points of span{v1, v2} (orthonormal) with last entry 1 and squared norm 4.  For ANY rank-2
+// Z = w1 z1 z1^T + w2 z2 z2^T (z_i = [vec R_i; 1], |z_i|^2 = 4) whose range is span{v1, v2} these are
+// exactly z1 and z2: a line-circle intersection instead of the reference's 21-quadratic solve
+// (cvxpnpl.py:303-315).  Degenerates gracefully to the rank-1 ratio when v2 carries no weight.
+CVX_HD void twin_candidates(const double *v1, const double *v2, double *zp, double *zm)
+{
+    const double a = v1[9], b = v2[9], n2 = a * a + b * b;
+    const double inv = rcp(n2), rn = rsqrt_(n2);
+    const double rad = 4.0 - inv;
+    const double sq = rad > 0 ? sqrt(rad) : 0.0;
+    const double c1 = a * inv, c2 = b * inv, d1 = -b * rn * sq, d2 = a * rn * sq;
+    CVX_UNROLL for (int i = 0; i < 10; ++i) {
+        zp[i] = (c1 + d1) * v1[i] + (c2 + d2) * v2[i];
+        zm[i] = (c1 - d1) * v1[i] + (c2 - d2) * v2[i];
+    }
+}
+
+// Dual half: given the polished rotation c.R (and c.pobj), recover a dual and test it.
+CVX_HD void dual_certificate(const double *Qs, const double *W, const double *Wp, double rho, double delta, double d0, Cert &c)
+{
+    c.ok = false;
     double z[10];
     CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) z[3 * j + i] = c.R[i * 3 + j];
     z[9] = 1.0;
-    double Qz[9];
-    q9_mul(Qs, z, Qz);
-    c.pobj = 0;
-    CVX_UNROLL for (int i = 0; i < 9; ++i) c.pobj += z[i] * Qz[i];
     // dual hint S_h = -rho Wm = rho (Wp - W); S1 = S_h - P_null(S_h - Qs)  (in Qs + span A_i)
     double S[55], T[55];
     CVX_UNROLL for (int i = 0; i < 55; ++i) { S[i] = rho * (Wp[i] - W[i]); T[i] = S[i]; }
@@ -696,6 +720,14 @@ CVX_HD void certify(const double *Qs, const double *W, const double *Wp, const d
     CVX_UNROLL for (int i = 0; i < 10; ++i) S[sidx(i, i)] += delta;
     c.min_piv = ldl_min_pivot(S);
     c.ok = spd && (c.min_piv > 0) && (c.res < 1e-10) && (d0 > 0) && (c.pobj == c.pobj);
+}
+
+// Qs: 45 packed, trace-normalised.  W, Wp: current ADMM iterate and its PSD part.
+// v: candidate (multiple of [r; 1]), e.g. the unit top eigenvector of Wp.  delta: PSD slack.
+CVX_HD void certify(const double *Qs, const double *W, const double *Wp, const double *v, double rho, double delta, Cert &c)
+{
+    const double d0 = polish_candidate(Qs, v, c.R, c.pobj);
+    dual_certificate(Qs, W, Wp, rho, delta, d0, c);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -745,6 +777,9 @@ CVX_HD void fallback_pose(const double *Qs, double tr, const double *v, int rank
 // handoff (optional, 56 doubles) with handoff_at > 0: a solve that is not finished after handoff_at
 // iterations stores W and the iteration count there, sets status = -1 and returns (hybrid
 // schedule: the wave-per-problem kernel resumes it).
+// TWIN = false compiles the two-fold-ambiguity branch out (the lane phase of the hybrid schedule hands
+// off before iteration 6, where that branch starts, and the extra live state costs it registers).
+template <bool TWIN = true>
 CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution &sol, double *Zout, int handoff_at = 0,
                       double *handoff = nullptr)
 {
@@ -773,7 +808,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
     Eig e;
     Cert c;
     c.ok = false;
-    int it = 0, next_check = o.first_check, late_fails = 0;
+    int it = 0, next_check = o.first_check;
     bool done = false;
     double fp_res = 1e300;
     double Vn[10][10];
@@ -817,25 +852,71 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                 best = b1 ? n2 : best;
                 jm = b1 ? j : jm;
             }
-            // Two-fold ambiguous problems (two poses 180 degrees apart with nearly equal cost) make
-            // Z hover at the average of both: eigenvalues (~2, ~2), and the top eigenvector may be the
-            // non-optimal pose for hundreds of iterations.  From iteration 12 on, failed checks with a
-            // comparable second eigenvalue alternate between the top and the second eigenvector.
-            const bool two = it >= 12 && (sqrt(second) - e.sigma) > 0.5 * (sqrt(best) - e.sigma);
-            const bool use2 = two && (late_fails % 3 == 2);
-            const int jc = use2 ? j2 : jm;
-            double v[10], vt[10], il = rsqrt_(use2 ? second : best), il1 = rsqrt_(best);
+            // Two-fold ambiguous problems (two poses with equal or nearly equal cost -- every planar scene is
+            // one: R diag(-1,-1,1) has exactly the same algebraic cost) make Z converge to a rank-2 mixture
+            // of both, eigenvalues (~2, ~2), and the top eigenvector need not be either pose.  From iteration
+            // 6 on, when the second eigenvalue is comparable, both poses are read off the top-2 eigenspace
+            // in closed form (twin_candidates) and polished: equal cost => the problem IS two-fold ambiguous:
+            // stop with rank 2 and the exact Z = (z+ z+^T + z- z-^T) / 2, like the reference's rank-2 branch;
+            // otherwise the better one goes through the dual certificate.
+            const double l1 = sqrt(best) - e.sigma, l2 = sqrt(second) - e.sigma;
+            const bool two = TWIN && it >= 6 && l2 > 0.5 * l1;
+            double vt[10], v2[10], il1 = rsqrt_(best), il2 = rsqrt_(second);
             CVX_UNROLL for (int i = 0; i < 10; ++i) {
-                double s = 0, st = 0;
-                CVX_UNROLL for (int j = 0; j < 10; ++j) { s = (j == jc) ? e.G[j][i] : s; st = (j == jm) ? e.G[j][i] : st; }
-                v[i] = s * il;
-                vt[i] = st * il1;
+                double s1 = 0, s2 = 0;
+                CVX_UNROLL for (int j = 0; j < 10; ++j) { s1 = (j == jm) ? e.G[j][i] : s1; s2 = (j == j2) ? e.G[j][i] : s2; }
+                vt[i] = s1 * il1;
+                v2[i] = s2 * il2;
             }
-            certify(Qs, W, Wp, v, rho, delta, c);
+            bool ambiguous = false, twin_tested = false;
+            double Rm[9], fm = 0;
+            if (!two) {
+                certify(Qs, W, Wp, vt, rho, delta, c);
+            } else {
+                double zp[10], zm[10], fp;
+                twin_candidates(vt, v2, zp, zm);
+                const double dp = polish_candidate(Qs, zp, c.R, fp);
+                const double dm = polish_candidate(Qs, zm, Rm, fm);
+                double trc = 0;
+                bool fin = (fp == fp) && (fm == fm);
+                CVX_UNROLL for (int i = 0; i < 9; ++i) { trc += c.R[i] * Rm[i]; fin &= (c.R[i] == c.R[i]) && (Rm[i] == Rm[i]); }
+                const double gtol = (o.eps > 8e-13 * tr ? o.eps : 8e-13 * tr) * itr;
+                ambiguous = fin && dp > 0 && dm > 0 && fabs(fp - fm) <= gtol && trc < 2.9;
+                // Equal cost alone is not enough: a symmetric problem maps every stationary point to a twin of
+                // equal cost, local minima included.  The pair is accepted only with a certificate: z+ must pass
+                // the dual test (it is then a global optimum, and so is z- with the same cost).
+                if (ambiguous) {
+                    c.pobj = fp;
+                    dual_certificate(Qs, W, Wp, rho, delta, dp, c);
+                    ambiguous = c.ok && (tr * (fabs(c.zSz) + 4.0 * delta) <= (o.eps > 8e-13 * tr ? o.eps : 8e-13 * tr));
+                    twin_tested = true;
+                }
+                if (!ambiguous && !twin_tested) {
+                    const bool take_m = dm > 0 && (fm == fm) && (!(dp > 0) || !(fp == fp) || fm < fp);
+                    if (take_m) { CVX_UNROLL for (int i = 0; i < 9; ++i) c.R[i] = Rm[i]; }
+                    c.pobj = take_m ? fm : fp;
+                    dual_certificate(Qs, W, Wp, rho, delta, take_m ? dm : dp, c);
+                } else if (!ambiguous) {
+                    c.ok = false; // equal-cost twins whose certificate is not there yet: keep iterating
+                }
+            }
             next_check = next_check_after(it, o);
+            if (ambiguous) {
+                CVX_UNROLL for (int i = 0; i < 9; ++i) sol.R[i] = c.R[i];
+                sol.cost = tr * c.pobj;
+                sol.dobj = NAN;
+                sol.status = ST_RANK_GT1;
+                sol.rank = 2;
+                if (Zout) {
+                    double za[10], zb[10];
+                    CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) { za[3 * j + i] = c.R[i * 3 + j]; zb[3 * j + i] = Rm[i * 3 + j]; }
+                    za[9] = 1.0; zb[9] = 1.0;
+                    CVX_UNROLL for (int i = 0; i < 10; ++i) CVX_UNROLL for (int j = i; j < 10; ++j) Zout[sidx(i, j)] = 0.5 * (za[i] * za[j] + zb[i] * zb[j]);
+                }
+                done = true;
+            }
             bool gap_ok = c.ok && (tr * (fabs(c.zSz) + 4.0 * delta) <= (o.eps > 8e-13 * tr ? o.eps : 8e-13 * tr));
-            if (!gap_ok && it >= 12) ++late_fails;
-            if (gap_ok) {
+            if (gap_ok && !done) {
                 CVX_UNROLL for (int i = 0; i < 9; ++i) sol.R[i] = c.R[i];
                 sol.cost = tr * c.pobj;
                 sol.dobj = tr * (c.pobj - c.zSz - 4.0 * delta);
@@ -848,7 +929,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                     CVX_UNROLL for (int i = 0; i < 10; ++i) CVX_UNROLL for (int j = i; j < 10; ++j) Zout[sidx(i, j)] = z[i] * z[j];
                 }
                 done = true;
-            } else if (last) {
+            } else if (last && !done) {
                 int rank = 0;
                 CVX_UNROLL for (int j = 0; j < 10; ++j) rank += (sqrt(e.n2[j]) - e.sigma) > 1e-3;
                 fallback_pose(Qs, tr, vt, rank, sol);

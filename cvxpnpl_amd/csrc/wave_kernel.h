@@ -33,10 +33,10 @@ constexpr int L_Y = 320;    // 200  (g, w g) per [slot][row]
 constexpr int L_X = 520;    // 64   entry scratch (affine projection gathers)
 constexpr int L_G = 584;    // 100  full 10x10
 constexpr int L_B = 684;    // 28   translation map B (27)
-constexpr int L_M = 712;    // 40   misc scalars / results of lane 0
-constexpr int L_V = 752;    // 20   candidate eigenvectors (top, runner-up)
-constexpr int L_VN = 772;   // 100  unit eigenvectors of the previous iterate [position][row] (warm start)
-constexpr int LDSW = 872;
+constexpr int L_M = 712;    // 56   misc scalars / results (16.. R, 25.. cost, dobj, status, rank; 30.., 40.. twin R's)
+constexpr int L_V = 768;    // 20   candidate eigenvectors (top, runner-up)
+constexpr int L_VN = 788;   // 100  unit eigenvectors of the previous iterate [position][row] (warm start)
+constexpr int LDSW = 888;
 
 struct LaneTab {
     signed char ei[64], ej[64], p1[64], p2[64], s0[64], s1[64], s2[64], diag[64];
@@ -233,8 +233,9 @@ __device__ __forceinline__ double coop_ldl(double *L, const Roles &r, double &Me
 // Cooperative version of cvx::certify (solver_core.h): identical mathematics, all 64 lanes.
 // Inputs: entry-lane values Qs, W, Wp; unit top eigenvector v (10, LDS pointer); outputs R
 // (row-major, every lane), pobj, zSz.  Returns the wave-uniform verdict c.ok of cvx::certify.
-__device__ __forceinline__ bool coop_certify(double *L, const Roles &r, double Qs, double W, double Wp, const double *v,
-                                             double rho, double delta, double *R, double &pobj, double &zSz)
+// Primal half (cvx::polish_candidate, all lanes): candidate v (any multiple of [r; 1]) -> rotation R
+// (every lane), pobj = r^T Qs r; returns the determinant of the rounded matrix.
+__device__ __forceinline__ double coop_polish(double *L, const Roles &r, double Qs, const double *v, double *R, double &pobj)
 {
     double2 *L2 = reinterpret_cast<double2 *>(L);
     const int lane = r.lane;
@@ -342,6 +343,25 @@ __device__ __forceinline__ bool coop_certify(double *L, const Roles &r, double Q
         if (lane < 9) part = L[C_XV + lane] * dot10(L2 + (C_QF + lane * 10) / 2, L2 + C_XV / 2);
         pobj = wave_sum(part);
     }
+    return d0;
+}
+
+// Dual half (cvx::dual_certificate, all lanes) for the rotation R: returns the verdict c.ok.
+__device__ __forceinline__ bool coop_dual(double *L, const Roles &r, double Qs, double W, double Wp, const double *R, double d0,
+                                          double pobj, double rho, double delta, double &zSz)
+{
+    double2 *L2 = reinterpret_cast<double2 *>(L);
+    const int lane = r.lane;
+    const int xsrc = kXTab.src[lane < 40 ? lane : 0];
+    const double xsgn = (double)kXTab.sgn[lane < 40 ? lane : 0];
+    // z and the tangent vectors of R (the polish may have left those of another candidate in LDS)
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) L[C_RL + i] = R[i];
+    }
+    CVXW_SYNC();
+    if (lane < 40) L[C_XV + lane] = (lane == 9) ? 1.0 : xsgn * L[C_RL + xsrc];
+    CVXW_SYNC();
     // ---- dual hint S_h = rho (Wp - W); S1 = S_h - P_null(S_h - Qs)
     const double Sh = rho * (Wp - W);
     double S = Sh - coop_proj(L, r, Sh - (r.ej < 9 ? Qs : 0.0), 0.0);
@@ -397,6 +417,14 @@ __device__ __forceinline__ bool coop_certify(double *L, const Roles &r, double Q
     double Se = S + (r.is_diag ? delta : 0.0), dummy = 0.0;
     const double minp = coop_ldl<false>(L, r, Se, dummy);
     return (minpM > 0) && (minp > 0) && (res < 1e-10) && (d0 > 0) && (pobj == pobj);
+}
+
+// both halves (cvx::certify)
+__device__ __forceinline__ bool coop_certify(double *L, const Roles &r, double Qs, double W, double Wp, const double *v,
+                                             double rho, double delta, double *R, double &pobj, double &zSz)
+{
+    const double d0 = coop_polish(L, r, Qs, v, R, pobj);
+    return coop_dual(L, r, Qs, W, Wp, R, d0, pobj, rho, delta, zSz);
 }
 
 struct WaveArgs {
@@ -540,7 +568,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
     delta = delta < 1e-13 ? 1e-13 : delta;
     double rho = o.rho, irho = 1.0 / o.rho;
     double W = (lane == 54) ? 1.0 : 0.0, Wp = 0.0;
-    int it = 0, total_sweeps = 0, next_check = o.first_check, late_fails = 0;
+    int it = 0, total_sweeps = 0, next_check = o.first_check;
     bool cold = false; // resumed solves have no previous eigenvectors for their first eigen-solve
     if (resume) {
         W = resume[el];
@@ -682,46 +710,94 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
             int rank = 0;
 #pragma unroll
             for (int s = 0; s < 10; ++s) rank += (sqrt(L[L_M + s]) - sigma) > 1e-3;
-            // candidates: the top eigenvector; for a late failed check with a comparable second
-            // eigenvalue (two-fold ambiguous problems, see solver_core.h) also the second one
-            const bool two = it >= 12 && (sqrt(second) - sigma) > 0.5 * (sqrt(best) - sigma);
+            // candidates (see cvx::solve_sdp): the top eigenvector; from iteration 6 on, with a comparable
+            // second eigenvalue, the two poses of the top-2 eigenspace in closed form (cvx::twin_candidates)
+            const double l1 = sqrt(best) - sigma, l2 = sqrt(second) - sigma;
+            const bool two = it >= 6 && l2 > 0.5 * l1;
             double Rc[9], pobj = 0, zSz = 0;
-            // the candidate of this check: top eigenvector, or -- alternating on late failed checks
-            // of two-fold ambiguous problems -- the runner-up.  Saved to LDS first: the certificate
-            // reuses the L_Y region.
-            const bool use2 = two && (late_fails % 3 == 2);
-            {
-                const int sl = use2 ? s2nd : smax;
-                const double il = cvx::rsqrt_(use2 ? second : best), il1 = cvx::rsqrt_(best);
+            {   // unit eigenvectors saved to LDS first: the certificate reuses the L_Y region
+                const double il1 = cvx::rsqrt_(best), il2 = cvx::rsqrt_(second);
                 if (lane < 10) {
-                    L[L_V + lane] = L[L_Y + 2 * (sl * 10 + lane)] * il;
-                    L[L_V + 10 + lane] = L[L_Y + 2 * (smax * 10 + lane)] * il1; // top one, for the fallback
+                    L[L_V + lane] = L[L_Y + 2 * (smax * 10 + lane)] * il1;
+                    L[L_V + 10 + lane] = L[L_Y + 2 * (s2nd * 10 + lane)] * il2;
                 }
             }
             CVXW_SYNC();
-            double vloc[10];
+            bool gap_ok = false, ambiguous = false;
+            const double gap_tol = o.eps > 8e-13 * tr ? o.eps : 8e-13 * tr;
+            if (!two) {
+                double vloc[10];
 #pragma unroll
-            for (int i = 0; i < 10; ++i) vloc[i] = L[L_V + i];
-            const bool cok = coop_certify(L, roles, Qs, W, Wp, vloc, rho, delta, Rc, pobj, zSz);
-            const bool gap_ok = cok && (tr * (fabs(zSz) + 4.0 * delta) <= (o.eps > 8e-13 * tr ? o.eps : 8e-13 * tr));
-            if (!gap_ok && it >= 12) ++late_fails;
+                for (int i = 0; i < 10; ++i) vloc[i] = L[L_V + i];
+                const bool cok = coop_certify(L, roles, Qs, W, Wp, vloc, rho, delta, Rc, pobj, zSz);
+                gap_ok = cok && (tr * (fabs(zSz) + 4.0 * delta) <= gap_tol);
+            } else {
+                // z+- = (c1 +- d1) v1 + (c2 +- d2) v2: last entry 1, squared norm 4
+                const double ta = L[L_V + 9], tb = L[L_V + 19], n2 = ta * ta + tb * tb;
+                const double inv = cvx::rcp(n2), rn = cvx::rsqrt_(n2), rad = 4.0 - inv;
+                const double sq = rad > 0 ? sqrt(rad) : 0.0;
+                const double c1 = ta * inv, c2 = tb * inv, d1 = -tb * rn * sq, d2 = ta * rn * sq;
+                double zc[10], fp, fm;
+#pragma unroll
+                for (int i = 0; i < 10; ++i) zc[i] = (c1 + d1) * L[L_V + i] + (c2 + d2) * L[L_V + 10 + i];
+                const double dp = coop_polish(L, roles, Qs, zc, Rc, fp);
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) L[L_M + 30 + i] = Rc[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 10; ++i) zc[i] = (c1 - d1) * L[L_V + i] + (c2 - d2) * L[L_V + 10 + i];
+                CVXW_SYNC();
+                const double dm = coop_polish(L, roles, Qs, zc, Rc, fm);
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) L[L_M + 40 + i] = Rc[i];
+                }
+                CVXW_SYNC();
+                double trc = 0;
+                bool fin = (fp == fp) && (fm == fm);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { const double rp = L[L_M + 30 + i]; trc += rp * Rc[i]; fin = fin && (rp == rp) && (Rc[i] == Rc[i]); }
+                const bool twins = fin && dp > 0 && dm > 0 && fabs(fp - fm) <= gap_tol * itr && trc < 2.9;
+                // equal-cost twins: the pair is accepted only if z+ passes the dual test (then both are
+                // global optima: the problem is exactly two-fold ambiguous -> rank 2, like the reference)
+                const bool take_m = !twins && dm > 0 && (fm == fm) && (!(dp > 0) || !(fp == fp) || fm < fp);
+                if (!take_m) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) Rc[i] = L[L_M + 30 + i];
+                }
+                pobj = take_m ? fm : fp;
+                const bool cok = coop_dual(L, roles, Qs, W, Wp, Rc, take_m ? dm : dp, pobj, rho, delta, zSz);
+                const bool ok = cok && (tr * (fabs(zSz) + 4.0 * delta) <= gap_tol);
+                ambiguous = twins && ok;
+                gap_ok = !twins && ok;
+            }
             CVXW_SYNC();
-            if (gap_ok) {
+            if (lane == 0) L[L_M + 29] = ambiguous ? 1.0 : 0.0;
+            if (ambiguous) {
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) L[L_M + 16 + i] = Rc[i];
+                    L[L_M + 25] = tr * pobj; L[L_M + 26] = NAN;
+                    L[L_M + 27] = (double)cvx::ST_RANK_GT1; L[L_M + 28] = 2.0;
+                }
+            }
+            if (gap_ok && !ambiguous) {
                 if (lane == 0) {
 #pragma unroll
                     for (int i = 0; i < 9; ++i) L[L_M + 16 + i] = Rc[i];
                     L[L_M + 25] = tr * pobj; L[L_M + 26] = tr * (pobj - zSz - 4.0 * delta);
                     L[L_M + 27] = (double)cvx::ST_CERTIFIED; L[L_M + 28] = 1.0;
                 }
-            } else if (last) {
+            } else if (last && !ambiguous) {
                 // cold path: the reference's recovery from the uncertified iterate (cvx::fallback_pose):
                 // R = U V^T of the rank-1 ratio (no determinant fix), cost = r^T Q r via the LDS copy of Qs
                 double M0[9], Rf[9];
-                const double iv = cvx::rcp(L[L_V + 19]);
+                const double iv = cvx::rcp(L[L_V + 9]);
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) M0[i * 3 + j] = L[L_V + 10 + 3 * j + i] * iv;
+                    for (int j = 0; j < 3; ++j) M0[i * 3 + j] = L[L_V + 3 * j + i] * iv;
                 cvx::polar3(M0, Rf, 12);
                 if (lane < 10) L[C_XV + lane] = lane == 9 ? 1.0 : Rf[0]; // placeholder, overwritten below
                 CVXW_SYNC();
@@ -747,11 +823,11 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
                     L[L_M + 27] = (double)fst; L[L_M + 28] = (double)rank;
                 }
             }
-            if (lane == 0) L[L_M + 15] = gap_ok ? 1.0 : 0.0;
+            if (lane == 0) L[L_M + 15] = (gap_ok && !ambiguous) ? 1.0 : 0.0;
             CVXW_SYNC();
             certified = L[L_M + 15] != 0.0;
             next_check = cvx::next_check_after(it, o);
-            if (certified || last) {
+            if (certified || last || ambiguous) {
                 status = (int)L[L_M + 27];
                 rank_out = (int)L[L_M + 28];
                 done = true;
@@ -797,6 +873,10 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
             const double zi = ei == 9 ? 1.0 : L[L_M + 16 + (ei % 3) * 3 + ei / 3];
             const double zj = ej == 9 ? 1.0 : L[L_M + 16 + (ej % 3) * 3 + ej / 3];
             zv = zi * zj;
+        } else if (L[L_M + 29] != 0.0) { // exactly two-fold ambiguous: Z = (z+ z+^T + z- z-^T) / 2
+            const double ai = ei == 9 ? 1.0 : L[L_M + 30 + (ei % 3) * 3 + ei / 3], aj = ej == 9 ? 1.0 : L[L_M + 30 + (ej % 3) * 3 + ej / 3];
+            const double bi = ei == 9 ? 1.0 : L[L_M + 40 + (ei % 3) * 3 + ei / 3], bj = ej == 9 ? 1.0 : L[L_M + 40 + (ej % 3) * 3 + ej / 3];
+            zv = 0.5 * (ai * aj + bi * bj);
         } else zv = Wp;
         a.Z[b * 55 + lane] = zv;
     }
