@@ -809,7 +809,8 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
     Cert c;
     c.ok = false;
     int it = 0, next_check = o.first_check;
-    bool done = false;
+    bool done = false, have_prev = false;
+    double Rprev[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, fprev = 0;
     double fp_res = 1e300;
     double Vn[10][10];
     while (!done) {
@@ -871,7 +872,27 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
             bool ambiguous = false, twin_tested = false;
             double Rm[9], fm = 0;
             if (!two) {
-                certify(Qs, W, Wp, vt, rho, delta, c);
+                // 4 of 5 repeated checks round to the pose the previous check already polished (it was the
+                // dual that was not ready): if the raw rank-1 ratio is within 0.3 (Frobenius) of that
+                // rotation, reuse it and go straight to the dual test
+                double M0[9], dist2 = 0;
+                const double iv = rcp(vt[9]);
+                CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) {
+                    M0[i * 3 + j] = vt[3 * j + i] * iv;
+                    dist2 += (M0[i * 3 + j] - Rprev[i * 3 + j]) * (M0[i * 3 + j] - Rprev[i * 3 + j]);
+                }
+                double d0;
+                if (have_prev && dist2 < 0.09) {
+                    CVX_UNROLL for (int i = 0; i < 9; ++i) c.R[i] = Rprev[i];
+                    c.pobj = fprev;
+                    d0 = 1.0;
+                } else {
+                    d0 = polish_candidate(Qs, vt, c.R, c.pobj);
+                }
+                dual_certificate(Qs, W, Wp, rho, delta, d0, c);
+                have_prev = d0 > 0 && (c.pobj == c.pobj);
+                CVX_UNROLL for (int i = 0; i < 9; ++i) Rprev[i] = c.R[i];
+                fprev = c.pobj;
             } else {
                 double zp[10], zm[10], fp;
                 twin_candidates(vt, v2, zp, zm);

@@ -33,10 +33,10 @@ constexpr int L_Y = 320;    // 200  (g, w g) per [slot][row]
 constexpr int L_X = 520;    // 64   entry scratch (affine projection gathers)
 constexpr int L_G = 584;    // 100  full 10x10
 constexpr int L_B = 684;    // 28   translation map B (27)
-constexpr int L_M = 712;    // 56   misc scalars / results (16.. R, 25.. cost, dobj, status, rank; 30.., 40.. twin R's)
-constexpr int L_V = 768;    // 20   candidate eigenvectors (top, runner-up)
-constexpr int L_VN = 788;   // 100  unit eigenvectors of the previous iterate [position][row] (warm start)
-constexpr int LDSW = 888;
+constexpr int L_M = 712;    // 64   misc: 0.. slot norms, 16.. R, 25.. cost, dobj, status, rank, 30../40.. twin R's, 50.. previous R
+constexpr int L_V = 776;    // 20   candidate eigenvectors (top, runner-up)
+constexpr int L_VN = 796;   // 100  unit eigenvectors of the previous iterate [position][row] (warm start)
+constexpr int LDSW = 896;
 
 struct LaneTab {
     signed char ei[64], ej[64], p1[64], p2[64], s0[64], s1[64], s2[64], diag[64];
@@ -569,6 +569,8 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
     double rho = o.rho, irho = 1.0 / o.rho;
     double W = (lane == 54) ? 1.0 : 0.0, Wp = 0.0;
     int it = 0, total_sweeps = 0, next_check = o.first_check;
+    bool have_prev = false; // L_M + 50.. holds the rotation polished by the previous check
+    double fprev = 0.0;
     bool cold = false; // resumed solves have no previous eigenvectors for their first eigen-solve
     if (resume) {
         W = resume[el];
@@ -729,8 +731,34 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
                 double vloc[10];
 #pragma unroll
                 for (int i = 0; i < 10; ++i) vloc[i] = L[L_V + i];
-                const bool cok = coop_certify(L, roles, Qs, W, Wp, vloc, rho, delta, Rc, pobj, zSz);
+                // repeated checks mostly round to the pose the previous check already polished (see
+                // cvx::solve_sdp): reuse it when the raw rank-1 ratio is within 0.3 of that rotation
+                double dist2 = 0;
+                {
+                    const double iv = cvx::rcp(vloc[9]);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) { const double dd = vloc[3 * j + i] * iv - L[L_M + 50 + i * 3 + j]; dist2 += dd * dd; }
+                }
+                double d0;
+                if (have_prev && dist2 < 0.09) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) Rc[i] = L[L_M + 50 + i];
+                    pobj = fprev;
+                    d0 = 1.0;
+                } else {
+                    d0 = coop_polish(L, roles, Qs, vloc, Rc, pobj);
+                }
+                const bool cok = coop_dual(L, roles, Qs, W, Wp, Rc, d0, pobj, rho, delta, zSz);
                 gap_ok = cok && (tr * (fabs(zSz) + 4.0 * delta) <= gap_tol);
+                have_prev = d0 > 0 && (pobj == pobj);
+                fprev = pobj;
+                CVXW_SYNC();
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) L[L_M + 50 + i] = Rc[i];
+                }
             } else {
                 // z+- = (c1 +- d1) v1 + (c2 +- d2) v2: last entry 1, squared norm 4
                 const double ta = L[L_V + 9], tb = L[L_V + 19], n2 = ta * ta + tb * tb;
