@@ -51,7 +51,7 @@ typedef struct {
     int32_t check_every; /* then every this many, default 1 */
     double res_tol;    /* fixed-point residual at which an uncertifiable problem stops, default 1e-5 */
     int32_t jacobi_sweeps; /* cap on Jacobi sweeps per PSD projection, default 12 */
-    double jacobi_tol; /* eigen-solve ends after a sweep whose largest column cosine is below this, default 3e-2 */
+    double jacobi_tol; /* eigen-solve ends after a sweep whose largest column cosine is below this, default 6e-2 */
     int32_t warm_start; /* 1 (default): each eigen-solve starts from the previous iteration's eigenvectors */
     double rho_tail;    /* penalty from iteration tail_from on (dual rescaled at the switch), default 0.05 */
     int32_t tail_from;  /* default 3; <= 0 never */
