@@ -411,6 +411,37 @@ CVX_HD constexpr int rr_col(int step, int pos /* 0..4 = a_k, 5..9 = b_k */)
     return pos < 5 ? a[pos] : b[pos - 5];
 }
 
+// The 5 rotations of round-robin step `st`, written phase-major (all 5 dot products, then all 5
+// angles, then all 5 column updates, innermost index = the pair): the five are independent
+// dependency chains, and in this order consecutive instructions belong to different chains, so the
+// in-order SIMD overlaps their latencies (a lane-per-problem wave has no other wave to hide behind).
+template <int ST>
+CVX_HD double eig_step5(Eig &e)
+{
+    constexpr int P[5] = {rr_col(ST, 0), rr_col(ST, 1), rr_col(ST, 2), rr_col(ST, 3), rr_col(ST, 4)};
+    constexpr int Q[5] = {rr_col(ST, 5), rr_col(ST, 6), rr_col(ST, 7), rr_col(ST, 8), rr_col(ST, 9)};
+    double gam[5] = {0, 0, 0, 0, 0};
+    CVX_UNROLL for (int i = 0; i < 10; ++i)
+        CVX_UNROLL for (int k = 0; k < 5; ++k) gam[k] += e.G[P[k]][i] * e.G[Q[k]][i];
+    double c[5], s[5], t[5], worst = 0;
+    CVX_UNROLL for (int k = 0; k < 5; ++k) {
+        const double al = e.n2[P[k]], be = e.n2[Q[k]];
+        const double g2 = gam[k] * gam[k], ab = al * be;
+        jacobi_cs(al, be, gam[k], g2 > 1e-30 * ab, c[k], s[k], t[k]);
+        const double r = g2 / ab;
+        worst = r > worst ? r : worst;
+        e.n2[P[k]] = al - t[k] * gam[k];
+        e.n2[Q[k]] = be + t[k] * gam[k];
+    }
+    CVX_UNROLL for (int i = 0; i < 10; ++i)
+        CVX_UNROLL for (int k = 0; k < 5; ++k) {
+            const double gp = e.G[P[k]][i], gq = e.G[Q[k]][i];
+            e.G[P[k]][i] = c[k] * gp - s[k] * gq;
+            e.G[Q[k]][i] = s[k] * gp + c[k] * gq;
+        }
+    return worst;
+}
+
 // sweeps until the largest squared cosine met in a sweep is below tol2 (quadratic convergence:
 // the columns are then orthogonal to ~tol2 after that sweep), or max_sweeps
 CVX_HD int eig_solve(Eig &e, int max_sweeps, double tol2)
@@ -418,12 +449,16 @@ CVX_HD int eig_solve(Eig &e, int max_sweeps, double tol2)
     int sweeps = 0;
     for (; sweeps < max_sweeps;) {
         eig_norms(e);
-        double worst = 0;
-        CVX_UNROLL for (int st = 0; st < 9; ++st)
-            CVX_UNROLL for (int k = 0; k < 5; ++k) {
-                double r = eig_rotate(e, rr_col(st, k), rr_col(st, 5 + k));
-                worst = r > worst ? r : worst;
-            }
+        double worst = 0, r;
+        r = eig_step5<0>(e); worst = r > worst ? r : worst;
+        r = eig_step5<1>(e); worst = r > worst ? r : worst;
+        r = eig_step5<2>(e); worst = r > worst ? r : worst;
+        r = eig_step5<3>(e); worst = r > worst ? r : worst;
+        r = eig_step5<4>(e); worst = r > worst ? r : worst;
+        r = eig_step5<5>(e); worst = r > worst ? r : worst;
+        r = eig_step5<6>(e); worst = r > worst ? r : worst;
+        r = eig_step5<7>(e); worst = r > worst ? r : worst;
+        r = eig_step5<8>(e); worst = r > worst ? r : worst;
         ++sweeps;
         if (!(worst > tol2)) break;
     }
