@@ -151,19 +151,36 @@ def _single(pts_2d, line_2d, pts_3d, line_3d, K, eps, max_iters, verbose) -> Lis
     return [(res.R[0].cpu().numpy(), res.t[0].cpu().numpy())]
 
 
-def _translation_map(p2, l2, p3, l3, Kn):
+def assemble_batch(pts_2d, line_2d, pts_3d, line_3d, K, device=None):
+    """Device-side constraint assembly only (cvxpnpl.py:432-452): returns (B [batch,27], Q [batch,45]),
+    the translation map t = B r and the packed 9x9 cost r^T Q r, as float64 device tensors.  What
+    the rank > 1 recovery (recover_multi) needs next to Z."""
+    _require_gpu()
     L = _lib.lib()
-    dev = torch.device("cuda", torch.cuda.current_device())
-    a = [torch.as_tensor(x, device=dev).contiguous() if x is not None else None for x in (p2, p3, l2, l3)]
-    Kd = torch.as_tensor(Kn, device=dev).contiguous()
-    Bt = torch.empty((1, 27), dtype=torch.float64, device=dev)
-    Qt = torch.empty((1, 45), dtype=torch.float64, device=dev)
-    n_p = a[1].shape[1] if a[1] is not None else 0
-    n_l = a[3].shape[1] if a[3] is not None else 0
-    rc = L.cvxpnpl_assemble_batch(1, n_p, _ptr(a[0]), _ptr(a[1]), n_l, _ptr(a[2]), _ptr(a[3]), _ptr(Kd), 0, _ptr(Bt),
-                                  _ptr(Qt), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    p3 = _as_dev(pts_3d, dev, (3,)) if pts_3d is not None else None
+    l3 = _as_dev(line_3d, dev, (2, 3)) if line_3d is not None else None
+    n_p = p3.shape[-2] if p3 is not None and p3.dim() >= 3 else 0
+    n_l = l3.shape[-3] if l3 is not None and l3.dim() >= 4 else 0
+    if n_p == 0 and n_l == 0:
+        raise ValueError("need at least one point or line correspondence ([B,n,3] points / [B,n,2,3] lines)")
+    batch = (p3 if n_p else l3).shape[0]
+    p2 = _as_dev(pts_2d, dev, (2,)).reshape(batch, n_p, 2) if n_p else None
+    l2 = _as_dev(line_2d, dev, (2, 2)).reshape(batch, n_l, 2, 2) if n_l else None
+    Kd = _as_dev(K, dev, (3, 3))
+    per = int(Kd.dim() == 3)
+    with torch.cuda.device(dev):
+        Bt = torch.empty((batch, 27), dtype=torch.float64, device=dev)
+        Qt = torch.empty((batch, 45), dtype=torch.float64, device=dev)
+        rc = L.cvxpnpl_assemble_batch(batch, n_p, _ptr(p2), _ptr(p3 if n_p else None), n_l, _ptr(l2), _ptr(l3 if n_l else None),
+                                      _ptr(Kd), per, _ptr(Bt), _ptr(Qt), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     if rc != 0:
-        raise RuntimeError(_lib.last_error())
+        raise RuntimeError(f"cvxpnpl_assemble_batch failed ({rc}): {_lib.last_error()}")
+    return Bt, Qt
+
+
+def _translation_map(p2, l2, p3, l3, Kn):
+    Bt, Qt = assemble_batch(p2, l2, p3, l3, Kn)
     return Bt[0].cpu().numpy(), Qt[0].cpu().numpy()
 
 

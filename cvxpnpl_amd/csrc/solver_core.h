@@ -94,6 +94,16 @@ CVX_HD constexpr int tri_j(int t, int k)
     return T[t][k];
 }
 CVX_HD constexpr double tri_s(int t, int k) { return (t >= 6 && k >= 1) ? -1.0 : 1.0; }
+CVX_HD constexpr bool odd_entry(int i, int j) { return (i < 6) != (j < 6); }
+CVX_HD constexpr bool odd_tri(int t) { return odd_entry(tri_i(t, 0), tri_j(t, 0)); }
+constexpr bool tri_parity_uniform()
+{
+    for (int t = 0; t < 15; ++t)
+        for (int k = 1; k < 3; ++k)
+            if (odd_entry(tri_i(t, k), tri_j(t, k)) != odd_tri(t)) return false;
+    return true;
+}
+static_assert(tri_parity_uniform(), "every equality triple must have a single parity under D = diag(-I6, I4)");
 
 // ---------------------------------------------------------------------------------------
 // tiny helpers
@@ -588,42 +598,48 @@ CVX_HD double ldl_min_pivot(double *S)
 }
 
 // Cholesky solve of a full 10x10 SPD system (row-major), in place on M and x.
+template <bool SEMI = true>
 CVX_HD bool chol_solve10(double *M, double *x)
 {
     bool ok = true;
+    bool skip[10];
     CVX_UNROLL for (int j = 0; j < 10; ++j) {
         double d = M[j * 10 + j];
         CVX_UNROLL for (int k = 0; k < j; ++k) d -= M[j * 10 + k] * M[j * 10 + k];
-        ok &= d > 0;
-        d = sqrt(d > 0 ? d : 1.0);
+        // SEMI: semidefinite but consistent system (|z|^2 = 4 sets the scale): null pivot -> lam_j = 0
+        skip[j] = SEMI && !(d > 1e-10);
+        ok &= SEMI ? (d > -1e-8) : (d > 0);
+        if (!SEMI) d = d > 0 ? d : 1.0;
+        d = skip[j] ? 1.0 : sqrt(d);
         M[j * 10 + j] = d;
         double id = rcp(d);
         CVX_UNROLL for (int i = j + 1; i < 10; ++i) {
             double s = M[i * 10 + j];
             CVX_UNROLL for (int k = 0; k < j; ++k) s -= M[i * 10 + k] * M[j * 10 + k];
-            M[i * 10 + j] = s * id;
+            M[i * 10 + j] = skip[j] ? 0.0 : s * id;
         }
     }
     CVX_UNROLL for (int i = 0; i < 10; ++i) {
         double s = x[i];
         CVX_UNROLL for (int k = 0; k < i; ++k) s -= M[i * 10 + k] * x[k];
-        x[i] = s * rcp(M[i * 10 + i]);
+        x[i] = skip[i] ? 0.0 : s * rcp(M[i * 10 + i]);
     }
     CVX_UNROLL for (int i = 9; i >= 0; --i) {
         double s = x[i];
         CVX_UNROLL for (int k = i + 1; k < 10; ++k) s -= M[k * 10 + i] * x[k];
-        x[i] = s * rcp(M[i * 10 + i]);
+        x[i] = skip[i] ? 0.0 : s * rcp(M[i * 10 + i]);
     }
     return ok;
 }
 
 // P_range(sym(lam z^T)) applied to z, accumulated as the 10x10 Gram matrix
 //   Mz = sum_i (Ahat_i z)(Ahat_i z)^T   over an orthonormal basis Ahat_i of span{A_i}
-CVX_HD void build_Mz(const double *z, double *M)
+CVX_HD void build_Mz(const double *z, double *M, bool symm = false)
 {
     CVX_UNROLL for (int i = 0; i < 100; ++i) M[i] = 0;
     // off-diagonal triples: pattern has +-1/2 at (i,j),(j,i); |pattern|^2 = 3/2
     CVX_UNROLL for (int t = 0; t < 15; ++t) {
+        if (symm && odd_tri(t)) continue;
         double g[10];
         CVX_UNROLL for (int i = 0; i < 10; ++i) g[i] = 0;
         CVX_UNROLL for (int k = 0; k < 3; ++k) {
@@ -652,11 +668,11 @@ CVX_HD void build_Mz(const double *z, double *M)
 
 // E <- P_range(E) = E - P_null(E), for E = sym(lam z^T) given implicitly; subtracts the
 // result from S:  S <- S - P_range(sym(lam z^T))
-CVX_HD void sub_range_of_rank2(double *S, const double *lam, const double *z)
+CVX_HD void sub_range_of_rank2(double *S, const double *lam, const double *z, bool symm = false)
 {
     double E[55];
     CVX_UNROLL for (int i = 0; i < 10; ++i)
-        CVX_UNROLL for (int j = i; j < 10; ++j) E[sidx(i, j)] = 0.5 * (lam[i] * z[j] + z[i] * lam[j]);
+        CVX_UNROLL for (int j = i; j < 10; ++j) E[sidx(i, j)] = (symm && odd_entry(i, j)) ? 0.0 : 0.5 * (lam[i] * z[j] + z[i] * lam[j]);
     double N[55];
     CVX_UNROLL for (int i = 0; i < 55; ++i) N[i] = E[i];
     proj_affine(N, true); // N = P_null(E)
@@ -710,22 +726,29 @@ CVX_HD void twin_candidates(const double *v1, const double *v2, double *zp, doub
 }
 
 // Dual half: given the polished rotation c.R (and c.pobj), recover a dual and test it.
+// SYMM: recognise planar scenes (Qs blind to the third column of R), whose relaxation is invariant
+// under D = diag(-I6, I4), and build the correction in the D-even subspace so that it annihilates
+// both twins z and D z at once.
+template <bool SYMM = true>
 CVX_HD void dual_certificate(const double *Qs, const double *W, const double *Wp, double rho, double delta, double d0, Cert &c)
 {
     c.ok = false;
     double z[10];
     CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) z[3 * j + i] = c.R[i * 3 + j];
     z[9] = 1.0;
+    bool symm = SYMM;
+    if (SYMM) { CVX_UNROLL for (int i = 0; i < 9; ++i) CVX_UNROLL for (int j = 6; j < 9; ++j) symm &= fabs(Qs[qidx(i, j)]) < 1e-13; }
     // dual hint S_h = -rho Wm = rho (Wp - W); S1 = S_h - P_null(S_h - Qs)  (in Qs + span A_i)
     double S[55], T[55];
     CVX_UNROLL for (int i = 0; i < 55; ++i) { S[i] = rho * (Wp[i] - W[i]); T[i] = S[i]; }
     CVX_UNROLL for (int i = 0; i < 9; ++i) CVX_UNROLL for (int j = i; j < 9; ++j) T[sidx(i, j)] -= Qs[qidx(i, j)];
     proj_affine(T, true);
     CVX_UNROLL for (int i = 0; i < 55; ++i) S[i] -= T[i];
+    if (symm) { CVX_UNROLL for (int i = 0; i < 10; ++i) CVX_UNROLL for (int j = i; j < 10; ++j) if (odd_entry(i, j)) S[sidx(i, j)] = 0.0; }
     // correction: min-norm dS in span A_i with (S - dS) z = 0
     double rhs[10], Mz[100];
     sym_mul10(S, z, rhs);
-    build_Mz(z, Mz);
+    build_Mz(z, Mz, symm);
     // Mz is singular on the 3 tangent directions [vec(R [e_k]x); 0] of SO(3) (|.|^2 = 2):
     // add their projector so that the system is SPD; rhs has no tangent component at a
     // stationary point.
@@ -745,8 +768,8 @@ CVX_HD void dual_certificate(const double *Qs, const double *W, const double *Wp
     }
     double lam[10];
     CVX_UNROLL for (int i = 0; i < 10; ++i) lam[i] = rhs[i];
-    bool spd = chol_solve10(Mz, lam);
-    sub_range_of_rank2(S, lam, z);
+    bool spd = chol_solve10<SYMM>(Mz, lam);
+    sub_range_of_rank2(S, lam, z, symm);
     // checks
     double Sz[10];
     sym_mul10(S, z, Sz);
@@ -759,10 +782,11 @@ CVX_HD void dual_certificate(const double *Qs, const double *W, const double *Wp
 
 // Qs: 45 packed, trace-normalised.  W, Wp: current ADMM iterate and its PSD part.
 // v: candidate (multiple of [r; 1]), e.g. the unit top eigenvector of Wp.  delta: PSD slack.
+template <bool SYMM = true>
 CVX_HD void certify(const double *Qs, const double *W, const double *Wp, const double *v, double rho, double delta, Cert &c)
 {
     const double d0 = polish_candidate(Qs, v, c.R, c.pobj);
-    dual_certificate(Qs, W, Wp, rho, delta, d0, c);
+    dual_certificate<SYMM>(Qs, W, Wp, rho, delta, d0, c);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -924,7 +948,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                 } else {
                     d0 = polish_candidate(Qs, vt, c.R, c.pobj);
                 }
-                dual_certificate(Qs, W, Wp, rho, delta, d0, c);
+                dual_certificate<TWIN>(Qs, W, Wp, rho, delta, d0, c);
                 have_prev = d0 > 0 && (c.pobj == c.pobj);
                 CVX_UNROLL for (int i = 0; i < 9; ++i) Rprev[i] = c.R[i];
                 fprev = c.pobj;
@@ -943,7 +967,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                 // the dual test (it is then a global optimum, and so is z- with the same cost).
                 if (ambiguous) {
                     c.pobj = fp;
-                    dual_certificate(Qs, W, Wp, rho, delta, dp, c);
+                    dual_certificate<TWIN>(Qs, W, Wp, rho, delta, dp, c);
                     ambiguous = c.ok && (tr * (fabs(c.zSz) + 4.0 * delta) <= (o.eps > 8e-13 * tr ? o.eps : 8e-13 * tr));
                     twin_tested = true;
                 }
@@ -951,7 +975,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                     const bool take_m = dm > 0 && (fm == fm) && (!(dp > 0) || !(fp == fp) || fm < fp);
                     if (take_m) { CVX_UNROLL for (int i = 0; i < 9; ++i) c.R[i] = Rm[i]; }
                     c.pobj = take_m ? fm : fp;
-                    dual_certificate(Qs, W, Wp, rho, delta, take_m ? dm : dp, c);
+                    dual_certificate<TWIN>(Qs, W, Wp, rho, delta, take_m ? dm : dp, c);
                 } else if (!ambiguous) {
                     c.ok = false; // equal-cost twins whose certificate is not there yet: keep iterating
                 }

@@ -90,6 +90,7 @@ struct MTab {
     double c[64][10];
 };
 
+template <bool SYMM>
 constexpr MTab make_mtab()
 {
     MTab t{};
@@ -108,7 +109,8 @@ constexpr MTab make_mtab()
                     if (i == b) { cb = 0.5 * sg; pb = j; }
                     if (j == b) { cb = 0.5 * sg; pb = i; }
                 }
-                if (ca != 0 && cb != 0) { t.p[e][n] = (signed char)pa; t.q[e][n] = (signed char)pb; t.c[e][n] = (2.0 / 3.0) * ca * cb; ++n; }
+                const bool drop = SYMM && cvx::odd_tri(tr);
+                if (ca != 0 && cb != 0) { t.p[e][n] = (signed char)pa; t.q[e][n] = (signed char)pb; t.c[e][n] = drop ? 0.0 : (2.0 / 3.0) * ca * cb; ++n; }
             }
             if (b < 9) {
                 const double P = ((a % 3) == (b % 3) ? 1.0 / 3.0 : 0.0) + ((a / 3) == (b / 3) ? 1.0 / 3.0 : 0.0) - 1.0 / 9.0;
@@ -122,7 +124,9 @@ constexpr MTab make_mtab()
     return t;
 }
 
-__device__ const MTab kMTab = make_mtab();
+__device__ const MTab kMTab = make_mtab<false>();
+// the same with the parity-odd triples dropped (planar scenes, cvx::build_Mz(symm = true))
+__device__ const MTab kMTabS = make_mtab<true>();
 
 // element i (0..9) of x-vector v (0: z = [vec(R); 1]; 1..3: [vec(R [e_k]x); 0]) as sign * R[src]
 struct XTab { signed char src[40]; signed char sgn[40]; };
@@ -216,8 +220,18 @@ __device__ __forceinline__ double coop_ldl(double *L, const Roles &r, double &Me
         if (RHS && r.lane == k) L[C_ROW + 10] = y;
         CVXW_SYNC();
         const double d = L[C_ROW + k];
-        minp = d < minp ? d : minp;
-        const double id = fast_rcp(d);
+        double id;
+        if (RHS) {
+            // semidefinite but consistent system (cvx::chol_solve10): a null pivot means lam_k = 0
+            const bool skip = !(d > 1e-10);
+            const double dm = skip ? (d > -1e-8 ? 1.0 : -1.0) : d;
+            minp = dm < minp ? dm : minp;
+            id = skip ? 0.0 : fast_rcp(d);
+            if (skip && r.ei == k && r.ej == k) Me = 0.0;
+        } else {
+            minp = d < minp ? d : minp;
+            id = fast_rcp(d);
+        }
         const double ra = L[C_ROW + r.ei], rb = L[C_ROW + r.ej];
         if (r.ei > k) Me -= ra * id * rb;
         if (RHS) {
@@ -350,6 +364,10 @@ __device__ __forceinline__ double coop_polish(double *L, const Roles &r, double 
 __device__ __forceinline__ bool coop_dual(double *L, const Roles &r, double Qs, double W, double Wp, const double *R, double d0,
                                           double pobj, double rho, double delta, double &zSz)
 {
+    // planar scene (Qs blind to the third column of R): the problem is invariant under
+    // D = diag(-I6, I4) and the correction is built in the D-even subspace (cvx::dual_certificate)
+    const bool symm = __all(!(r.lane < 55 && r.ej >= 6 && r.ej < 9) || fabs(Qs) < 1e-13);
+    const bool odd = symm && ((r.ei < 6) != (r.ej < 6));
     double2 *L2 = reinterpret_cast<double2 *>(L);
     const int lane = r.lane;
     const int xsrc = kXTab.src[lane < 40 ? lane : 0];
@@ -365,6 +383,7 @@ __device__ __forceinline__ bool coop_dual(double *L, const Roles &r, double Qs, 
     // ---- dual hint S_h = rho (Wp - W); S1 = S_h - P_null(S_h - Qs)
     const double Sh = rho * (Wp - W);
     double S = Sh - coop_proj(L, r, Sh - (r.ej < 9 ? Qs : 0.0), 0.0);
+    if (odd) S = 0.0;
     if (lane < 55) { L[C_SF + r.ei * 10 + r.ej] = S; L[C_SF + r.ej * 10 + r.ei] = S; }
     CVXW_SYNC();
     // rhs = S z on lanes 0..9
@@ -375,8 +394,11 @@ __device__ __forceinline__ bool coop_dual(double *L, const Roles &r, double Qs, 
     }
     // ---- M = Ghat Ghat^T + T T^T (entry lanes), LDL^T solve M lam = rhs
     double Me = 0.0;
+    {
+        const MTab &mt = symm ? kMTabS : kMTab;
 #pragma unroll
-    for (int t = 0; t < 10; ++t) Me += kMTab.c[lane][t] * L[C_XV + kMTab.p[lane][t]] * L[C_XV + kMTab.q[lane][t]];
+        for (int t = 0; t < 10; ++t) Me += mt.c[lane][t] * L[C_XV + mt.p[lane][t]] * L[C_XV + mt.q[lane][t]];
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) Me += L[C_XV + (1 + k) * 10 + r.ei] * L[C_XV + (1 + k) * 10 + r.ej];
     CVXW_SYNC();
@@ -386,7 +408,8 @@ __device__ __forceinline__ bool coop_dual(double *L, const Roles &r, double Qs, 
     // back substitution: lam_k = y_k / U_kk; y_a -= U[a][k] lam_k (a < k)
 #pragma unroll
     for (int k = 9; k >= 0; --k) {
-        const double lk_local = y * fast_rcp(L[C_UF + k * 10 + k]);
+        const double ukk = L[C_UF + k * 10 + k];
+        const double lk_local = ukk == 0.0 ? 0.0 : y * fast_rcp(ukk);
         const double lk = __shfl(lk_local, k, 64);
         if (lane == 0) L[C_LAM + k] = lk;
         const int a = lane < 10 ? lane : 0;
@@ -396,7 +419,7 @@ __device__ __forceinline__ bool coop_dual(double *L, const Roles &r, double Qs, 
     CVXW_SYNC();
     // ---- S2 = S1 - P_range(sym(lam z^T))
     {
-        const double E = 0.5 * (L[C_LAM + r.ei] * L[C_XV + r.ej] + L[C_XV + r.ei] * L[C_LAM + r.ej]);
+        const double E = odd ? 0.0 : 0.5 * (L[C_LAM + r.ei] * L[C_XV + r.ej] + L[C_XV + r.ei] * L[C_LAM + r.ej]);
         const double Nn = coop_proj(L, r, E, 0.0);
         S -= E - Nn;
     }

@@ -161,3 +161,18 @@ def test_uncertifiable_and_degenerate_inputs():
     hs = hostsim.solve_batch(d2["pts_2d"], d2["pts_3d"], None, None, d2["K"])
     assert hs["status"][1] == 3 and np.isnan(hs["R"][1]).all()
     assert (hs["status"][[0, 2, 3]] == 0).all()
+
+
+def test_planar_scenes_certify_the_two_fold_pair_early():
+    """Planar scenes: R and R diag(-1,-1,1) have equal cost, the SDP solution is rank 2
+    (cvxpnpl.py:509-545).  The parity-even dual correction (solver_core.h, dual_certificate, symm)
+    certifies the pair after a handful of iterations instead of ~130."""
+    from cvxpnpl_amd import synth
+
+    d = synth.make_pnp(400, 10, 0.0, seed=1)
+    d["pts_3d"][:, :, 2] = 0.0
+    rs = np.random.RandomState(5)
+    d["pts_2d"] = synth.project(d["pts_3d"], d["K"], d["R_gt"], d["t_gt"]) + rs.normal(scale=1.0, size=d["pts_2d"].shape)
+    hs = hostsim.solve_batch(d["pts_2d"], d["pts_3d"], None, None, d["K"])
+    assert (hs["status"] == 1).all()
+    assert np.median(hs["iters"]) <= 20
