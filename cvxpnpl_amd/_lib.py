@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcvxpnpl_amd.so")
+# CVXPNPL_AMD_LIB: diagnostics only (tools/phase_profile.py loads an instrumented build through it)
+LIB_PATH = os.environ.get("CVXPNPL_AMD_LIB") or os.path.join(_HERE, "libcvxpnpl_amd.so")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)

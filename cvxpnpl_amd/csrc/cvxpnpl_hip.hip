@@ -248,3 +248,16 @@ int cvxpnpl_device_count(void)
 }
 
 } // extern "C"
+
+#ifdef CVXW_PROFILE
+// diagnostics build only (tools/phase_profile.py): read and reset the per-phase cycle counters
+extern "C" int cvxpnpl_debug_phase_cycles(unsigned long long *out32, int reset)
+{
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(cvxw::g_phase_cycles), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(cvxw::g_phase_cycles), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

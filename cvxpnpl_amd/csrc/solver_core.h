@@ -518,7 +518,11 @@ CVX_HD void so3_newton(const double *Q9, double *R, int iters)
             CVX_UNROLL for (int j = 0; j < 3; ++j) N[i * 3 + j] = R[0 * 3 + i] * Qr[3 * j] + R[1 * 3 + i] * Qr[3 * j + 1] + R[2 * 3 + i] * Qr[3 * j + 2];
         double g[3] = {2 * (N[7] - N[5]), 2 * (N[2] - N[6]), 2 * (N[3] - N[1])};
         // converged: projected gradient at rounding level (Q is trace-normalised, |R| = O(1))
-        if (it >= 2 && fabs(g[0]) + fabs(g[1]) + fabs(g[2]) < 1e-15) break;
+        const double gn = fabs(g[0]) + fabs(g[1]) + fabs(g[2]);
+        if (it >= 2 && gn < 1e-15) break;
+        // Newton converges quadratically: from |g| < 1e-8 the step below lands at rounding level, so it is
+        // the last one (saves the iteration that would only have confirmed it)
+        const bool final_step = gn < 1e-8;
         // a_k = vec(R [e_k]x): columns (0, c2, -c1), (-c2, 0, c0), (c1, -c0, 0)
         double a[3][9], Qa[3][9];
         CVX_UNROLL for (int i = 0; i < 3; ++i) {
@@ -559,6 +563,7 @@ CVX_HD void so3_newton(const double *Q9, double *R, int iters)
         CVX_UNROLL for (int i = 0; i < 3; ++i)
             CVX_UNROLL for (int j = 0; j < 3; ++j) Rn[i * 3 + j] = R[i * 3] * Cm[j] + R[i * 3 + 1] * Cm[3 + j] + R[i * 3 + 2] * Cm[6 + j];
         CVX_UNROLL for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+        if (final_step && pd) break;
     }
     // one polar step squares any drift from orthogonality
     double Ri[9], det;
@@ -666,6 +671,96 @@ CVX_HD void build_Mz(const double *z, double *M, bool symm = false)
     M[99] += z[9] * z[9];
 }
 
+// Closed form of the multiplier solve.  span{A_i} is invariant under the congruence with
+// P(R) = blkdiag(R, R, R, 1) (orthonormality and cross-product constraints are invariant under
+// R -> R0 R), so  Mz(z_R) = P(R) Mz(z_I) P(R)^T  and likewise for the tangent projector: the 10x10
+// system of the dual correction is the CONSTANT matrix M_I = Mz(z_I) + T_I T_I^T seen in a rotated
+// frame, and  lam = P(R) M_I^-1 P(R)^T rhs.  M_I^-1 is built at compile time (block structure
+// {0,4,8,9}, {1,3}, {2,6}, {5,7}: 28 non-zeros); `symm` = the D-even variant used for planar scenes,
+// a pivot-skipping generalised inverse there (any solution of the consistent system gives the same
+// projected correction).
+struct DualC { double c[100]; };
+constexpr DualC make_dual_c(bool symm)
+{
+    const double z[10] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 1};
+    double M[100] = {};
+    for (int t = 0; t < 15; ++t) {
+        if (symm && odd_tri(t)) continue;
+        double g[10] = {};
+        for (int k = 0; k < 3; ++k) {
+            g[tri_i(t, k)] += 0.5 * tri_s(t, k) * z[tri_j(t, k)];
+            g[tri_j(t, k)] += 0.5 * tri_s(t, k) * z[tri_i(t, k)];
+        }
+        for (int a = 0; a < 10; ++a)
+            for (int b = 0; b < 10; ++b) M[a * 10 + b] += (2.0 / 3.0) * g[a] * g[b];
+    }
+    for (int k = 0; k < 9; ++k)
+        for (int l = 0; l < 9; ++l) {
+            const double p = ((k % 3) == (l % 3) ? 1.0 / 3.0 : 0.0) + ((k / 3) == (l / 3) ? 1.0 / 3.0 : 0.0) - 1.0 / 9.0;
+            M[k * 10 + l] += z[k] * p * z[l];
+        }
+    M[99] += 1.0;
+    // tangents [vec([e_k]x); 0] of SO(3) at the identity
+    const double tv[3][10] = {{0, 0, 0, 0, 0, 1, 0, -1, 0, 0}, {0, 0, -1, 0, 0, 0, 1, 0, 0, 0}, {0, 1, 0, -1, 0, 0, 0, 0, 0, 0}};
+    for (int k = 0; k < 3; ++k)
+        for (int i = 0; i < 10; ++i)
+            for (int j = 0; j < 10; ++j) M[i * 10 + j] += tv[k][i] * tv[k][j];
+    // L D L^T with null pivots skipped, then one solve per unit vector
+    double Lm[100] = {}, d[10] = {};
+    bool skip[10] = {};
+    for (int j = 0; j < 10; ++j) {
+        double dj = M[j * 10 + j];
+        for (int k = 0; k < j; ++k) dj -= Lm[j * 10 + k] * Lm[j * 10 + k] * d[k];
+        skip[j] = !(dj > 1e-10);
+        d[j] = skip[j] ? 0.0 : dj;
+        Lm[j * 10 + j] = 1.0;
+        for (int i = j + 1; i < 10; ++i) {
+            double v = M[i * 10 + j];
+            for (int k = 0; k < j; ++k) v -= Lm[i * 10 + k] * Lm[j * 10 + k] * d[k];
+            Lm[i * 10 + j] = skip[j] ? 0.0 : v / dj;
+        }
+    }
+    DualC out{};
+    for (int col = 0; col < 10; ++col) {
+        double x[10] = {};
+        x[col] = 1.0;
+        for (int i = 0; i < 10; ++i) {
+            double v = x[i];
+            for (int k = 0; k < i; ++k) v -= Lm[i * 10 + k] * x[k];
+            x[i] = skip[i] ? 0.0 : v;
+        }
+        for (int i = 0; i < 10; ++i) x[i] = skip[i] ? 0.0 : x[i] / d[i];
+        for (int i = 9; i >= 0; --i) {
+            double v = x[i];
+            for (int k = i + 1; k < 10; ++k) v -= Lm[k * 10 + i] * x[k];
+            x[i] = skip[i] ? 0.0 : v;
+        }
+        for (int i = 0; i < 10; ++i) out.c[i * 10 + col] = (x[i] > -1e-15 && x[i] < 1e-15) ? 0.0 : x[i];
+    }
+    return out;
+}
+constexpr DualC kDualC = make_dual_c(false), kDualCs = make_dual_c(true);
+
+// lam = P(R) C P(R)^T rhs,  (P x)[3 j + i] = sum_k R[i][k] x[3 j + k],  R row-major
+CVX_HD void dual_lambda(const double *R, const double *rhs, bool symm, double *lam)
+{
+    double yp[10], lp[10];
+    CVX_UNROLL for (int j = 0; j < 3; ++j)
+        CVX_UNROLL for (int i = 0; i < 3; ++i) yp[3 * j + i] = R[0 * 3 + i] * rhs[3 * j] + R[1 * 3 + i] * rhs[3 * j + 1] + R[2 * 3 + i] * rhs[3 * j + 2];
+    yp[9] = rhs[9];
+    CVX_UNROLL for (int a = 0; a < 10; ++a) {
+        double u = 0, v = 0;
+        CVX_UNROLL for (int b = 0; b < 10; ++b) {
+            if (kDualC.c[a * 10 + b] != 0.0) u += kDualC.c[a * 10 + b] * yp[b];
+            if (kDualCs.c[a * 10 + b] != 0.0) v += kDualCs.c[a * 10 + b] * yp[b];
+        }
+        lp[a] = symm ? v : u;
+    }
+    CVX_UNROLL for (int j = 0; j < 3; ++j)
+        CVX_UNROLL for (int i = 0; i < 3; ++i) lam[3 * j + i] = R[i * 3] * lp[3 * j] + R[i * 3 + 1] * lp[3 * j + 1] + R[i * 3 + 2] * lp[3 * j + 2];
+    lam[9] = lp[9];
+}
+
 // E <- P_range(E) = E - P_null(E), for E = sym(lam z^T) given implicitly; subtracts the
 // result from S:  S <- S - P_range(sym(lam z^T))
 CVX_HD void sub_range_of_rank2(double *S, const double *lam, const double *z, bool symm = false)
@@ -691,7 +786,9 @@ struct Cert {
 // Primal half of a certification attempt: round the candidate v (any multiple of [r; 1]) to a rotation
 // (cvxpnpl.py:504-505 + nearest proper rotation), Newton-polish r^T Qs r on SO(3).  Returns det of the
 // rounded matrix (<= 0: the candidate was a reflection and cannot certify) and pobj = r^T Qs r.
-CVX_HD double polish_candidate(const double *Qs, const double *v, double *R, double &pobj)
+// rank-1 rounding (cvxpnpl.py:504-505) and projection to the nearest proper rotation; returns det of the
+// rounded matrix (<= 0: the candidate was a reflection and cannot certify)
+CVX_HD double round_candidate(const double *v, double *R)
 {
     double iv = rcp(v[9]);
     double M0[9];
@@ -699,12 +796,24 @@ CVX_HD double polish_candidate(const double *Qs, const double *v, double *R, dou
     double d0 = det3(M0);
     if (d0 < 0) { CVX_UNROLL for (int i = 0; i < 9; ++i) M0[i] = -M0[i]; } // polish needs SO(3); a reflection cannot certify
     polar3(M0, R, 8);
+    return d0;
+}
+
+// Newton polish of r^T Qs r on SO(3) from R; pobj = r^T Qs r
+CVX_HD void polish_rotation(const double *Qs, double *R, double &pobj)
+{
     so3_newton(Qs, R, 6);
     double z[9], Qz[9];
     CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) z[3 * j + i] = R[i * 3 + j];
     q9_mul(Qs, z, Qz);
     pobj = 0;
     CVX_UNROLL for (int i = 0; i < 9; ++i) pobj += z[i] * Qz[i];
+}
+
+CVX_HD double polish_candidate(const double *Qs, const double *v, double *R, double &pobj)
+{
+    const double d0 = round_candidate(v, R);
+    polish_rotation(Qs, R, pobj);
     return d0;
 }
 
@@ -746,29 +855,10 @@ CVX_HD void dual_certificate(const double *Qs, const double *W, const double *Wp
     CVX_UNROLL for (int i = 0; i < 55; ++i) S[i] -= T[i];
     if (symm) { CVX_UNROLL for (int i = 0; i < 10; ++i) CVX_UNROLL for (int j = i; j < 10; ++j) if (odd_entry(i, j)) S[sidx(i, j)] = 0.0; }
     // correction: min-norm dS in span A_i with (S - dS) z = 0
-    double rhs[10], Mz[100];
+    // (closed form: the system matrix is a constant in the frame of R, see dual_lambda)
+    double rhs[10], lam[10];
     sym_mul10(S, z, rhs);
-    build_Mz(z, Mz, symm);
-    // Mz is singular on the 3 tangent directions [vec(R [e_k]x); 0] of SO(3) (|.|^2 = 2):
-    // add their projector so that the system is SPD; rhs has no tangent component at a
-    // stationary point.
-    {
-        double tv[3][10];
-        CVX_UNROLL for (int i = 0; i < 3; ++i) {
-            double c0 = c.R[i * 3], c1 = c.R[i * 3 + 1], c2 = c.R[i * 3 + 2];
-            tv[0][i] = 0;   tv[0][3 + i] = c2;  tv[0][6 + i] = -c1;
-            tv[1][i] = -c2; tv[1][3 + i] = 0;   tv[1][6 + i] = c0;
-            tv[2][i] = c1;  tv[2][3 + i] = -c0; tv[2][6 + i] = 0;
-        }
-        CVX_UNROLL for (int k = 0; k < 3; ++k) {
-            tv[k][9] = 0;
-            CVX_UNROLL for (int i = 0; i < 9; ++i)
-                CVX_UNROLL for (int j = 0; j < 9; ++j) Mz[i * 10 + j] += tv[k][i] * tv[k][j];
-        }
-    }
-    double lam[10];
-    CVX_UNROLL for (int i = 0; i < 10; ++i) lam[i] = rhs[i];
-    bool spd = chol_solve10<SYMM>(Mz, lam);
+    dual_lambda(c.R, rhs, symm, lam);
     sub_range_of_rank2(S, lam, z, symm);
     // checks
     double Sz[10];
@@ -777,7 +867,7 @@ CVX_HD void dual_certificate(const double *Qs, const double *W, const double *Wp
     CVX_UNROLL for (int i = 0; i < 10; ++i) { c.res = fabs(Sz[i]) > c.res ? fabs(Sz[i]) : c.res; c.zSz += z[i] * Sz[i]; }
     CVX_UNROLL for (int i = 0; i < 10; ++i) S[sidx(i, i)] += delta;
     c.min_piv = ldl_min_pivot(S);
-    c.ok = spd && (c.min_piv > 0) && (c.res < 1e-10) && (d0 > 0) && (c.pobj == c.pobj);
+    c.ok = (c.min_piv > 0) && (c.res < 1e-10) && (d0 > 0) && (c.pobj == c.pobj);
 }
 
 // Qs: 45 packed, trace-normalised.  W, Wp: current ADMM iterate and its PSD part.
@@ -931,22 +1021,17 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
             bool ambiguous = false, twin_tested = false;
             double Rm[9], fm = 0;
             if (!two) {
-                // 4 of 5 repeated checks round to the pose the previous check already polished (it was the
-                // dual that was not ready): if the raw rank-1 ratio is within 0.3 (Frobenius) of that
-                // rotation, reuse it and go straight to the dual test
-                double M0[9], dist2 = 0;
-                const double iv = rcp(vt[9]);
-                CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) {
-                    M0[i * 3 + j] = vt[3 * j + i] * iv;
-                    dist2 += (M0[i * 3 + j] - Rprev[i * 3 + j]) * (M0[i * 3 + j] - Rprev[i * 3 + j]);
-                }
-                double d0;
-                if (have_prev && dist2 < 0.09) {
+                // 9 of 10 repeated checks polish to the pose the previous check already had (it was the dual
+                // that was not ready): when the rounded candidate lies within 0.22 (Frobenius) of that
+                // rotation -- 99.9 % of those polish back onto it -- reuse it and skip the Newton iterations
+                const double d0 = round_candidate(vt, c.R);
+                double dist2 = 0;
+                CVX_UNROLL for (int i = 0; i < 9; ++i) dist2 += (c.R[i] - Rprev[i]) * (c.R[i] - Rprev[i]);
+                if (have_prev && dist2 < 0.05) {
                     CVX_UNROLL for (int i = 0; i < 9; ++i) c.R[i] = Rprev[i];
                     c.pobj = fprev;
-                    d0 = 1.0;
                 } else {
-                    d0 = polish_candidate(Qs, vt, c.R, c.pobj);
+                    polish_rotation(Qs, c.R, c.pobj);
                 }
                 dual_certificate<TWIN>(Qs, W, Wp, rho, delta, d0, c);
                 have_prev = d0 > 0 && (c.pobj == c.pobj);

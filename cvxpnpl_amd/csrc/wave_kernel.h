@@ -83,51 +83,6 @@ __device__ __forceinline__ double wave_sum(double x)
 // ---------------------------------------------------------------------------------------
 // cooperative certificate: constant tables
 
-// M = sum_i (Ahat_i z)(Ahat_i z)^T over an orthonormal basis of span{A_i} (solver_core.h
-// build_Mz), entry (a, b) as a short list of terms  coef * z[p] * z[q].
-struct MTab {
-    signed char p[64][10], q[64][10];
-    double c[64][10];
-};
-
-template <bool SYMM>
-constexpr MTab make_mtab()
-{
-    MTab t{};
-    int e = 0;
-    for (int a = 0; a < 10; ++a)
-        for (int b = a; b < 10; ++b) {
-            int n = 0;
-            for (int tr = 0; tr < 15; ++tr) {
-                double ca = 0, cb = 0;
-                int pa = 0, pb = 0;
-                for (int k = 0; k < 3; ++k) {
-                    const int i = cvx::tri_i(tr, k), j = cvx::tri_j(tr, k);
-                    const double sg = cvx::tri_s(tr, k);
-                    if (i == a) { ca = 0.5 * sg; pa = j; }
-                    if (j == a) { ca = 0.5 * sg; pa = i; }
-                    if (i == b) { cb = 0.5 * sg; pb = j; }
-                    if (j == b) { cb = 0.5 * sg; pb = i; }
-                }
-                const bool drop = SYMM && cvx::odd_tri(tr);
-                if (ca != 0 && cb != 0) { t.p[e][n] = (signed char)pa; t.q[e][n] = (signed char)pb; t.c[e][n] = drop ? 0.0 : (2.0 / 3.0) * ca * cb; ++n; }
-            }
-            if (b < 9) {
-                const double P = ((a % 3) == (b % 3) ? 1.0 / 3.0 : 0.0) + ((a / 3) == (b / 3) ? 1.0 / 3.0 : 0.0) - 1.0 / 9.0;
-                t.p[e][n] = (signed char)a; t.q[e][n] = (signed char)b; t.c[e][n] = P; ++n;
-            }
-            if (a == 9 && b == 9) { t.p[e][n] = 9; t.q[e][n] = 9; t.c[e][n] = 1.0; ++n; }
-            ++e;
-        }
-    for (int l = 55; l < 64; ++l)
-        for (int n = 0; n < 10; ++n) { t.p[l][n] = t.p[l - 55][n]; t.q[l][n] = t.q[l - 55][n]; t.c[l][n] = t.c[l - 55][n]; }
-    return t;
-}
-
-__device__ const MTab kMTab = make_mtab<false>();
-// the same with the parity-odd triples dropped (planar scenes, cvx::build_Mz(symm = true))
-__device__ const MTab kMTabS = make_mtab<true>();
-
 // element i (0..9) of x-vector v (0: z = [vec(R); 1]; 1..3: [vec(R [e_k]x); 0]) as sign * R[src]
 struct XTab { signed char src[40]; signed char sgn[40]; };
 constexpr XTab make_xtab()
@@ -170,6 +125,40 @@ __device__ __forceinline__ double dot10(const double2 *a, const double2 *b)
            (a4.x * b4.x + a4.y * b4.y);
 }
 
+// Optional phase profile (-DCVXW_PROFILE, tools/phase_profile.py): shader-clock cycles of every wave,
+// accumulated per phase in SGPRs and added to g_phase_cycles at the end.  Not part of the product build.
+#ifdef CVXW_PROFILE
+__device__ unsigned long long g_phase_cycles[32];
+__device__ __forceinline__ unsigned long long cvxw_clock()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+// ph_[0..22]: cycles per phase / event counts; ph_[23]: time of the last marker
+#define CVXW_PH_DECL unsigned long long ph_[24]; { _Pragma("unroll") for (int k_ = 0; k_ < 24; ++k_) ph_[k_] = 0; ph_[23] = cvxw_clock(); }
+#define CVXW_PH_PARAM , unsigned long long (&ph_)[24]
+#define CVXW_PH_ARG , ph_
+#define CVXW_PHX(A, P) do { const unsigned long long n_ = cvxw_clock(); (A)[P] += n_ - (A)[23]; (A)[23] = n_; } while (0)
+#define CVXW_PH(P) CVXW_PHX(ph_, P)
+#define CVXW_PHR(P) CVXW_PHX(ph_, P)
+#define CVXW_CNT(P) do { ph_[P] += 1; } while (0)
+#define CVXW_PH_FLUSH() do { if ((threadIdx.x & 63) == 0) { _Pragma("unroll") for (int k_ = 0; k_ < 23; ++k_) atomicAdd(&g_phase_cycles[k_], ph_[k_]); atomicAdd(&g_phase_cycles[31], 1ull); } } while (0)
+#else
+#define CVXW_PH_DECL
+#define CVXW_PH_PARAM
+#define CVXW_PH_ARG
+#define CVXW_PH(P)
+#define CVXW_PHR(P)
+#define CVXW_CNT(P)
+#define CVXW_PH_FLUSH()
+#endif
+enum { PH_ASSEMBLE = 0, PH_EIG_SETUP, PH_JACOBI, PH_WP, PH_TOPSEL, PH_POLISH, PH_DUAL, PH_CHECK_TAIL, PH_UPDATE, PH_OUTPUT,
+       PH_P_POLAR = 10, PH_P_NEWTON, PH_P_FINAL, PH_D_HINT, PH_D_MBUILD, PH_D_LDL1, PH_D_BACKSUB, PH_D_RANGE, PH_D_LDL2,
+       CNT_NEWTON = 20, CNT_POLISH, CNT_DUAL };
+
 struct Roles {
     int lane, el, ei, ej, p1, p2;
     bool is_diag;
@@ -205,7 +194,6 @@ constexpr int C_RL = L_EX + 180;    // 10   R (row-major)
 constexpr int C_ROW = L_EX + 190;   // 12   pivot row (+ rhs entry) of the elimination
 constexpr int C_LAM = L_EX + 202;   // 10   multipliers of the dual correction
 constexpr int C_SF = L_G;           // 100  full 10x10 S
-constexpr int C_UF = L_Y;           // 100  upper factor of M
 
 // In-place LDL^T elimination of the SPD matrix held one entry (a <= b) per lane, through
 // LDS row broadcasts; optionally carries a right-hand side (lanes 0..9) along.  Returns
@@ -249,11 +237,9 @@ __device__ __forceinline__ double coop_ldl(double *L, const Roles &r, double &Me
 // (row-major, every lane), pobj, zSz.  Returns the wave-uniform verdict c.ok of cvx::certify.
 // Primal half (cvx::polish_candidate, all lanes): candidate v (any multiple of [r; 1]) -> rotation R
 // (every lane), pobj = r^T Qs r; returns the determinant of the rounded matrix.
-__device__ __forceinline__ double coop_polish(double *L, const Roles &r, double Qs, const double *v, double *R, double &pobj)
+// rank-1 rounding (cvxpnpl.py:504-505) and projection to SO(3) (cvx::round_candidate), every lane
+__device__ __forceinline__ double coop_round(const double *v, double *R)
 {
-    double2 *L2 = reinterpret_cast<double2 *>(L);
-    const int lane = r.lane;
-    // ---- rank-1 rounding (cvxpnpl.py:504-505) and projection to SO(3)
     const double iv = cvx::rcp(v[9]);
     double X[9];
 #pragma unroll
@@ -266,13 +252,30 @@ __device__ __forceinline__ double coop_polish(double *L, const Roles &r, double 
         for (int i = 0; i < 9; ++i) X[i] = -X[i];
     }
     cvx::polar3(X, R, 8);
-    // full Qs (row stride 10) for the matrix-vector products
-    if (r.ej < 9 && lane < 55) { L[C_QF + r.ei * 10 + r.ej] = Qs; L[C_QF + r.ej * 10 + r.ei] = Qs; }
-    if (lane < 9) L[C_QF + lane * 10 + 9] = 0.0;
+    return d0;
+}
+
+// full Qs (row stride 10, zero last column) in LDS for the matrix-vector products of the certificate
+__device__ __forceinline__ void coop_store_qf(double *L, const Roles &r, double Qs)
+{
+    if (r.ej < 9 && r.lane < 55) { L[C_QF + r.ei * 10 + r.ej] = Qs; L[C_QF + r.ej * 10 + r.ei] = Qs; }
+    if (r.lane < 9) L[C_QF + r.lane * 10 + 9] = 0.0;
+}
+
+// Newton polish of r^T Qs r on SO(3) from the rotation R (cvx::polish_rotation, all lanes): R (every
+// lane) and pobj = r^T Qs r on exit.
+__device__ __forceinline__ void coop_polish(double *L, const Roles &r, double Qs, double *R, double &pobj CVXW_PH_PARAM)
+{
+    double2 *L2 = reinterpret_cast<double2 *>(L);
+    const int lane = r.lane;
+    CVXW_PHR(PH_P_POLAR);
+    CVXW_CNT(CNT_POLISH);
+    coop_store_qf(L, r, Qs);
     const int xsrc = kXTab.src[lane < 40 ? lane : 0];
     const double xsgn = (double)kXTab.sgn[lane < 40 ? lane : 0];
     // ---- Newton on SO(3) for f(R) = r^T Qs r (cvx::so3_newton)
     for (int it = 0; it < 6; ++it) {
+        CVXW_CNT(CNT_NEWTON);
         if (lane == 0) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) L[C_RL + i] = R[i];
@@ -301,7 +304,9 @@ __device__ __forceinline__ double coop_polish(double *L, const Roles &r, double 
             for (int j = 0; j < 3; ++j) N[i * 3 + j] = R[0 * 3 + i] * Qr[3 * j] + R[1 * 3 + i] * Qr[3 * j + 1] + R[2 * 3 + i] * Qr[3 * j + 2];
         const double g[3] = {2 * (N[7] - N[5]), 2 * (N[2] - N[6]), 2 * (N[3] - N[1])};
         CVXW_SYNC();
-        if (it >= 2 && fabs(g[0]) + fabs(g[1]) + fabs(g[2]) < 1e-15) break; // wave-uniform
+        const double gn = fabs(g[0]) + fabs(g[1]) + fabs(g[2]);
+        if (it >= 2 && gn < 1e-15) break; // wave-uniform
+        const bool final_step = gn < 1e-8;  // quadratic convergence: this step lands at rounding level
         const double trN = N[0] + N[4] + N[8];
         double H[9];
 #pragma unroll
@@ -333,7 +338,9 @@ __device__ __forceinline__ double coop_polish(double *L, const Roles &r, double 
             for (int j = 0; j < 3; ++j) Rn[i * 3 + j] = R[i * 3] * Cm[j] + R[i * 3 + 1] * Cm[3 + j] + R[i * 3 + 2] * Cm[6 + j];
 #pragma unroll
         for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+        if (final_step && pd) break;
     }
+    CVXW_PHR(PH_P_NEWTON);
     { // one polar step squares any drift from orthogonality
         double Ri[9], det, Rn[9];
         cvx::inv3(R, Ri, det);
@@ -357,12 +364,12 @@ __device__ __forceinline__ double coop_polish(double *L, const Roles &r, double 
         if (lane < 9) part = L[C_XV + lane] * dot10(L2 + (C_QF + lane * 10) / 2, L2 + C_XV / 2);
         pobj = wave_sum(part);
     }
-    return d0;
+    CVXW_PHR(PH_P_FINAL);
 }
 
 // Dual half (cvx::dual_certificate, all lanes) for the rotation R: returns the verdict c.ok.
 __device__ __forceinline__ bool coop_dual(double *L, const Roles &r, double Qs, double W, double Wp, const double *R, double d0,
-                                          double pobj, double rho, double delta, double &zSz)
+                                          double pobj, double rho, double delta, double &zSz CVXW_PH_PARAM)
 {
     // planar scene (Qs blind to the third column of R): the problem is invariant under
     // D = diag(-I6, I4) and the correction is built in the D-even subspace (cvx::dual_certificate)
@@ -392,31 +399,25 @@ __device__ __forceinline__ bool coop_dual(double *L, const Roles &r, double Qs, 
         const int a = lane < 10 ? lane : 0;
         y = dot10(L2 + (C_SF + a * 10) / 2, L2 + C_XV / 2);
     }
-    // ---- M = Ghat Ghat^T + T T^T (entry lanes), LDL^T solve M lam = rhs
-    double Me = 0.0;
+    CVXW_PHR(PH_D_HINT);
+    CVXW_CNT(CNT_DUAL);
+    // ---- multipliers lam = P(R) M_I^-1 P(R)^T rhs in closed form (cvx::dual_lambda): every lane
+    // computes all ten from the gathered rhs (compile-time sparse constants, no tables)
+    if (lane < 10) L[C_ROW + lane] = y;
+    CVXW_SYNC();
     {
-        const MTab &mt = symm ? kMTabS : kMTab;
+        double rhs[10], lam[10];
 #pragma unroll
-        for (int t = 0; t < 10; ++t) Me += mt.c[lane][t] * L[C_XV + mt.p[lane][t]] * L[C_XV + mt.q[lane][t]];
-    }
+        for (int i = 0; i < 10; ++i) rhs[i] = L[C_ROW + i];
+        cvx::dual_lambda(R, rhs, symm, lam);
+        CVXW_SYNC();
+        if (lane == 0) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) Me += L[C_XV + (1 + k) * 10 + r.ei] * L[C_XV + (1 + k) * 10 + r.ej];
-    CVXW_SYNC();
-    const double minpM = coop_ldl<true>(L, r, Me, y);
-    if (lane < 55) L[C_UF + r.ei * 10 + r.ej] = Me; // U[a][b], a <= b
-    CVXW_SYNC();
-    // back substitution: lam_k = y_k / U_kk; y_a -= U[a][k] lam_k (a < k)
-#pragma unroll
-    for (int k = 9; k >= 0; --k) {
-        const double ukk = L[C_UF + k * 10 + k];
-        const double lk_local = ukk == 0.0 ? 0.0 : y * fast_rcp(ukk);
-        const double lk = __shfl(lk_local, k, 64);
-        if (lane == 0) L[C_LAM + k] = lk;
-        const int a = lane < 10 ? lane : 0;
-        const double u = L[C_UF + a * 10 + k];
-        if (lane < k) y -= u * lk;
+            for (int i = 0; i < 10; ++i) L[C_LAM + i] = lam[i];
+        }
     }
     CVXW_SYNC();
+    CVXW_PHR(PH_D_BACKSUB);
     // ---- S2 = S1 - P_range(sym(lam z^T))
     {
         const double E = odd ? 0.0 : 0.5 * (L[C_LAM + r.ei] * L[C_XV + r.ej] + L[C_XV + r.ei] * L[C_LAM + r.ej]);
@@ -438,16 +439,19 @@ __device__ __forceinline__ bool coop_dual(double *L, const Roles &r, double Qs, 
     CVXW_SYNC();
     // ---- LDL^T of S2 + delta I: all pivots positive  <=>  lambda_min(S2) > -delta
     double Se = S + (r.is_diag ? delta : 0.0), dummy = 0.0;
+    CVXW_PHR(PH_D_RANGE);
     const double minp = coop_ldl<false>(L, r, Se, dummy);
-    return (minpM > 0) && (minp > 0) && (res < 1e-10) && (d0 > 0) && (pobj == pobj);
+    CVXW_PHR(PH_D_LDL2);
+    return (minp > 0) && (res < 1e-10) && (d0 > 0) && (pobj == pobj);
 }
 
 // both halves (cvx::certify)
 __device__ __forceinline__ bool coop_certify(double *L, const Roles &r, double Qs, double W, double Wp, const double *v,
-                                             double rho, double delta, double *R, double &pobj, double &zSz)
+                                             double rho, double delta, double *R, double &pobj, double &zSz CVXW_PH_PARAM)
 {
-    const double d0 = coop_polish(L, r, Qs, v, R, pobj);
-    return coop_dual(L, r, Qs, W, Wp, R, d0, pobj, rho, delta, zSz);
+    const double d0 = coop_round(v, R);
+    coop_polish(L, r, Qs, R, pobj CVXW_PH_ARG);
+    return coop_dual(L, r, Qs, W, Wp, R, d0, pobj, rho, delta, zSz CVXW_PH_ARG);
 }
 
 struct WaveArgs {
@@ -476,6 +480,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
     Roles roles;
     roles.lane = lane; roles.el = el; roles.ei = ei; roles.ej = ej; roles.p1 = p1; roles.p2 = p2;
     roles.is_diag = is_diag; roles.s0 = s0; roles.s1 = s1; roles.s2 = s2;
+    CVXW_PH_DECL;
     const int jl = lane < 50 ? lane : lane - 50;      // jacobi lane (50..63 alias 0..13)
     const int ji = jl % 10, jk = jl / 10;
 
@@ -586,6 +591,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
     const double itr = finite ? cvx::rcp(tr) : 0.0;
     const double Qs = Qe * itr;
 
+    CVXW_PH(PH_ASSEMBLE);
     // ---------------------------------------------------------------- ADMM
     double delta = o.eps / (8.0 * tr);
     delta = delta < 1e-13 ? 1e-13 : delta;
@@ -659,6 +665,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
         const double tol2 = o.jacobi_tol * o.jacobi_tol;
         int sweeps = 0;
         bool more;
+        CVXW_PH(PH_EIG_SETUP);
         do {
             bool coarse = false;
             for (int step = 0; step < 9; ++step) {
@@ -690,6 +697,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
         } while (more);
         total_sweeps += sweeps;
         cold = false;
+        CVXW_PH(PH_JACOBI);
         // ---- Wp = sum_{lam > 0} lam v v^T, from (g, w g) with w = lam / lam'^2
         const double lpa = sqrt(al), lpb = sqrt(be);
         const double lama = lpa - sigma, lamb = lpb - sigma;
@@ -717,6 +725,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
         }
         }
         ++it;
+        CVXW_PH(PH_WP);
         const bool check = it >= next_check;
         const bool last = (it >= o.max_iters) || (fp_res < o.res_tol);
         if (check || last) {
@@ -754,26 +763,23 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
                 double vloc[10];
 #pragma unroll
                 for (int i = 0; i < 10; ++i) vloc[i] = L[L_V + i];
-                // repeated checks mostly round to the pose the previous check already polished (see
-                // cvx::solve_sdp): reuse it when the raw rank-1 ratio is within 0.3 of that rotation
+                // repeated checks mostly polish to the pose the previous check already had (see
+                // cvx::solve_sdp): reuse it when the rounded candidate is within 0.22 of that rotation
+                const double d0 = coop_round(vloc, Rc);
                 double dist2 = 0;
-                {
-                    const double iv = cvx::rcp(vloc[9]);
 #pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) { const double dd = vloc[3 * j + i] * iv - L[L_M + 50 + i * 3 + j]; dist2 += dd * dd; }
-                }
-                double d0;
-                if (have_prev && dist2 < 0.09) {
+                for (int i = 0; i < 9; ++i) { const double dd = Rc[i] - L[L_M + 50 + i]; dist2 += dd * dd; }
+                CVXW_PH(PH_TOPSEL);
+                if (have_prev && dist2 < 0.05) {
 #pragma unroll
                     for (int i = 0; i < 9; ++i) Rc[i] = L[L_M + 50 + i];
                     pobj = fprev;
-                    d0 = 1.0;
                 } else {
-                    d0 = coop_polish(L, roles, Qs, vloc, Rc, pobj);
+                    coop_polish(L, roles, Qs, Rc, pobj CVXW_PH_ARG);
                 }
-                const bool cok = coop_dual(L, roles, Qs, W, Wp, Rc, d0, pobj, rho, delta, zSz);
+                CVXW_PH(PH_POLISH);
+                const bool cok = coop_dual(L, roles, Qs, W, Wp, Rc, d0, pobj, rho, delta, zSz CVXW_PH_ARG);
+                CVXW_PH(PH_DUAL);
                 gap_ok = cok && (tr * (fabs(zSz) + 4.0 * delta) <= gap_tol);
                 have_prev = d0 > 0 && (pobj == pobj);
                 fprev = pobj;
@@ -791,7 +797,8 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
                 double zc[10], fp, fm;
 #pragma unroll
                 for (int i = 0; i < 10; ++i) zc[i] = (c1 + d1) * L[L_V + i] + (c2 + d2) * L[L_V + 10 + i];
-                const double dp = coop_polish(L, roles, Qs, zc, Rc, fp);
+                const double dp = coop_round(zc, Rc);
+                coop_polish(L, roles, Qs, Rc, fp CVXW_PH_ARG);
                 if (lane == 0) {
 #pragma unroll
                     for (int i = 0; i < 9; ++i) L[L_M + 30 + i] = Rc[i];
@@ -799,7 +806,8 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
 #pragma unroll
                 for (int i = 0; i < 10; ++i) zc[i] = (c1 - d1) * L[L_V + i] + (c2 - d2) * L[L_V + 10 + i];
                 CVXW_SYNC();
-                const double dm = coop_polish(L, roles, Qs, zc, Rc, fm);
+                const double dm = coop_round(zc, Rc);
+                coop_polish(L, roles, Qs, Rc, fm CVXW_PH_ARG);
                 if (lane == 0) {
 #pragma unroll
                     for (int i = 0; i < 9; ++i) L[L_M + 40 + i] = Rc[i];
@@ -818,7 +826,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
                     for (int i = 0; i < 9; ++i) Rc[i] = L[L_M + 30 + i];
                 }
                 pobj = take_m ? fm : fp;
-                const bool cok = coop_dual(L, roles, Qs, W, Wp, Rc, take_m ? dm : dp, pobj, rho, delta, zSz);
+                const bool cok = coop_dual(L, roles, Qs, W, Wp, Rc, take_m ? dm : dp, pobj, rho, delta, zSz CVXW_PH_ARG);
                 const bool ok = cok && (tr * (fabs(zSz) + 4.0 * delta) <= gap_tol);
                 ambiguous = twins && ok;
                 gap_ok = !twins && ok;
@@ -850,6 +858,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
 #pragma unroll
                     for (int j = 0; j < 3; ++j) M0[i * 3 + j] = L[L_V + 3 * j + i] * iv;
                 cvx::polar3(M0, Rf, 12);
+                coop_store_qf(L, roles, Qs); // (a reused pose skipped the polish that would have stored it)
                 if (lane < 10) L[C_XV + lane] = lane == 9 ? 1.0 : Rf[0]; // placeholder, overwritten below
                 CVXW_SYNC();
                 if (lane == 0) {
@@ -883,6 +892,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
                 rank_out = (int)L[L_M + 28];
                 done = true;
             }
+            CVXW_PH(PH_CHECK_TAIL);
         }
         if (!done && it == o.tail_from) { // smaller penalty for the slow tail; keeps the dual: Wm scales by rho / rho_tail
             W = Wp + (W - Wp) * (rho / o.rho_tail);
@@ -897,6 +907,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
             fp_res = sqrt(wave_sum(wgt * dd * dd));
             if (!(fp_res == fp_res)) { status = cvx::ST_NONFINITE; done = true; }
             CVXW_SYNC();
+            CVXW_PH(PH_UPDATE);
         }
     }
 
@@ -931,6 +942,8 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
         } else zv = Wp;
         a.Z[b * 55 + lane] = zv;
     }
+    CVXW_PH(PH_OUTPUT);
+    CVXW_PH_FLUSH();
 }
 
 __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx::Opts o)
