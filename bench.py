@@ -39,6 +39,13 @@ def algorithmic_bytes(n_p, n_l):
     return 8 * (5 * n_p + 10 * n_l) + 100
 
 
+def _kernel_name(layout, batch):
+    """kernels of one step (AUTO policy of cvxpnpl_solve_batch)"""
+    if layout == 0:
+        layout = 2 if batch < 12288 else (3 if batch < 40960 else 1)
+    return {1: "solve_lane_kernel + resume_wave_kernel", 2: "solve_wave_kernel", 3: "solve_quad_kernel + resume_wave_kernel"}[layout]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -50,7 +57,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="skip the extra two-stream (overlapped batches) measurement")
     ap.add_argument("--cpu-sample", type=int, default=0, help="problems in the CPU baseline sample (0 = auto)")
-    ap.add_argument("--layout", type=int, default=0, help="kernel layout (0 auto, 1 lane, 2 wave)")
+    ap.add_argument("--layout", type=int, default=0, help="kernel layout (0 auto, 1 lane/hybrid, 2 wave, 3 quad/hybrid)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of results when --gpus > 1")
     ap.add_argument("--opt", action="append", default=[], help="solver option override name=value (diagnostics)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the steps are issued round-robin on (1 = the contract's "
@@ -207,7 +214,7 @@ def main():
                    "streams": nstreams,
                    "parallelism": f"batch-sharded x{world}" + (", RCCL all_gather of results" if gather else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                     "traffic": None, "kernel": "solve_wave_kernel" if (opts.layout == 2 or (opts.layout == 0 and batch < 12288)) else "solve_lane_kernel + resume_wave_kernel", "mean_launch_ms": 1e3 * mean_launch_s,
+                     "traffic": None, "kernel": _kernel_name(opts.layout, batch), "mean_launch_ms": 1e3 * mean_launch_s,
                      "algorithmic_bytes_per_problem": algorithmic_bytes(n_p, n_l),
                      "note": "VALU/latency-bound by construction (~500 B and ~1e5-1e6 flop per pose), see DESIGN.md"},
         "solver": {"certified_frac": float((st == 0).mean()), "status_hist": np.bincount(st, minlength=5).tolist(),

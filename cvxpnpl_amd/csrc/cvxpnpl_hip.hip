@@ -12,6 +12,7 @@
 #include "problem_io.h"
 #include "solver_core.h"
 #include "wave_kernel.h"
+#include "quad_kernel.h"
 
 namespace {
 
@@ -154,18 +155,37 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
     int64_t grid = (batch + block - 1) / block;
     if (grid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }
     int layout = opts ? opts->layout : CVXPNPL_LAYOUT_AUTO;
-    // AUTO: a wavefront per problem finishes each problem fast and keeps every SIMD busy at small
-    // batches; from ~12 k problems the hybrid schedule (64 problems per wavefront for the first
-    // lane_iters iterations, the unfinished ones resumed one per wavefront) wins on instruction
-    // count.  Measured, one MI355X (M poses/s, wave vs hybrid): 4 k: 12.8 vs 9.5; 10 k: 18.5 vs 19.7;
-    // 16 k: 22 vs 28; 49 k: 27 vs 54; 1 M: 30 vs 78.  At 10 k the two are within 6 %; the wave layout is
-    // kept there because it moves 7x less memory (no scratch spills: 16 MB vs 112 MB per launch).
-    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch >= 12288 ? CVXPNPL_LAYOUT_LANE : CVXPNPL_LAYOUT_WAVE;
-    if (layout == CVXPNPL_LAYOUT_WAVE) {
-        cvxw::WaveArgs w;
-        w.batch = batch; w.n_p = n_p; w.n_l = n_l; w.K_per_problem = K_per_problem;
-        w.p2 = d_pts_2d; w.p3 = d_pts_3d; w.l2 = d_line_2d; w.l3 = d_line_3d; w.K = d_K;
-        w.R = d_R; w.t = d_t; w.cost = d_cost; w.Z = d_Z; w.status = d_status; w.iters = d_iters; w.work = d_work;
+    // AUTO, by launch size (measured on one MI355X, M poses/s for wave / quad / lane-hybrid, PnP N = 10):
+    //   5 k: 16.5 / 15.3 / 11.8    10 k: 25.3 / 25.5 / 20.9    16 k: 29.0 / 36.4 / 27.9
+    //   32 k: 31.9 / 45.3 / 42.5   50 k: 32.9 / 50.2 / 54.3    125 k: 37.8 / 59.2 / 67.9
+    // * below 12288 problems a wavefront per problem: every SIMD gets work and a finished problem frees
+    //   its slot at once;
+    // * from there four problems per wavefront (one per DPP row): 2.3x fewer instructions per problem;
+    // * from 40960 the lane-hybrid schedule (64 problems per wavefront for the first lane_iters
+    //   iterations): fewest instructions, but it needs tens of thousands of problems to fill the chip.
+    // The unfinished problems of the quad and lane phases are resumed one per wavefront.
+    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 12288 ? CVXPNPL_LAYOUT_WAVE : (batch < 40960 ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
+    cvxw::WaveArgs w;
+    w.batch = batch; w.n_p = n_p; w.n_l = n_l; w.K_per_problem = K_per_problem;
+    w.p2 = d_pts_2d; w.p3 = d_pts_3d; w.l2 = d_line_2d; w.l3 = d_line_3d; w.K = d_K;
+    w.R = d_R; w.t = d_t; w.cost = d_cost; w.Z = d_Z; w.status = d_status; w.iters = d_iters; w.work = d_work;
+    int quad_iters = opts ? opts->lane_iters : -1;
+    if (quad_iters < 0) quad_iters = 6;
+    if (layout == CVXPNPL_LAYOUT_QUAD && !(quad_iters >= 1 && o.max_iters > quad_iters)) layout = CVXPNPL_LAYOUT_WAVE;
+    if (layout == CVXPNPL_LAYOUT_QUAD) {
+        // four problems per wavefront for the first quad_iters iterations, survivors resumed one per wavefront
+        const size_t qbytes = ((size_t)(batch + 1) * sizeof(int32_t) + 255) & ~(size_t)255;
+        char *wsp = (char *)get_workspace(qbytes + (size_t)batch * 56 * sizeof(double), stream);
+        if (!wsp) { snprintf(g_err, sizeof(g_err), "cvxpnpl: workspace allocation failed"); return -2; }
+        int32_t *queue = (int32_t *)wsp;
+        double *ws = (double *)(wsp + qbytes);
+        hipError_t me = hipMemsetAsync(queue, 0, sizeof(int32_t), s);
+        if (me != hipSuccess) return set_err("hipMemsetAsync", me);
+        const int64_t qgrid = (batch + 3) / 4;
+        hipLaunchKernelGGL(cvxq::solve_quad_kernel, dim3((unsigned)qgrid), dim3(64), 0, s, w, o, quad_iters, queue, ws);
+        const int64_t rgrid = batch < 8192 ? batch : 8192;
+        hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64 * cvxw::WPB), 0, s, w, o, queue, ws);
+    } else if (layout == CVXPNPL_LAYOUT_WAVE) {
         int64_t wgrid = (batch + cvxw::WPB - 1) / cvxw::WPB;
         if (wgrid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }
         hipLaunchKernelGGL(cvxw::solve_wave_kernel, dim3((unsigned)wgrid), dim3(64 * cvxw::WPB), 0, s, w, o);
@@ -186,10 +206,6 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
             if (me != hipSuccess) return set_err("hipMemsetAsync", me);
             if (lane_iters < 6) hipLaunchKernelGGL(solve_lane_kernel<false>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, queue, ws);
             else hipLaunchKernelGGL(solve_lane_kernel<true>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, queue, ws);
-            cvxw::WaveArgs w;
-            w.batch = batch; w.n_p = n_p; w.n_l = n_l; w.K_per_problem = K_per_problem;
-            w.p2 = d_pts_2d; w.p3 = d_pts_3d; w.l2 = d_line_2d; w.l3 = d_line_3d; w.K = d_K;
-            w.R = d_R; w.t = d_t; w.cost = d_cost; w.Z = d_Z; w.status = d_status; w.iters = d_iters; w.work = d_work;
             const int64_t rgrid = batch < 8192 ? batch : 8192;
             hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64 * cvxw::WPB), 0, s, w, o, queue, ws);
         } else {

@@ -1,0 +1,774 @@
+// quad_kernel.h -- sixteen lanes per problem, four problems per gfx950 wavefront.
+//
+// The 10x10 SDP is too small for 64 lanes: in the wave-per-problem layout most instructions are 3x3 /
+// scalar algebra replicated in every lane, and the kernel is VALU-issue bound on that redundancy.
+// Here a DPP row (16 lanes) owns one problem, so every replicated instruction serves four problems:
+//   * eigen-solve: lane j < 10 owns COLUMN j of G = (W + sigma I) V in registers.  A one-sided Jacobi
+//     rotation needs the partner's column: 22 ds_bpermute per round-robin round (no LDS memory, no
+//     barrier), then both lanes of a pair compute the same rotation and update their own column;
+//   * entry work (affine projection, ADMM update, PSD reconstruction, LDL^T): the 55 entries of the
+//     symmetric iterate are dealt round-robin, entry e to lane e % 16 (3-4 entries per lane);
+//   * reductions over a problem are 4-step DPP butterflies inside the row (quad_perm, row_half_mirror,
+//     row_mirror); the four problems of a wave run in lock step, control flow is wave-uniform and a
+//     finished problem just idles until its three neighbours are done.
+// The kernel runs the first `handoff_at` ADMM iterations (certificate attempts from first_check on);
+// the few problems that are not certified by then park their iterate in ws[] and are queued for
+// cvxw::resume_wave_kernel (twin candidates, slow tails and the reference's uncertified exits live there).
+// Mathematics identical to solver_core.h / wave_kernel.h; see those files for the derivations.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "problem_io.h"
+#include "solver_core.h"
+#include "wave_kernel.h"
+
+namespace cvxq {
+
+using cvxw::WaveArgs;
+
+// LDS slice per problem, in doubles (even offsets: 16-byte aligned): 3.1 KB, 12.4 KB per wave, so that three
+// waves per SIMD fit the 160 KB of a CU.  388 * 2 dwords = 8 mod 64 banks: the four slices of a wave start
+// 8 banks apart.  Regions are reused across phases (noted per region).
+constexpr int Q_WF = 0;    // 100  full 10x10: W (warm start), S (certificate); assembly: records, then the 60 Gram sums
+constexpr int Q_QF = 100;  // 100  full Qs, row stride 10, zero last column (certificate mat-vecs); assembly: records
+constexpr int Q_Y = 200;   // 124  eigen columns g [column][row] + weights (100..109); certificate scratch
+constexpr int Q_X = Q_Y + 40; // 56 entry scratch of the affine projection (over C_YV.. : never live together)
+constexpr int Q_B = 324;   // 28   translation map B (27)
+constexpr int Q_M = 352;   // 36   0.. R out, 12.. previous polished R, 22.. candidate eigenvector
+constexpr int QLDS = 388;
+constexpr int C_XV = Q_Y;         // 40  x-vectors z, a_0, a_1, a_2 (stride 10)
+constexpr int C_YV = Q_Y + 40;    // 40  Qs x
+constexpr int C_H1 = Q_Y + 80;    // 10  a_k . Q a_l
+constexpr int C_RL = Q_Y + 90;    // 10  R (row-major)
+constexpr int C_ROW = Q_Y + 100;  // 12  pivot row of the elimination / gathered rhs
+constexpr int C_LAM = Q_Y + 112;  // 10  multipliers of the dual correction
+
+// entry e of the symmetric 10x10 (vech order): ei | ej << 4 | p1 << 8 | p2 << 14 | neg0 << 20 | neg1 << 21 |
+// neg2 << 22 | diag << 23, with (p1, p2, signs) the other two members of its equality triple
+struct ETab { unsigned w[64]; };
+constexpr ETab make_etab()
+{
+    const cvxw::LaneTab t = cvxw::make_lane_tab();
+    ETab o{};
+    for (int e = 0; e < 64; ++e) {
+        const int s = e < 55 ? e : 0;
+        o.w[e] = (unsigned)t.ei[s] | ((unsigned)t.ej[s] << 4) | ((unsigned)t.p1[s] << 8) | ((unsigned)t.p2[s] << 14) |
+                 ((unsigned)(t.s0[s] < 0) << 20) | ((unsigned)(t.s1[s] < 0) << 21) | ((unsigned)(t.s2[s] < 0) << 22) |
+                 ((unsigned)(t.diag[s] != 0) << 23);
+    }
+    return o;
+}
+__device__ const ETab kETab = make_etab();
+
+// round-robin partner of column l at step st (cvx::rr_col), 4 bits per step; idle lanes pair with themselves
+struct PTab { unsigned long long packed[16]; };
+constexpr PTab make_ptab()
+{
+    PTab t{};
+    for (int l = 0; l < 16; ++l) {
+        unsigned long long w = 0;
+        for (int st = 0; st < 9; ++st) {
+            int partner = l;
+            for (int k = 0; k < 5; ++k) {
+                const int p = cvx::rr_col(st, k), q = cvx::rr_col(st, k + 5);
+                if (p == l) partner = q;
+                if (q == l) partner = p;
+            }
+            w |= (unsigned long long)partner << (4 * st);
+        }
+        t.packed[l] = w;
+    }
+    return t;
+}
+__device__ const PTab kPTab = make_ptab();
+
+// x-vector table of the polish: element (v, i) of z / a_k as sign * R[src]  (cvxw::kXTab), 40 entries
+// dealt to lane idx % 16
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// all-reduce over the 16 lanes of a DPP row: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ double row_sum(double x)
+{
+    x += dpp_mov<0xB1>(x);
+    x += dpp_mov<0x4E>(x);
+    x += dpp_mov<0x141>(x);
+    x += dpp_mov<0x140>(x);
+    return x;
+}
+__device__ __forceinline__ double row_max(double x)
+{
+    x = fmax(x, dpp_mov<0xB1>(x));
+    x = fmax(x, dpp_mov<0x4E>(x));
+    x = fmax(x, dpp_mov<0x141>(x));
+    x = fmax(x, dpp_mov<0x140>(x));
+    return x;
+}
+__device__ __forceinline__ double bperm(int addr, double v)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double flip(double x, unsigned neg) // neg in {0, 1}
+{
+    return __hiloint2double(__double2hiint(x) ^ (int)(neg << 31), __double2loint(x));
+}
+__device__ __forceinline__ unsigned grp_bits(unsigned long long m, int grp) { return (unsigned)(m >> (16 * grp)) & 0xFFFFu; }
+
+// entries owned by a lane
+struct Own {
+    int e[4], ei[4], ej[4];
+    unsigned pk[4];
+    bool ok[4];
+    double wgt[4];
+};
+
+// Projection of the symmetric matrix held 3-4 entries per lane onto { <A_i, Z> = b_i } (tgt = 1) or its
+// direction space (tgt = 0); closed form of cvx::proj_affine.
+__device__ __forceinline__ void quad_proj(double *L, const Own &w, double *X, double tgt)
+{
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        if (w.ok[m]) L[Q_X + w.e[m]] = X[m];
+    CVXW_SYNC();
+    double d[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) d[k] = L[Q_X + cvx::sidx(k, k)];
+    const double r0 = d[0] + d[3] + d[6] - tgt, r1 = d[1] + d[4] + d[7] - tgt, r2 = d[2] + d[5] + d[8] - tgt;
+    const double c0 = d[0] + d[1] + d[2] - tgt, c1 = d[3] + d[4] + d[5] - tgt, c2 = d[6] + d[7] + d[8] - tgt;
+    const double tot = r0 + r1 + r2;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const unsigned pk = w.pk[m];
+        const int ri = w.ei[m] % 3, ci = w.ei[m] / 3; // diagonal entry (ei, ei), ei < 9, is D[ri][ci]
+        const double rr = ri == 0 ? r0 : (ri == 1 ? r1 : r2), cc = ci == 0 ? c0 : (ci == 1 ? c1 : c2);
+        const double xdiag = (w.ei[m] == 9) ? tgt : X[m] - (rr + cc) * (1.0 / 3.0) + tot * (1.0 / 9.0);
+        const double x1 = L[Q_X + ((pk >> 8) & 63)], x2 = L[Q_X + ((pk >> 14) & 63)];
+        const unsigned n0 = (pk >> 20) & 1;
+        const double mm = (flip(X[m], n0) + flip(x1, (pk >> 21) & 1) + flip(x2, (pk >> 22) & 1)) * (1.0 / 3.0);
+        X[m] = ((pk >> 23) & 1) ? xdiag : X[m] - flip(mm, n0);
+    }
+    CVXW_SYNC();
+}
+
+// Rotation of one one-sided Jacobi step seen from ONE of the two lanes of a pair: d = |other|^2 - |own|^2,
+// gam = own . other.  own' = c own - s other; the partner, with d -> -d, gets t -> -t: together the same
+// plane rotation as cvx::jacobi_cs.  tie_neg breaks d == 0 consistently (the pair must not both pick +t).
+__device__ __forceinline__ void pair_cs(double d, double gam, bool rot, bool tie_neg, double &c, double &s, double &t)
+{
+    const double g2 = 2.0 * gam;
+    const float df = (float)d, gf = (float)g2;
+    const float h2 = df * df + gf * gf + 1e-37f;
+    const float hf = h2 * __builtin_amdgcn_rsqf(h2);
+    float tf = gf * __builtin_amdgcn_rcpf(fabsf(df) + hf);
+    const bool neg = d < 0.0 || (d == 0.0 && tie_neg);
+    tf = neg ? -tf : tf;
+    t = rot ? (double)tf : 0.0;
+    const double x = 1.0 + t * t;
+    double z = (double)__builtin_amdgcn_rsqf((float)x);
+    { const double hh = 0.5 * x * z; const double e = fma(-hh, z, 0.5); z = fma(z, e, z); }
+    c = z;
+    s = t * c;
+}
+
+// In-place LDL^T of the symmetric matrix held 3-4 entries per lane, pivot rows broadcast through LDS;
+// returns the smallest pivot (cvx::ldl_min_pivot).
+__device__ __forceinline__ double quad_ldl(double *L, const Own &w, double *Me)
+{
+    double minp = 1e300;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (w.ok[m] && w.ei[m] == k) L[C_ROW + w.ej[m]] = Me[m];
+        CVXW_SYNC();
+        const double d = L[C_ROW + k];
+        minp = d < minp ? d : minp;
+        const double id = cvxw::fast_rcp(d);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const double ra = L[C_ROW + w.ei[m]], rb = L[C_ROW + w.ej[m]];
+            if (w.ei[m] > k) Me[m] -= ra * id * rb;
+        }
+        CVXW_SYNC();
+    }
+    return minp;
+}
+
+// Four problems per wavefront: problem b = 4 * blockIdx.x + (lane >> 4).
+__global__ void __launch_bounds__(64, 2) solve_quad_kernel(WaveArgs a, cvx::Opts o, int handoff_at, int32_t *queue, double *ws)
+{
+    __shared__ __attribute__((aligned(16))) double lds_all[4 * QLDS];
+    const int lane = threadIdx.x & 63, gl = lane & 15, grp = lane >> 4;
+    double *L = lds_all + grp * QLDS;
+    double2 *L2 = reinterpret_cast<double2 *>(L);
+    const int64_t b_raw = (int64_t)blockIdx.x * 4 + grp;
+    const bool gvalid = b_raw < a.batch;
+    const int64_t b = gvalid ? b_raw : a.batch - 1; // surplus rows redo the last problem, outputs suppressed
+
+    // ---------------------------------------------------------------- roles
+    Own w;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        w.e[m] = gl + 16 * m;
+        w.ok[m] = w.e[m] < 55;
+        w.pk[m] = kETab.w[w.e[m]];
+        w.ei[m] = (int)(w.pk[m] & 15);
+        w.ej[m] = (int)((w.pk[m] >> 4) & 15);
+        w.wgt[m] = w.ok[m] ? (w.ei[m] == w.ej[m] ? 1.0 : 2.0) : 0.0;
+    }
+    const unsigned long long ptab = kPTab.packed[gl];
+    const int lane_base4 = (lane & 48) << 2;
+
+    // ---------------------------------------------------------------- assembly (cvxpnpl.py:20-153, :545-549)
+    cvx::ProblemView pv = cvx::make_view(b, a.n_p, a.p2, a.p3, a.n_l, a.l2, a.l3, a.K, a.K_per_problem);
+    double Ki[9];
+    bool okK;
+    {
+        double Kc[9], det;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Kc[i] = pv.K[i];
+        cvx::inv3(Kc, Ki, det);
+        okK = (det == det) && det != 0.0;
+    }
+    // Gram sums: role r = gl + 16 m < 60 is  sum rec[6 + qa] rec[6 + qb] rec[te]  with rec = (T[6], 1, P[3]):
+    // M0 (6): qa = qb = 0 | M1 (3 x 6): qa = 1 + a | M2 (6 x 6): qa = 1 + a, qb = 1 + b
+    int rqa[4], rqb[4], rte[4];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int r = gl + 16 * m;
+        const int al = r < 60 ? r : 0;
+        int qa = 0, qb = 0, te = al;
+        if (al >= 6 && al < 24) { qa = 1 + (al - 6) / 6; te = (al - 6) % 6; }
+        if (al >= 24) {
+            const int ab = (al - 24) / 6;
+            te = (al - 24) % 6;
+            qa = 1 + (ab < 3 ? 0 : (ab < 5 ? 1 : 2));
+            qb = 1 + (ab < 3 ? ab : (ab < 5 ? ab - 2 : 2));
+        }
+        rqa[m] = 6 + qa; rqb[m] = 6 + qb; rte[m] = te;
+    }
+    const int nrec = pv.n_p + 2 * pv.n_l;
+    for (int base = 0; base < nrec; base += 16) {
+        const int cnt = nrec - base < 16 ? nrec - base : 16;
+        if (gl < cnt) {
+            const int r = base + gl;
+            double T[6], P[3];
+            if (r < pv.n_p) {
+                double p[3];
+                cvx::bearing(Ki, pv.p2[2 * r], pv.p2[2 * r + 1], p);
+                const double n2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+                T[0] = n2 - p[0] * p[0]; T[1] = -p[0] * p[1]; T[2] = -p[0] * p[2];
+                T[3] = n2 - p[1] * p[1]; T[4] = -p[1] * p[2]; T[5] = n2 - p[2] * p[2];
+                P[0] = pv.p3[3 * r]; P[1] = pv.p3[3 * r + 1]; P[2] = pv.p3[3 * r + 2];
+            } else {
+                const int li = (r - pv.n_p) >> 1, en = (r - pv.n_p) & 1;
+                const double *l2 = pv.l2 + 4 * li, *l3 = pv.l3 + 6 * li + 3 * en;
+                double u[3], v[3];
+                cvx::bearing(Ki, l2[0], l2[1], u);
+                cvx::bearing(Ki, l2[2], l2[3], v);
+                double n[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+                const double inv = cvx::rsqrt_(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                n[0] *= inv; n[1] *= inv; n[2] *= inv;
+                T[0] = n[0] * n[0]; T[1] = n[0] * n[1]; T[2] = n[0] * n[2]; T[3] = n[1] * n[1]; T[4] = n[1] * n[2]; T[5] = n[2] * n[2];
+                P[0] = l3[0]; P[1] = l3[1]; P[2] = l3[2];
+            }
+            double *rec = L + Q_WF + gl * 10;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) rec[i] = T[i];
+            rec[6] = 1.0; rec[7] = P[0]; rec[8] = P[1]; rec[9] = P[2];
+        }
+        CVXW_SYNC();
+        for (int c = 0; c < cnt; ++c) {
+            const double *rec = L + Q_WF + c * 10;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] += rec[rqa[m]] * rec[rqb[m]] * rec[rte[m]];
+        }
+        CVXW_SYNC();
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        if (gl + 16 * m < 60) L[Q_WF + gl + 16 * m] = acc[m];
+    CVXW_SYNC();
+    // B = M0^-1 [M1_0 M1_1 M1_2], Q = M2 - M1^T B
+    bool okG;
+    {
+        const double *mm = L + Q_WF;
+        double M0[9] = {mm[0], mm[1], mm[2], mm[1], mm[3], mm[4], mm[2], mm[4], mm[5]}, Mi[9], det;
+        cvx::inv3(M0, Mi, det);
+        const double sc = mm[0] + mm[3] + mm[5];
+        okG = det > 1e-12 * (sc * sc * sc) * (1.0 / 27.0);
+        if (gl < 9) {
+            double sel = Mi[0];
+#pragma unroll
+            for (int i = 1; i < 9; ++i) sel = gl == i ? Mi[i] : sel;
+            L[Q_X + gl] = sel;
+        }
+    }
+    CVXW_SYNC();
+    // packed index of (i, j) in a symmetric 3x3 (00 01 02 11 12 22)
+    auto psym = [](int i, int j) { const int lo = i < j ? i : j, hi = i < j ? j : i; return lo * 3 - (lo == 2 ? 1 : 0) + (hi - lo); };
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int idx = gl + 16 * m;
+        if (idx < 27) {
+            const int bb = idx / 9, i = (idx % 9) / 3, j = idx % 3;
+            const double *m1 = L + Q_WF + 6 + 6 * bb;
+            double v = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v += L[Q_X + i * 3 + k] * m1[psym(k, j)];
+            L[Q_B + i * 9 + 3 * bb + j] = v; // B[i][3 bb + j]
+        }
+    }
+    CVXW_SYNC();
+    double Qs[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        double v = 0.0;
+        if (w.ok[m] && w.ej[m] < 9) {
+            const int qa = w.ei[m] / 3, qi = w.ei[m] % 3, qb = w.ej[m] / 3, qj = w.ej[m] % 3;
+            const double *m1 = L + Q_WF + 6 + 6 * qa, *m2 = L + Q_WF + 24 + 6 * psym(qa, qb);
+            v = m2[psym(qi, qj)];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v -= m1[psym(qi, k)] * L[Q_B + k * 9 + 3 * qb + qj];
+        }
+        Qs[m] = v;
+    }
+    CVXW_SYNC();
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        if (w.ok[m]) L[Q_X + w.e[m]] = Qs[m];
+    CVXW_SYNC();
+    double tr = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) tr += L[Q_X + cvx::sidx(k, k)];
+    bool finite = okK && okG && (tr == tr) && tr > 0 && tr < 1e300;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) finite = finite && (Qs[m] == Qs[m]);
+    finite = grp_bits(__ballot(!finite), grp) == 0;
+    const double itr = finite ? cvx::rcp(tr) : 0.0;
+    CVXW_SYNC();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        Qs[m] *= itr;
+        if (w.ok[m] && w.ej[m] < 9) { L[Q_QF + w.ei[m] * 10 + w.ej[m]] = Qs[m]; L[Q_QF + w.ej[m] * 10 + w.ei[m]] = Qs[m]; }
+    }
+    if (gl < 9) L[Q_QF + gl * 10 + 9] = 0.0;
+    // planar scene: the cost is blind to the third column of R (cvx::dual_certificate, SYMM)
+    bool symm;
+    {
+        bool zero = true;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) zero = zero && !(w.ok[m] && w.ej[m] >= 6 && w.ej[m] < 9 && !(fabs(Qs[m]) < 1e-13));
+        symm = grp_bits(__ballot(!zero), grp) == 0;
+    }
+    bool odd[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) odd[m] = symm && ((w.ei[m] < 6) != (w.ej[m] < 6));
+
+    // ---------------------------------------------------------------- ADMM
+    double delta = o.eps / (8.0 * tr);
+    delta = delta < 1e-13 ? 1e-13 : delta;
+    const double gap_tol = o.eps > 8e-13 * tr ? o.eps : 8e-13 * tr;
+    double rho = o.rho, irho = 1.0 / o.rho;
+    double W[4], Wp[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { W[m] = (w.e[m] == 54) ? 1.0 : 0.0; Wp[m] = W[m]; }
+    double v[10]; // unit eigenvector owned by this lane (warm start of the next eigen-solve)
+#pragma unroll
+    for (int i = 0; i < 10; ++i) v[i] = (gl == i) ? 1.0 : 0.0;
+    int it = 0, total_sweeps = 0, next_check = o.first_check;
+    bool have_prev = false;
+    double fprev = 0.0;
+    bool done = !gvalid || !finite;
+    const double tol2 = o.jacobi_tol * o.jacobi_tol;
+    CVXW_SYNC();
+
+    if (gvalid && !finite) { // degenerate input: NaN pose (cvxpnpl.py:493-498)
+        if (gl < 9) a.R[b * 9 + gl] = NAN;
+        if (gl < 3) a.t[b * 3 + gl] = NAN;
+        if (gl == 0) {
+            a.status[b] = cvx::ST_NONFINITE;
+            if (a.iters) a.iters[b] = 0;
+            if (a.cost) { a.cost[2 * b] = NAN; a.cost[2 * b + 1] = NAN; }
+            if (a.work) { a.work[2 * b] = 0; a.work[2 * b + 1] = 0; }
+        }
+        if (a.Z) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                if (w.ok[m]) a.Z[b * 55 + w.e[m]] = NAN;
+        }
+    }
+
+    while (__any(!done)) {
+        double al = 0.0, sigma = 0.0;
+        if (!(it == 0 && o.first_check > 1)) {
+            // ---- eigendecomposition of W: one-sided Jacobi on G = (W + sigma I) V_prev, column gl in this lane
+            double fro = 0.0;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) fro += w.wgt[m] * W[m] * W[m];
+            sigma = 1.5 * cvx::sqrt_fast(row_sum(fro)) + 1e-300;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                if (w.ok[m]) { L[Q_WF + w.ei[m] * 10 + w.ej[m]] = W[m]; L[Q_WF + w.ej[m] * 10 + w.ei[m]] = W[m]; }
+            CVXW_SYNC();
+            double g[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const double2 *row = L2 + (Q_WF + i * 10) / 2;
+                const double2 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3], r4 = row[4];
+                g[i] = sigma * v[i] + (((r0.x * v[0] + r0.y * v[1]) + (r1.x * v[2] + r1.y * v[3])) + ((r2.x * v[4] + r2.y * v[5]) + (r3.x * v[6] + r3.y * v[7])) +
+                                       (r4.x * v[8] + r4.y * v[9]));
+            }
+            al = 0.0;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) al += g[i] * g[i];
+            int sweeps = 0;
+            bool active = !done; // row-uniform
+            do {
+                bool coarse = false;
+#pragma unroll
+                for (int st = 0; st < 9; ++st) {
+                    const int partner = (int)((ptab >> (4 * st)) & 15);
+                    const int addr = lane_base4 + (partner << 2);
+                    double og[10];
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) og[i] = bperm(addr, g[i]);
+                    const double be = bperm(addr, al);
+                    const double gam = ((g[0] * og[0] + g[1] * og[1]) + (g[2] * og[2] + g[3] * og[3])) + ((g[4] * og[4] + g[5] * og[5]) + (g[6] * og[6] + g[7] * og[7])) +
+                                       (g[8] * og[8] + g[9] * og[9]);
+                    const double g2 = gam * gam, ab = al * be;
+                    coarse |= (partner != gl) && g2 > tol2 * ab;
+                    double c, s, t;
+                    pair_cs(be - al, gam, active && (partner != gl) && g2 > 1e-30 * ab, gl > partner, c, s, t);
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) g[i] = c * g[i] - s * og[i];
+                    al -= t * gam;
+                }
+                al = 0.0; // exact norms once per sweep (the incremental update drifts)
+#pragma unroll
+                for (int i = 0; i < 10; ++i) al += g[i] * g[i];
+                const bool grp_more = grp_bits(__ballot(coarse && active), grp) != 0;
+                if (active) ++sweeps;
+                active = active && grp_more && sweeps < o.jacobi_sweeps;
+            } while (__any(active));
+            total_sweeps += sweeps;
+            // ---- Wp = sum_{lam > 0} lam u u^T from (g, w g), w = lam / |g|^2
+            const double lp = cvx::sqrt_fast(al), lam = lp - sigma;
+            const bool col = gl < 10;
+            const double wpos = (col && lam > 0) ? lam * cvx::rcp(al) : 0.0;
+            const double ilp = col ? cvx::rsqrt_(al) : 0.0;
+            if (col) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) L2[(Q_Y + gl * 10) / 2 + i] = make_double2(g[2 * i], g[2 * i + 1]);
+                L[Q_Y + 100 + gl] = wpos;
+            }
+#pragma unroll
+            for (int i = 0; i < 10; ++i) v[i] = g[i] * ilp;
+            const unsigned long long pm = __ballot(wpos > 0);
+            const unsigned anypos = (unsigned)((pm | (pm >> 16) | (pm >> 32) | (pm >> 48)) & 0x3FFull);
+            CVXW_SYNC();
+#pragma unroll
+            for (int m = 0; m < 4; ++m) Wp[m] = 0.0;
+#pragma unroll
+            for (int s = 0; s < 10; ++s) {
+                if ((anypos >> s) & 1u) { // wave-uniform; a column with no weight in THIS problem adds 0
+                    const double ws_ = L[Q_Y + 100 + s];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) Wp[m] += ws_ * L[Q_Y + s * 10 + w.ei[m]] * L[Q_Y + s * 10 + w.ej[m]];
+                }
+            }
+        }
+        ++it;
+        const bool check = it >= next_check;
+        if (check) {
+            // ---- certificate attempt (cvx::solve_sdp, non-twin branch): top eigenvector of Wp
+            const double best = row_max(gl < 10 ? al : -1.0);
+            const unsigned tm = grp_bits(__ballot(gl < 10 && al == best), grp);
+            const int jmax = __builtin_ctz(tm | 0x10000u);
+            CVXW_SYNC(); // (the Wp gathers above are done with Q_Y)
+            if (gl == jmax) {
+#pragma unroll
+                for (int i = 0; i < 10; ++i) L[Q_M + 22 + i] = v[i];
+            }
+            CVXW_SYNC();
+            double vloc[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) vloc[i] = L[Q_M + 22 + i];
+            double Rc[9], pobj = 0.0;
+            const double d0 = cvxw::coop_round(vloc, Rc);
+            double dist2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { const double dd = Rc[i] - L[Q_M + 12 + i]; dist2 += dd * dd; }
+            const bool reuse = have_prev && dist2 < 0.05;
+            // the four problems polish together; when none needs it (done, or the rounded candidate is the pose
+            // the previous check already polished) the Newton iterations are skipped altogether
+            if (__any(!done && !reuse)) {
+                // ---- Newton on SO(3) for f(R) = r^T Qs r (cvx::so3_newton)
+                int xsrc[3];
+                double xsgn[3];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const int idx = gl + 16 * m < 40 ? gl + 16 * m : 0;
+                    xsrc[m] = cvxw::kXTab.src[idx];
+                    xsgn[m] = (double)cvxw::kXTab.sgn[idx];
+                }
+                for (int nit = 0; nit < 6; ++nit) {
+                    if (gl == 0) {
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) L[C_RL + i] = Rc[i];
+                    }
+                    CVXW_SYNC();
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        const int idx = gl + 16 * m;
+                        if (idx < 40) L[C_XV + idx] = (idx == 9) ? 1.0 : xsgn[m] * L[C_RL + xsrc[m]];
+                    }
+                    CVXW_SYNC();
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        const int idx = gl + 16 * m;
+                        if (idx < 36) {
+                            const int vv = idx / 9, i = idx % 9;
+                            L[C_YV + vv * 10 + i] = cvxw::dot10(L2 + (Q_QF + i * 10) / 2, L2 + (C_XV + vv * 10) / 2);
+                        }
+                    }
+                    if (gl < 4) L[C_YV + gl * 10 + 9] = 0.0;
+                    CVXW_SYNC();
+                    if (gl < 9) {
+                        const int k = gl / 3, l = gl % 3;
+                        L[C_H1 + gl] = cvxw::dot10(L2 + (C_XV + (1 + k) * 10) / 2, L2 + (C_YV + (1 + l) * 10) / 2);
+                    }
+                    CVXW_SYNC();
+                    double Qr[9], H1[9];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) { Qr[i] = L[C_YV + i]; H1[i] = L[C_H1 + i]; }
+                    double N[9];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) N[i * 3 + j] = Rc[0 * 3 + i] * Qr[3 * j] + Rc[1 * 3 + i] * Qr[3 * j + 1] + Rc[2 * 3 + i] * Qr[3 * j + 2];
+                    const double g3[3] = {2 * (N[7] - N[5]), 2 * (N[2] - N[6]), 2 * (N[3] - N[1])};
+                    const double gn = fabs(g3[0]) + fabs(g3[1]) + fabs(g3[2]);
+                    CVXW_SYNC();
+                    if (nit >= 2 && !__any(!done && !(gn < 1e-15))) break;
+                    const bool final_step = gn < 1e-8;
+                    const double trN = N[0] + N[4] + N[8];
+                    double H[9];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int l = 0; l < 3; ++l) H[k * 3 + l] = 2 * H1[k * 3 + l] + N[l * 3 + k] + N[k * 3 + l] - (k == l ? 2 * trN : 0.0);
+                    double Hi[9], det;
+                    cvx::inv3(H, Hi, det);
+                    const bool pd = H[0] > 0 && (H[0] * H[4] - H[1] * H[3]) > 0 && det > 0;
+                    const double hn = fabs(H[0]) + fabs(H[4]) + fabs(H[8]) + 1e-300;
+                    double ww[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const double nw = -(Hi[k * 3] * g3[0] + Hi[k * 3 + 1] * g3[1] + Hi[k * 3 + 2] * g3[2]);
+                        ww[k] = pd ? nw : -g3[k] * cvx::rcp(hn);
+                    }
+                    const double wn = cvx::sqrt_fast(ww[0] * ww[0] + ww[1] * ww[1] + ww[2] * ww[2]);
+                    const double lim = wn > 0.5 ? 0.5 * cvx::rcp(wn) : 1.0;
+                    const double q0 = 0.5 * lim * ww[0], q1 = 0.5 * lim * ww[1], q2 = 0.5 * lim * ww[2];
+                    const double ss = q0 * q0 + q1 * q1 + q2 * q2;
+                    const double f = 2.0 * cvx::rcp(1.0 + ss);
+                    const double Cm[9] = {1 + f * (q0 * q0 - ss), f * (-q2 + q0 * q1), f * (q1 + q0 * q2),
+                                          f * (q2 + q0 * q1), 1 + f * (q1 * q1 - ss), f * (-q0 + q1 * q2),
+                                          f * (-q1 + q0 * q2), f * (q0 + q1 * q2), 1 + f * (q2 * q2 - ss)};
+                    double Rn[9];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) Rn[i * 3 + j] = Rc[i * 3] * Cm[j] + Rc[i * 3 + 1] * Cm[3 + j] + Rc[i * 3 + 2] * Cm[6 + j];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) Rc[i] = Rn[i];
+                    if (!__any(!done && !(final_step && pd))) break;
+                }
+                { // one polar step squares any drift from orthogonality
+                    double Ri[9], det, Rn[9];
+                    cvx::inv3(Rc, Ri, det);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) Rn[i * 3 + j] = 0.5 * (Rc[i * 3 + j] + Ri[j * 3 + i]);
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) Rc[i] = Rn[i];
+                }
+                // z of the final R; pobj = z^T Qs z
+                if (gl == 0) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) L[C_XV + 3 * j + i] = Rc[i * 3 + j];
+                    L[C_XV + 9] = 1.0;
+                }
+                CVXW_SYNC();
+                double part = 0.0;
+                if (gl < 9) part = L[C_XV + gl] * cvxw::dot10(L2 + (Q_QF + gl * 10) / 2, L2 + C_XV / 2);
+                pobj = row_sum(part);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Rc[i] = L[Q_M + 12 + i];
+                pobj = fprev;
+                CVXW_SYNC();
+                if (gl == 0) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) L[C_XV + 3 * j + i] = Rc[i * 3 + j];
+                    L[C_XV + 9] = 1.0;
+                }
+                CVXW_SYNC();
+            }
+            // ---- dual half (cvx::dual_certificate): hint S_h = rho (Wp - W); S1 = S_h - P_null(S_h - Qs)
+            double S[4];
+            {
+                double T[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { S[m] = rho * (Wp[m] - W[m]); T[m] = S[m] - (w.ej[m] < 9 ? Qs[m] : 0.0); }
+                quad_proj(L, w, T, 0.0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    S[m] = odd[m] ? 0.0 : S[m] - T[m];
+                    if (w.ok[m]) { L[Q_WF + w.ei[m] * 10 + w.ej[m]] = S[m]; L[Q_WF + w.ej[m] * 10 + w.ei[m]] = S[m]; }
+                }
+            }
+            CVXW_SYNC();
+            if (gl < 10) L[C_ROW + gl] = cvxw::dot10(L2 + (Q_WF + gl * 10) / 2, L2 + C_XV / 2); // rhs = S z
+            CVXW_SYNC();
+            {
+                double rhs[10], lamv[10];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) rhs[i] = L[C_ROW + i];
+                cvx::dual_lambda(Rc, rhs, symm, lamv);
+                if (gl == 0) {
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) L[C_LAM + i] = lamv[i];
+                }
+            }
+            CVXW_SYNC();
+            {   // S2 = S1 - P_range(sym(lam z^T))
+                double E[4], Nn[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    E[m] = odd[m] ? 0.0 : 0.5 * (L[C_LAM + w.ei[m]] * L[C_XV + w.ej[m]] + L[C_XV + w.ei[m]] * L[C_LAM + w.ej[m]]);
+                    Nn[m] = E[m];
+                }
+                quad_proj(L, w, Nn, 0.0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    S[m] -= E[m] - Nn[m];
+                    if (w.ok[m]) { L[Q_WF + w.ei[m] * 10 + w.ej[m]] = S[m]; L[Q_WF + w.ej[m] * 10 + w.ei[m]] = S[m]; }
+                }
+            }
+            CVXW_SYNC();
+            double res, zSz;
+            {
+                const int aa = gl < 10 ? gl : 0;
+                const double sz = cvxw::dot10(L2 + (Q_WF + aa * 10) / 2, L2 + C_XV / 2);
+                res = row_max(gl < 10 ? fabs(sz) : 0.0);
+                zSz = row_sum(gl < 10 ? L[C_XV + aa] * sz : 0.0);
+            }
+            CVXW_SYNC();
+            double Se[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) Se[m] = S[m] + (((w.pk[m] >> 23) & 1) ? delta : 0.0);
+            const double minp = quad_ldl(L, w, Se);
+            const bool cok = (minp > 0) && (res < 1e-10) && (d0 > 0) && (pobj == pobj);
+            const bool gap_ok = cok && (tr * (fabs(zSz) + 4.0 * delta) <= gap_tol);
+            have_prev = d0 > 0 && (pobj == pobj);
+            fprev = pobj;
+            if (gl == 0) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { L[Q_M + 12 + i] = Rc[i]; L[Q_M + i] = Rc[i]; }
+            }
+            CVXW_SYNC();
+            next_check = cvx::next_check_after(it, o);
+            if (gap_ok && !done) {
+                // ---- outputs of a certified problem
+                if (gl < 9) a.R[b * 9 + gl] = L[Q_M + gl];
+                if (gl < 3) { // t = -B r (cvxpnpl.py:513), r = vec_colmajor(R)
+                    double tv = 0;
+#pragma unroll
+                    for (int c3 = 0; c3 < 3; ++c3)
+#pragma unroll
+                        for (int r3 = 0; r3 < 3; ++r3) tv += L[Q_B + gl * 9 + 3 * c3 + r3] * L[Q_M + r3 * 3 + c3];
+                    a.t[b * 3 + gl] = -tv;
+                }
+                if (gl == 0) {
+                    a.status[b] = cvx::ST_CERTIFIED;
+                    if (a.iters) a.iters[b] = it;
+                    if (a.cost) { a.cost[2 * b] = tr * pobj; a.cost[2 * b + 1] = tr * (pobj - zSz - 4.0 * delta); }
+                    if (a.work) { a.work[2 * b] = 1; a.work[2 * b + 1] = total_sweeps; }
+                }
+                if (a.Z) { // Z = z z^T with z = [vec_colmajor(R); 1]
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        if (w.ok[m]) a.Z[b * 55 + w.e[m]] = L[C_XV + w.ei[m]] * L[C_XV + w.ej[m]];
+                }
+                done = true;
+            }
+        }
+        if (!done && it == o.tail_from) { // smaller penalty for the slow tail; keeps the dual: Wm scales by rho / rho_tail
+#pragma unroll
+            for (int m = 0; m < 4; ++m) W[m] = Wp[m] + (W[m] - Wp[m]) * (rho / o.rho_tail);
+        }
+        if (it == o.tail_from) { rho = o.rho_tail; irho = 1.0 / rho; }
+        // ---- X = Pi_aff(2 Wp - W - Qs / rho);  W <- W + alpha (X - Wp)
+        {
+            double X[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) X[m] = 2.0 * Wp[m] - W[m] - irho * (w.ej[m] < 9 ? Qs[m] : 0.0);
+            quad_proj(L, w, X, 1.0);
+            double r2 = 0.0;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const double dd = X[m] - Wp[m];
+                W[m] += o.alpha * dd;
+                r2 += w.wgt[m] * dd * dd;
+            }
+            const double fp_res = cvx::sqrt_fast(row_sum(r2));
+            if (!done && !(fp_res == fp_res)) { // NaN guard
+                if (gl < 9) a.R[b * 9 + gl] = NAN;
+                if (gl < 3) a.t[b * 3 + gl] = NAN;
+                if (gl == 0) {
+                    a.status[b] = cvx::ST_NONFINITE;
+                    if (a.iters) a.iters[b] = it;
+                    if (a.cost) { a.cost[2 * b] = NAN; a.cost[2 * b + 1] = NAN; }
+                    if (a.work) { a.work[2 * b] = 0; a.work[2 * b + 1] = total_sweeps; }
+                }
+                if (a.Z) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        if (w.ok[m]) a.Z[b * 55 + w.e[m]] = NAN;
+                }
+                done = true;
+            }
+        }
+        if (it >= handoff_at) {
+            // ---- hand the unfinished problems to the wave-per-problem kernel
+            if (!done) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    if (w.ok[m]) ws[b * 56 + w.e[m]] = W[m];
+                if (gl == 0) {
+                    ws[b * 56 + 55] = (double)it;
+                    const int q = atomicAdd(&queue[0], 1);
+                    queue[1 + q] = (int32_t)b;
+                }
+            }
+            break;
+        }
+    }
+}
+
+} // namespace cvxq

@@ -135,6 +135,20 @@ CVX_HD double rsqrt_(double x)
 #endif
 }
 
+// sqrt for non-negative x: x * rsqrt(x) on the device (7 VALU instead of the 18 of the IEEE expansion).
+// The scalar core keeps the library sqrt (sqrt_) where it is not in the eigen-solve: measured on the
+// lane-per-problem kernels, the shorter sequence there lengthens live ranges and costs more in spills than
+// it saves (125 k PnP: 70 M poses/s with sqrt_fast everywhere, 76 M with this split).
+CVX_HD double sqrt_fast(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return x > 0 ? x * rsqrt_(x) : 0.0;
+#else
+    return sqrt(x);
+#endif
+}
+CVX_HD double sqrt_(double x) { return sqrt(x); }
+
 CVX_HD void inv3(const double *M, double *Mi, double &det)
 {
     double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
@@ -322,7 +336,7 @@ CVX_HD void eig_load(Eig &e, const double *W)
     double fro = 0;
     CVX_UNROLL for (int i = 0; i < 10; ++i)
         CVX_UNROLL for (int j = i; j < 10; ++j) fro += (i == j ? 1.0 : 2.0) * W[sidx(i, j)] * W[sidx(i, j)];
-    e.sigma = 1.5 * sqrt(fro) + 1e-300;
+    e.sigma = 1.5 * sqrt_fast(fro) + 1e-300;
     CVX_UNROLL for (int j = 0; j < 10; ++j)
         CVX_UNROLL for (int i = 0; i < 10; ++i) e.G[j][i] = W[sidx(i, j)] + (i == j ? e.sigma : 0.0);
 }
@@ -335,7 +349,7 @@ CVX_HD void eig_load_warm(Eig &e, const double *W, const double (*Vn)[10])
     double fro = 0;
     CVX_UNROLL for (int i = 0; i < 10; ++i)
         CVX_UNROLL for (int j = i; j < 10; ++j) fro += (i == j ? 1.0 : 2.0) * W[sidx(i, j)] * W[sidx(i, j)];
-    e.sigma = 1.5 * sqrt(fro) + 1e-300;
+    e.sigma = 1.5 * sqrt_fast(fro) + 1e-300;
     CVX_UNROLL for (int j = 0; j < 10; ++j)
         CVX_UNROLL for (int i = 0; i < 10; ++i) {
             double acc = e.sigma * Vn[j][i];
@@ -481,7 +495,7 @@ CVX_HD void eig_pospart(const Eig &e, double *Wp)
 {
     double w[10];
     CVX_UNROLL for (int j = 0; j < 10; ++j) {
-        double lp = sqrt(e.n2[j]);
+        double lp = sqrt_fast(e.n2[j]);
         double lam = lp - e.sigma;
         w[j] = lam > 0 ? lam / e.n2[j] : 0.0;
     }
@@ -550,7 +564,7 @@ CVX_HD void so3_newton(const double *Q9, double *R, int iters)
             double nw = -(Hi[k * 3] * g[0] + Hi[k * 3 + 1] * g[1] + Hi[k * 3 + 2] * g[2]);
             w[k] = pd ? nw : -g[k] * rcp(hn);
         }
-        double wn = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        double wn = sqrt_(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
         double lim = wn > 0.5 ? 0.5 * rcp(wn) : 1.0;
         // Cayley retraction R <- R (I - S)^-1 (I + S), S = [w/2]x  = R (I + 2/(1+|s|^2) (S + S^2))
         double s0 = 0.5 * lim * w[0], s1 = 0.5 * lim * w[1], s2 = 0.5 * lim * w[2];
@@ -826,7 +840,7 @@ CVX_HD void twin_candidates(const double *v1, const double *v2, double *zp, doub
     const double a = v1[9], b = v2[9], n2 = a * a + b * b;
     const double inv = rcp(n2), rn = rsqrt_(n2);
     const double rad = 4.0 - inv;
-    const double sq = rad > 0 ? sqrt(rad) : 0.0;
+    const double sq = rad > 0 ? sqrt_(rad) : 0.0;
     const double c1 = a * inv, c2 = b * inv, d1 = -b * rn * sq, d2 = a * rn * sq;
     CVX_UNROLL for (int i = 0; i < 10; ++i) {
         zp[i] = (c1 + d1) * v1[i] + (c2 + d2) * v2[i];
@@ -1009,8 +1023,9 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
             // in closed form (twin_candidates) and polished: equal cost => the problem IS two-fold ambiguous:
             // stop with rank 2 and the exact Z = (z+ z+^T + z- z-^T) / 2, like the reference's rank-2 branch;
             // otherwise the better one goes through the dual certificate.
-            const double l1 = sqrt(best) - e.sigma, l2 = sqrt(second) - e.sigma;
-            const bool two = TWIN && it >= 6 && l2 > 0.5 * l1;
+            // l2 > l1 / 2 with l = sqrt(n2) - sigma, evaluated only where the twin logic can fire
+            bool two = false;
+            if (TWIN && it >= 6) two = (sqrt_fast(second) - e.sigma) > 0.5 * (sqrt_fast(best) - e.sigma);
             double vt[10], v2[10], il1 = rsqrt_(best), il2 = rsqrt_(second);
             CVX_UNROLL for (int i = 0; i < 10; ++i) {
                 double s1 = 0, s2 = 0;
@@ -1096,7 +1111,8 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                 done = true;
             } else if (last && !done) {
                 int rank = 0;
-                CVX_UNROLL for (int j = 0; j < 10; ++j) rank += (sqrt(e.n2[j]) - e.sigma) > 1e-3;
+                const double thr = (e.sigma + 1e-3) * (e.sigma + 1e-3); // eigenvalue > 1e-3 (cvxpnpl.py:501) without the roots
+                CVX_UNROLL for (int j = 0; j < 10; ++j) rank += e.n2[j] > thr;
                 fallback_pose(Qs, tr, vt, rank, sol);
                 if (Zout) { CVX_UNROLL for (int i = 0; i < 55; ++i) Zout[i] = Wp[i]; }
                 done = true;
@@ -1123,7 +1139,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                     r2 += (i == j ? 1.0 : 2.0) * d * d;
                     W[sidx(i, j)] += o.alpha * d;
                 }
-            fp_res = sqrt(r2);
+            fp_res = sqrt_(r2);
 #ifdef CVX_TRACE
             {
                 double lam[10];

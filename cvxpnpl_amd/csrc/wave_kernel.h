@@ -65,6 +65,7 @@ constexpr LaneTab make_lane_tab()
 
 __device__ const LaneTab kLaneTab = make_lane_tab();
 
+
 #define CVXW_SYNC()                                              \
     do {                                                         \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
@@ -107,6 +108,25 @@ constexpr XTab make_xtab()
     return t;
 }
 __device__ const XTab kXTab = make_xtab();
+
+// everything a lane needs to know about its roles in ONE 32-bit word (one global load at kernel start instead
+// of ten byte loads scattered over the phases): ei | ej << 4 | p1 << 8 | p2 << 14 | (s0 < 0) << 20 | (s1 < 0) << 21 |
+// (s2 < 0) << 22 | diag << 23 | xsrc << 24 | (xsgn: 0 zero, 1 plus, 2 minus) << 28
+struct LanePack { unsigned w[64]; };
+constexpr LanePack make_lane_pack()
+{
+    const LaneTab t = make_lane_tab();
+    const XTab x = make_xtab();
+    LanePack o{};
+    for (int l = 0; l < 64; ++l) {
+        const int xs = l < 40 ? x.src[l] : 0, xg = l < 40 ? x.sgn[l] : 0;
+        o.w[l] = (unsigned)t.ei[l] | ((unsigned)t.ej[l] << 4) | ((unsigned)t.p1[l] << 8) | ((unsigned)t.p2[l] << 14) |
+                 ((unsigned)(t.s0[l] < 0) << 20) | ((unsigned)(t.s1[l] < 0) << 21) | ((unsigned)(t.s2[l] < 0) << 22) |
+                 ((unsigned)(t.diag[l] != 0) << 23) | ((unsigned)xs << 24) | ((unsigned)(xg == 0 ? 0 : (xg > 0 ? 1 : 2)) << 28);
+    }
+    return o;
+}
+__device__ const LanePack kLanePack = make_lane_pack();
 
 __device__ __forceinline__ double fast_rcp(double x)
 {
@@ -160,9 +180,9 @@ enum { PH_ASSEMBLE = 0, PH_EIG_SETUP, PH_JACOBI, PH_WP, PH_TOPSEL, PH_POLISH, PH
        CNT_NEWTON = 20, CNT_POLISH, CNT_DUAL };
 
 struct Roles {
-    int lane, el, ei, ej, p1, p2;
+    int lane, el, ei, ej, p1, p2, xsrc;
     bool is_diag;
-    double s0, s1, s2;
+    double s0, s1, s2, xsgn;
 };
 
 // projection of the symmetric matrix held one entry per lane onto { <A_i, Z> = b_i }
@@ -271,8 +291,8 @@ __device__ __forceinline__ void coop_polish(double *L, const Roles &r, double Qs
     CVXW_PHR(PH_P_POLAR);
     CVXW_CNT(CNT_POLISH);
     coop_store_qf(L, r, Qs);
-    const int xsrc = kXTab.src[lane < 40 ? lane : 0];
-    const double xsgn = (double)kXTab.sgn[lane < 40 ? lane : 0];
+    const int xsrc = r.xsrc;
+    const double xsgn = r.xsgn;
     // ---- Newton on SO(3) for f(R) = r^T Qs r (cvx::so3_newton)
     for (int it = 0; it < 6; ++it) {
         CVXW_CNT(CNT_NEWTON);
@@ -323,7 +343,7 @@ __device__ __forceinline__ void coop_polish(double *L, const Roles &r, double Qs
             const double nw = -(Hi[k * 3] * g[0] + Hi[k * 3 + 1] * g[1] + Hi[k * 3 + 2] * g[2]);
             w[k] = pd ? nw : -g[k] * cvx::rcp(hn);
         }
-        const double wn = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        const double wn = cvx::sqrt_fast(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
         const double lim = wn > 0.5 ? 0.5 * cvx::rcp(wn) : 1.0;
         const double q0 = 0.5 * lim * w[0], q1 = 0.5 * lim * w[1], q2 = 0.5 * lim * w[2];
         const double ss = q0 * q0 + q1 * q1 + q2 * q2;
@@ -377,8 +397,8 @@ __device__ __forceinline__ bool coop_dual(double *L, const Roles &r, double Qs, 
     const bool odd = symm && ((r.ei < 6) != (r.ej < 6));
     double2 *L2 = reinterpret_cast<double2 *>(L);
     const int lane = r.lane;
-    const int xsrc = kXTab.src[lane < 40 ? lane : 0];
-    const double xsgn = (double)kXTab.sgn[lane < 40 ? lane : 0];
+    const int xsrc = r.xsrc;
+    const double xsgn = r.xsgn;
     // z and the tangent vectors of R (the polish may have left those of another candidate in LDS)
     if (lane == 0) {
 #pragma unroll
@@ -471,21 +491,47 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
     double2 *L2 = reinterpret_cast<double2 *>(L);
 
     // ---------------------------------------------------------------- lane roles
-    const int ei = kLaneTab.ei[lane], ej = kLaneTab.ej[lane];
+    const unsigned lw = kLanePack.w[lane];
+    const int ei = (int)(lw & 15), ej = (int)((lw >> 4) & 15);
     const int el = lane < 55 ? lane : lane - 55;      // entry index (lanes 55..63 alias 0..8, weight 0)
     const double wgt = lane < 55 ? (ei == ej ? 1.0 : 2.0) : 0.0;
-    const bool is_diag = kLaneTab.diag[lane] != 0;
-    const int p1 = kLaneTab.p1[lane], p2 = kLaneTab.p2[lane];
-    const double s0 = kLaneTab.s0[lane], s1 = kLaneTab.s1[lane], s2 = kLaneTab.s2[lane];
+    const bool is_diag = ((lw >> 23) & 1) != 0;
+    const int p1 = (int)((lw >> 8) & 63), p2 = (int)((lw >> 14) & 63);
+    const double s0 = ((lw >> 20) & 1) ? -1.0 : 1.0, s1 = ((lw >> 21) & 1) ? -1.0 : 1.0, s2 = ((lw >> 22) & 1) ? -1.0 : 1.0;
     Roles roles;
     roles.lane = lane; roles.el = el; roles.ei = ei; roles.ej = ej; roles.p1 = p1; roles.p2 = p2;
     roles.is_diag = is_diag; roles.s0 = s0; roles.s1 = s1; roles.s2 = s2;
+    roles.xsrc = (int)((lw >> 24) & 15);
+    roles.xsgn = ((lw >> 28) & 3) == 0 ? 0.0 : (((lw >> 28) & 3) == 1 ? 1.0 : -1.0);
     CVXW_PH_DECL;
     const int jl = lane < 50 ? lane : lane - 50;      // jacobi lane (50..63 alias 0..13)
     const int ji = jl % 10, jk = jl / 10;
 
     // ---------------------------------------------------------------- assembly
     cvx::ProblemView pv = cvx::make_view(b, a.n_p, a.p2, a.p3, a.n_l, a.l2, a.l3, a.K, a.K_per_problem);
+    const int nrec = pv.n_p + 2 * pv.n_l;
+    constexpr int CHUNK = 32; // records (T[6], P[3]) staged per pass in L_EX.. (32 * 10 doubles)
+    // raw inputs of record r: a point (u, v, X, Y, Z) or one endpoint of a line (2D segment + its 3D point).
+    // The first chunk is requested BEFORE K is inverted, so that all global loads of the problem are in
+    // flight together (one memory round trip instead of three).
+    // (separate registers for the point and the line case: loads into the same registers from both sides of
+    // the branch would force a wait between them)
+    auto load_point = [&](int r, double *q) {
+        q[0] = pv.p2[2 * r]; q[1] = pv.p2[2 * r + 1];
+        q[2] = pv.p3[3 * r]; q[3] = pv.p3[3 * r + 1]; q[4] = pv.p3[3 * r + 2];
+    };
+    auto load_line = [&](int r, double *q) {
+        const int li = (r - pv.n_p) >> 1, en = (r - pv.n_p) & 1;
+        const double *l2 = pv.l2 + 4 * li, *l3 = pv.l3 + 6 * li + 3 * en;
+        q[0] = l2[0]; q[1] = l2[1]; q[2] = l2[2]; q[3] = l2[3];
+        q[4] = l3[0]; q[5] = l3[1]; q[6] = l3[2];
+    };
+    double rawp[5] = {0, 0, 0, 0, 0}, rawl[7] = {0, 0, 0, 0, 0, 0, 0};
+    {
+        const int cnt0 = nrec < CHUNK ? nrec : CHUNK;
+        if (lane < cnt0 && lane < pv.n_p) load_point(lane, rawp);
+        if (lane < cnt0 && lane >= pv.n_p) load_line(lane, rawl);
+    }
     double Ki[9];
     bool okK;
     {
@@ -495,46 +541,44 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
         cvx::inv3(Kc, Ki, det);
         okK = (det == det) && det != 0.0;
     }
-    // accumulator role of this lane: M0 (6) | M1 (3 x 6) | M2 (6 x 6)
-    int acc_type = 0, acc_pa = 0, acc_pb = 0, acc_te = 0;
+    // accumulator role of this lane: sum rec[6 + qa] rec[6 + qb] rec[te] with rec = (T[6], 1, P[3]):
+    // M0 (6): qa = qb = 0 | M1 (3 x 6): qa = 1 + a | M2 (6 x 6): qa = 1 + a, qb = 1 + b
+    int acc_qa = 6, acc_qb = 6, acc_te = 0;
     {
         const int al = lane < 60 ? lane : 0;
-        if (al < 6) { acc_type = 0; acc_te = al; }
-        else if (al < 24) { acc_type = 1; acc_pa = (al - 6) / 6; acc_te = (al - 6) % 6; }
-        else {
-            acc_type = 2;
-            int ab = (al - 24) / 6;
+        acc_te = al;
+        if (al >= 6 && al < 24) { acc_qa = 7 + (al - 6) / 6; acc_te = (al - 6) % 6; }
+        if (al >= 24) {
+            const int ab = (al - 24) / 6;
             acc_te = (al - 24) % 6;
-            acc_pa = ab < 3 ? 0 : (ab < 5 ? 1 : 2);
-            acc_pb = ab < 3 ? ab : (ab < 5 ? ab - 2 : 2);
+            acc_qa = 7 + (ab < 3 ? 0 : (ab < 5 ? 1 : 2));
+            acc_qb = 7 + (ab < 3 ? ab : (ab < 5 ? ab - 2 : 2));
         }
     }
     double acc = 0.0;
-    const int nrec = pv.n_p + 2 * pv.n_l;
-    constexpr int CHUNK = 32; // records (T[6], P[3]) staged per pass in L_EX.. (32 * 10 doubles)
     for (int base = 0; base < nrec; base += CHUNK) {
         const int cnt = nrec - base < CHUNK ? nrec - base : CHUNK;
         if (lane < cnt) {
             const int r = base + lane;
             double T[6], P[3];
             if (r < pv.n_p) {
+                if (base > 0) load_point(r, rawp);
                 double p[3];
-                cvx::bearing(Ki, pv.p2[2 * r], pv.p2[2 * r + 1], p);
+                cvx::bearing(Ki, rawp[0], rawp[1], p);
                 double n2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
                 T[0] = n2 - p[0] * p[0]; T[1] = -p[0] * p[1]; T[2] = -p[0] * p[2];
                 T[3] = n2 - p[1] * p[1]; T[4] = -p[1] * p[2]; T[5] = n2 - p[2] * p[2];
-                P[0] = pv.p3[3 * r]; P[1] = pv.p3[3 * r + 1]; P[2] = pv.p3[3 * r + 2];
+                P[0] = rawp[2]; P[1] = rawp[3]; P[2] = rawp[4];
             } else {
-                const int li = (r - pv.n_p) >> 1, en = (r - pv.n_p) & 1;
-                const double *l2 = pv.l2 + 4 * li, *l3 = pv.l3 + 6 * li + 3 * en;
+                if (base > 0) load_line(r, rawl);
                 double u[3], v[3];
-                cvx::bearing(Ki, l2[0], l2[1], u);
-                cvx::bearing(Ki, l2[2], l2[3], v);
+                cvx::bearing(Ki, rawl[0], rawl[1], u);
+                cvx::bearing(Ki, rawl[2], rawl[3], v);
                 double n[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
                 double inv = cvx::rsqrt_(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
                 n[0] *= inv; n[1] *= inv; n[2] *= inv;
                 T[0] = n[0] * n[0]; T[1] = n[0] * n[1]; T[2] = n[0] * n[2]; T[3] = n[1] * n[1]; T[4] = n[1] * n[2]; T[5] = n[2] * n[2];
-                P[0] = l3[0]; P[1] = l3[1]; P[2] = l3[2];
+                P[0] = rawl[4]; P[1] = rawl[5]; P[2] = rawl[6];
             }
             double *rec = L + L_EX + lane * 10;
 #pragma unroll
@@ -544,41 +588,44 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
         CVXW_SYNC();
         for (int c = 0; c < cnt; ++c) {
             const double *rec = L + L_EX + c * 10;
-            double coef = (acc_type == 0 ? 1.0 : rec[7 + acc_pa]) * (acc_type == 2 ? rec[7 + acc_pb] : 1.0);
-            acc += coef * rec[acc_te];
+            acc += rec[acc_qa] * rec[acc_qb] * rec[acc_te];
         }
         CVXW_SYNC();
     }
     L[L_P + lane] = acc; // ACC[0..59]
     CVXW_SYNC();
     // B = M0^-1 [M1_0 M1_1 M1_2], Q = M2 - M1^T B; every lane inverts M0 redundantly
-    double Mi[9];
     bool okG;
     {
         const double *m = L + L_P;
-        double M0[9] = {m[0], m[1], m[2], m[1], m[3], m[4], m[2], m[4], m[5]}, det;
+        double M0[9] = {m[0], m[1], m[2], m[1], m[3], m[4], m[2], m[4], m[5]}, Mi[9], det;
         cvx::inv3(M0, Mi, det);
         double sc = m[0] + m[3] + m[5];
         okG = det > 1e-12 * (sc * sc * sc) * (1.0 / 27.0);
+        double sel = Mi[0]; // element `lane` of the inverse, without dynamic register indexing
+#pragma unroll
+        for (int i = 1; i < 9; ++i) sel = lane == i ? Mi[i] : sel;
+        if (lane < 9) L[L_X + lane] = sel;
     }
-    constexpr int psym[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
+    CVXW_SYNC();
+    // packed index of (i, j) in a symmetric 3x3 (00 01 02 11 12 22)
+    auto psym = [](int i, int j) { const int lo = i < j ? i : j, hi = i < j ? j : i; return lo * 3 - (lo == 2 ? 1 : 0) + (hi - lo); };
     if (lane < 27) {
         const int bb = lane / 9, i = (lane % 9) / 3, j = lane % 3;
         const double *m1 = L + L_P + 6 + 6 * bb;
         double v = 0;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) v += Mi[i * 3 + k] * m1[psym[3 * k + j]];
+        for (int k = 0; k < 3; ++k) v += L[L_X + i * 3 + k] * m1[psym(k, j)];
         L[L_B + i * 9 + 3 * bb + j] = v; // B[i][3 bb + j]
     }
     CVXW_SYNC();
     double Qe = 0.0; // Q9 entry of this entry-lane (0 outside the 9x9 block)
     if (ej < 9) {
         const int qa = ei / 3, qi = ei % 3, qb = ej / 3, qj = ej % 3;
-        constexpr int abidx[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
-        const double *m1 = L + L_P + 6 + 6 * qa, *m2 = L + L_P + 24 + 6 * abidx[3 * qa + qb];
-        double v = m2[psym[3 * qi + qj]];
+        const double *m1 = L + L_P + 6 + 6 * qa, *m2 = L + L_P + 24 + 6 * psym(qa, qb);
+        double v = m2[psym(qi, qj)];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) v -= m1[psym[3 * qi + k]] * L[L_B + k * 9 + 3 * qb + qj];
+        for (int k = 0; k < 3; ++k) v -= m1[psym(qi, k)] * L[L_B + k * 9 + 3 * qb + qj];
         Qe = v;
     }
     L[L_X + el] = Qe;
@@ -592,6 +639,9 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
     const double Qs = Qe * itr;
 
     CVXW_PH(PH_ASSEMBLE);
+#ifdef CVXW_STOP_AFTER_ASSEMBLY // timing ablation (tools/ablate.sh): assembly only
+    { const double chk = wave_sum(Qs); if (lane == 0) a.status[b] = chk > 1e300 ? 1 : 0; return; }
+#endif
     // ---------------------------------------------------------------- ADMM
     double delta = o.eps / (8.0 * tr);
     delta = delta < 1e-13 ? 1e-13 : delta;
@@ -624,7 +674,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
         } else {
         // ---- eigendecomposition of W: one-sided Jacobi on G = W + sigma I
         const double fro2 = wave_sum(wgt * W * W);
-        sigma = 1.5 * sqrt(fro2) + 1e-300;
+        sigma = 1.5 * cvx::sqrt_fast(fro2) + 1e-300;
         {
             const double g = W + (is_diag ? sigma : 0.0);
             L[L_G + ei * 10 + ej] = g;
@@ -699,7 +749,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
         cold = false;
         CVXW_PH(PH_JACOBI);
         // ---- Wp = sum_{lam > 0} lam v v^T, from (g, w g) with w = lam / lam'^2
-        const double lpa = sqrt(al), lpb = sqrt(be);
+        const double lpa = cvx::sqrt_fast(al), lpb = cvx::sqrt_fast(be);
         const double lama = lpa - sigma, lamb = lpb - sigma;
         const double wa = lama > 0 ? lama * cvx::rcp(al) : 0.0, wb = lamb > 0 ? lamb * cvx::rcp(be) : 0.0;
         if (o.warm_start) {
@@ -743,11 +793,11 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
             }
             int rank = 0;
 #pragma unroll
-            for (int s = 0; s < 10; ++s) rank += (sqrt(L[L_M + s]) - sigma) > 1e-3;
+            for (int s = 0; s < 10; ++s) rank += L[L_M + s] > (sigma + 1e-3) * (sigma + 1e-3); // eigenvalue > 1e-3, no roots
             // candidates (see cvx::solve_sdp): the top eigenvector; from iteration 6 on, with a comparable
             // second eigenvalue, the two poses of the top-2 eigenspace in closed form (cvx::twin_candidates)
-            const double l1 = sqrt(best) - sigma, l2 = sqrt(second) - sigma;
-            const bool two = it >= 6 && l2 > 0.5 * l1;
+            bool two = false;
+            if (it >= 6) two = (cvx::sqrt_fast(second) - sigma) > 0.5 * (cvx::sqrt_fast(best) - sigma); // wave-uniform
             double Rc[9], pobj = 0, zSz = 0;
             {   // unit eigenvectors saved to LDS first: the certificate reuses the L_Y region
                 const double il1 = cvx::rsqrt_(best), il2 = cvx::rsqrt_(second);
@@ -792,7 +842,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
                 // z+- = (c1 +- d1) v1 + (c2 +- d2) v2: last entry 1, squared norm 4
                 const double ta = L[L_V + 9], tb = L[L_V + 19], n2 = ta * ta + tb * tb;
                 const double inv = cvx::rcp(n2), rn = cvx::rsqrt_(n2), rad = 4.0 - inv;
-                const double sq = rad > 0 ? sqrt(rad) : 0.0;
+                const double sq = rad > 0 ? cvx::sqrt_fast(rad) : 0.0;
                 const double c1 = ta * inv, c2 = tb * inv, d1 = -tb * rn * sq, d2 = ta * rn * sq;
                 double zc[10], fp, fm;
 #pragma unroll
@@ -904,7 +954,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
             const double Xn = coop_proj(L, roles, 2.0 * Wp - W - irho * Qs, 1.0);
             const double dd = Xn - Wp;
             W += o.alpha * dd;
-            fp_res = sqrt(wave_sum(wgt * dd * dd));
+            fp_res = cvx::sqrt_fast(wave_sum(wgt * dd * dd));
             if (!(fp_res == fp_res)) { status = cvx::ST_NONFINITE; done = true; }
             CVXW_SYNC();
             CVXW_PH(PH_UPDATE);

@@ -36,10 +36,12 @@ enum {
 
 /* kernel layouts (A/B switch; all produce the same results) */
 enum {
-    CVXPNPL_LAYOUT_AUTO = 0, /* wave below 12288 problems per launch, lane (hybrid) from there */
+    CVXPNPL_LAYOUT_AUTO = 0, /* by launch size: wave below 12288 problems, quad below 40960, lane (hybrid) from there */
     CVXPNPL_LAYOUT_LANE = 1, /* one problem per lane, 64 per wavefront, for the first lane_iters iterations;
                                 unfinished problems are then resumed one per wavefront (hybrid schedule) */
-    CVXPNPL_LAYOUT_WAVE = 2  /* one problem per wavefront (cooperative lanes) */
+    CVXPNPL_LAYOUT_WAVE = 2, /* one problem per wavefront (cooperative lanes) */
+    CVXPNPL_LAYOUT_QUAD = 3  /* one problem per DPP row: 16 lanes, four per wavefront, for the first lane_iters
+                                iterations; the unfinished ones are resumed one per wavefront */
 };
 
 typedef struct {
@@ -55,8 +57,9 @@ typedef struct {
     int32_t warm_start; /* 1 (default): each eigen-solve starts from the previous iteration's eigenvectors */
     double rho_tail;    /* penalty from iteration tail_from on (dual rescaled at the switch), default 0.05 */
     int32_t tail_from;  /* default 3; <= 0 never */
-    int32_t lane_iters; /* lane layout: iterations before unfinished problems are handed to one wavefront
-                           each (hybrid schedule); default -1 = by batch size (3, 4 or 5); 0 = never */
+    int32_t lane_iters; /* lane and quad layouts: iterations before unfinished problems are handed to one
+                           wavefront each (hybrid schedule); default -1 = lane: by batch size (3, 4 or 5),
+                           quad: 6; 0 = never (lane), wave layout instead (quad) */
     int32_t layout;    /* CVXPNPL_LAYOUT_* */
 } cvxpnpl_opts_t;
 

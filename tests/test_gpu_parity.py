@@ -38,7 +38,7 @@ def _solve(gpu, d, n_p, n_l, **kw):
 
 
 CASES = [(10, 0, 0.0, 256), (10, 0, 2.0, 256), (5, 5, 0.0, 128), (5, 5, 1.0, 128), (0, 6, 1.0, 64), (6, 0, 1.0, 64), (4, 0, 1.0, 64)]
-LAYOUTS = {"lane": 1, "wave": 2}  # CVXPNPL_LAYOUT_*
+LAYOUTS = {"lane": 1, "wave": 2, "quad": 3}  # CVXPNPL_LAYOUT_*
 
 
 @pytest.mark.parametrize("layout", sorted(LAYOUTS))
@@ -86,30 +86,31 @@ def test_hip_equals_host_build_of_device_algorithm(gpu):
 
 
 def test_hybrid_lane_then_wave_schedule(gpu):
-    """Lane layout with hand-off: problems unfinished after `lane_iters` iterations are resumed one
+    """Lane and quad layouts with hand-off: problems unfinished after `lane_iters` iterations are resumed one
     per wavefront.  Forcing the hand-off early (lane_iters=3, 4) must not change any result."""
     from cvxpnpl_amd import synth
 
     d = synth.make_pnpl(3000, 5, 5, 1.0, seed=31)
     ref = _solve(gpu, d, 5, 5, layout=LAYOUTS["wave"])
-    for li in (3, 4, 10, 0):
-        r = _solve(gpu, d, 5, 5, layout=LAYOUTS["lane"], lane_iters=li)
-        assert (r["status"] == ref["status"]).mean() > 0.995, li
+    for layout, li in (("lane", 3), ("lane", 4), ("lane", 10), ("lane", 0), ("quad", 3), ("quad", 6), ("quad", 12)):
+        r = _solve(gpu, d, 5, 5, layout=LAYOUTS[layout], lane_iters=li)
+        assert (r["status"] == ref["status"]).mean() > 0.995, (layout, li)
         both = (r["status"] == 0) & (ref["status"] == 0)
         assert both.mean() > 0.99
         # two certified answers agree to the certificate's resolution: the cost gap is <= 1e-9, which on
         # an ill-conditioned (flat) problem leaves ~1e-9 rad of play; typical agreement is 1e-16
-        assert synth.geodesic(r["R"], ref["R"])[both].max() < 1e-7, li
+        assert synth.geodesic(r["R"], ref["R"])[both].max() < 1e-7, (layout, li)
         assert np.abs(r["t"] - ref["t"])[both].max() < 1e-7
         assert np.median(synth.geodesic(r["R"], ref["R"])[both]) < 1e-14
         assert np.abs(r["iters"][both] - ref["iters"][both]).mean() < 0.5
     # minimal problems: many hand-offs, uncertifiable ones included
     d4 = synth.make_pnp(2000, 4, 1.0, seed=9)
     a = _solve(gpu, d4, 4, 0, layout=LAYOUTS["wave"], max_iters=300)
-    b = _solve(gpu, d4, 4, 0, layout=LAYOUTS["lane"], lane_iters=6, max_iters=300)
-    assert (a["status"] == b["status"]).mean() > 0.97
-    both = (a["status"] == 0) & (b["status"] == 0)
-    assert synth.geodesic(a["R"], b["R"])[both].max() < 1e-7
+    for layout in ("lane", "quad"):
+        b = _solve(gpu, d4, 4, 0, layout=LAYOUTS[layout], lane_iters=6, max_iters=300)
+        assert (a["status"] == b["status"]).mean() > 0.97, layout
+        both = (a["status"] == 0) & (b["status"] == 0)
+        assert synth.geodesic(a["R"], b["R"])[both].max() < 1e-7, layout
 
 
 def test_examples_known_answer_single_problem_api(gpu, golden):
@@ -280,7 +281,7 @@ def test_planar_scene_returns_both_poses_through_dropin_api(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("layout", [1, 2])
+@pytest.mark.parametrize("layout", [1, 2, 3])
 def test_planar_batch_is_certified_two_fold_in_few_iterations(gpu, orc, layout):
     """Planar scenes are exactly two-fold ambiguous for the relaxation (R and R diag(-1,-1,1) have the
     same cost), so the solution is rank 2 (cvxpnpl.py:509-545).  The parity-even dual correction
