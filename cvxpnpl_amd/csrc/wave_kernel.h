@@ -215,38 +215,22 @@ constexpr int C_ROW = L_EX + 190;   // 12   pivot row (+ rhs entry) of the elimi
 constexpr int C_LAM = L_EX + 202;   // 10   multipliers of the dual correction
 constexpr int C_SF = L_G;           // 100  full 10x10 S
 
-// In-place LDL^T elimination of the SPD matrix held one entry (a <= b) per lane, through
-// LDS row broadcasts; optionally carries a right-hand side (lanes 0..9) along.  Returns
-// the smallest pivot.  On exit the entry lanes hold U = D L^T.
-template <bool RHS>
-__device__ __forceinline__ double coop_ldl(double *L, const Roles &r, double &Me, double &y)
+// In-place LDL^T elimination of the symmetric matrix held one entry (a <= b) per lane, through LDS row
+// broadcasts.  Returns the smallest pivot met; stops at the first non-positive one (the matrix is then
+// not positive definite and the caller rejects the certificate -- wave-uniform, the pivot is broadcast).
+__device__ __forceinline__ double coop_ldl(double *L, const Roles &r, double &Me)
 {
     double minp = 1e300;
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
         if (r.ei == k && r.lane < 55) L[C_ROW + r.ej] = Me;
-        if (RHS && r.lane == k) L[C_ROW + 10] = y;
         CVXW_SYNC();
         const double d = L[C_ROW + k];
-        double id;
-        if (RHS) {
-            // semidefinite but consistent system (cvx::chol_solve10): a null pivot means lam_k = 0
-            const bool skip = !(d > 1e-10);
-            const double dm = skip ? (d > -1e-8 ? 1.0 : -1.0) : d;
-            minp = dm < minp ? dm : minp;
-            id = skip ? 0.0 : fast_rcp(d);
-            if (skip && r.ei == k && r.ej == k) Me = 0.0;
-        } else {
-            minp = d < minp ? d : minp;
-            id = fast_rcp(d);
-        }
+        minp = d < minp ? d : minp;
+        if (!(d > 0)) { CVXW_SYNC(); break; }
+        const double id = fast_rcp(d);
         const double ra = L[C_ROW + r.ei], rb = L[C_ROW + r.ej];
         if (r.ei > k) Me -= ra * id * rb;
-        if (RHS) {
-            const int a = r.lane < 10 ? r.lane : 0;
-            const double rv = L[C_ROW + a] * id * L[C_ROW + 10];
-            if (r.lane < 10 && r.lane > k) y -= rv;
-        }
         CVXW_SYNC();
     }
     return minp;
@@ -458,9 +442,9 @@ __device__ __forceinline__ bool coop_dual(double *L, const Roles &r, double Qs, 
     }
     CVXW_SYNC();
     // ---- LDL^T of S2 + delta I: all pivots positive  <=>  lambda_min(S2) > -delta
-    double Se = S + (r.is_diag ? delta : 0.0), dummy = 0.0;
+    double Se = S + (r.is_diag ? delta : 0.0);
     CVXW_PHR(PH_D_RANGE);
-    const double minp = coop_ldl<false>(L, r, Se, dummy);
+    const double minp = coop_ldl(L, r, Se);
     CVXW_PHR(PH_D_LDL2);
     return (minp > 0) && (res < 1e-10) && (d0 > 0) && (pobj == pobj);
 }
