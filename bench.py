@@ -227,6 +227,12 @@ def main():
         if pmc:
             out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
             out["roofline"]["traffic_source"] = pmc["source"]
+            if pmc.get("valu_insts_per_launch"):
+                # what actually binds: VALU issue.  One wave64 VALU instruction occupies a SIMD for 4 cycles
+                # (fp64 FMA is full rate on gfx950); 256 CUs x 4 SIMDs at the 2.4 GHz peak engine clock.
+                n = pmc["valu_insts_per_launch"]
+                out["roofline"]["valu"] = {"insts_per_launch": n, "insts_per_pose": n / batch,
+                                           "issue_frac": n * 4.0 / (1024 * 2.4e9 * mean_launch_s), "source": "SQ_INSTS_VALU, same PMC passes"}
     if overlapped:
         out["overlapped"] = overlapped
     if sigma == 0.0:

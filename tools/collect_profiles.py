@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/<tag>/ (tools/profile_round.sh) into profiles/<tag>/ and profiles/pmc_traffic.json."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles", tag)
+os.makedirs(dst, exist_ok=True)
+WORKLOAD_KEY = {"default": "pnp_n10_10k:10000", "quad_24k": "pnp_n10_10k:24000", "hybrid_125k": "pnp_n10_125k:125000"}
+
+
+def counters(run):
+    """per-kernel means over launches of every counter in gpurun_out/<tag>/<run>/pmc_*"""
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    meta = {}
+    for f in glob.glob(os.path.join(src, run, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        per = collections.defaultdict(lambda: collections.defaultdict(float))
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            if "rocclr" in k:
+                continue
+            per[(k, r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
+            meta[k] = {x: r[x] for x in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count") if x in r}
+        for (k, _), d in per.items():
+            for c, v in d.items():
+                acc[k][c].append(v)
+    out = {}
+    for k, d in acc.items():
+        out[k] = {c: {"launches": len(v), "mean_per_launch": sum(v) / len(v), "min": min(v), "max": max(v)} for c, v in sorted(d.items())}
+        out[k]["_kernel"] = meta.get(k, {})
+    return out
+
+
+traffic = {}
+for run in ("default", "quad_24k", "hybrid_125k"):
+    if not os.path.isdir(os.path.join(src, run)):
+        continue
+    os.makedirs(os.path.join(dst, run), exist_ok=True)
+    for f in glob.glob(os.path.join(src, run, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(dst, run, "kernel_stats.csv"))
+    c = counters(run)
+    json.dump(c, open(os.path.join(dst, run, "pmc_summary.json"), "w"), indent=1)
+    fetch = sum(v.get("FETCH_SIZE", {}).get("mean_per_launch", 0.0) for v in c.values()) * 1024
+    write = sum(v.get("WRITE_SIZE", {}).get("mean_per_launch", 0.0) for v in c.values()) * 1024
+    tot = lambda name: sum(v.get(name, {}).get("mean_per_launch", 0.0) for v in c.values())  # noqa: E731
+    traffic[WORKLOAD_KEY[run]] = {
+        "hbm_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
+        "valu_insts_per_launch": tot("SQ_INSTS_VALU"), "salu_insts_per_launch": tot("SQ_INSTS_SALU"), "lds_insts_per_launch": tot("SQ_INSTS_LDS"),
+        "source": f"profiles/{tag}/{run}/pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KB*1024, "
+                  "summed over the kernels of one step, FETCH not doubled (narrow accesses)"}
+for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(src, "*.jsonl")) + glob.glob(os.path.join(src, "layout_sweep.txt")):
+    shutil.copy(f, dst)
+json.dump(traffic, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(traffic, indent=1))
