@@ -27,12 +27,11 @@ struct BatchArgs {
 };
 
 // ---------------------------------------------------------------------------------------
-// lane-per-problem: each lane owns one problem end to end (assembly -> ADMM -> certificate
-// -> pose); 64 independent problems per wavefront, no cross-lane traffic, no LDS.
-// handoff_at > 0: hybrid schedule -- a lane that is not finished after handoff_at iterations parks
-// its iterate in ws[b] and queues b for resume_wave_kernel, so that one slow problem cannot hold
-// the other 63 lanes (and the whole launch) for hundreds of lane-serial iterations.
-template <bool TWIN>
+// lane-per-problem: each lane owns one problem (assembly -> ADMM -> certificate -> pose) for the first
+// handoff_at (1..5) iterations; 64 independent problems per wavefront, no cross-lane traffic, no LDS.
+// Hybrid schedule: a lane that is not finished by then parks its iterate in ws[b] and queues b for
+// resume_wave_kernel, so that one slow problem cannot hold the other 63 lanes (and the whole launch)
+// for hundreds of lane-serial iterations.
 __global__ void __launch_bounds__(64) solve_lane_kernel(BatchArgs a, cvx::Opts o, int handoff_at, int32_t *queue, double *ws)
 {
     int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -40,7 +39,8 @@ __global__ void __launch_bounds__(64) solve_lane_kernel(BatchArgs a, cvx::Opts o
     cvx::ProblemView pv = cvx::make_view(b, a.n_p, a.p2, a.p3, a.n_l, a.l2, a.l3, a.K, a.K_per_problem);
     cvx::Solution sol;
     double Z[55];
-    cvx::solve_problem<TWIN>(pv, o, sol, a.Z ? Z : nullptr, handoff_at, handoff_at > 0 ? ws + b * 56 : nullptr);
+    // TWIN = false: the hand-off comes before iteration 6, where the twin-candidate logic would start
+    cvx::solve_problem<false>(pv, o, sol, a.Z ? Z : nullptr, handoff_at, ws + b * 56);
     if (sol.status == -1) {
         const int q = atomicAdd(&queue[0], 1);
         queue[1 + q] = (int32_t)b;
@@ -170,7 +170,7 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
     w.p2 = d_pts_2d; w.p3 = d_pts_3d; w.l2 = d_line_2d; w.l3 = d_line_3d; w.K = d_K;
     w.R = d_R; w.t = d_t; w.cost = d_cost; w.Z = d_Z; w.status = d_status; w.iters = d_iters; w.work = d_work;
     int quad_iters = opts ? opts->lane_iters : -1;
-    if (quad_iters < 0) quad_iters = 6;
+    if (quad_iters <= 0) quad_iters = 6;
     if (layout == CVXPNPL_LAYOUT_QUAD && !(quad_iters >= 1 && o.max_iters > quad_iters)) layout = CVXPNPL_LAYOUT_WAVE;
     if (layout == CVXPNPL_LAYOUT_QUAD) {
         // four problems per wavefront for the first quad_iters iterations, survivors resumed one per wavefront
@@ -194,8 +194,12 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
         // the lanes hand over early (3 iterations: one check) and the waves do more; big launches keep the
         // cheap lane layout for 5 iterations.  Measured optimum: 10 k -> 3, 16 k -> 4, >= 32 k -> 5.
         int lane_iters = opts ? opts->lane_iters : -1;
-        if (lane_iters < 0) lane_iters = batch < 12288 ? 3 : (batch < 24576 ? 4 : 5);
-        if (lane_iters > 0 && o.max_iters > lane_iters) {
+        if (lane_iters <= 0) lane_iters = batch < 12288 ? 3 : (batch < 24576 ? 4 : 5);
+        // The lane phase never runs past 5 iterations: from the sixth on the few problems still open are the
+        // slow / ambiguous ones (twin candidates, tails), which belong to the wave-per-problem kernel -- one of
+        // them would hold 63 idle lanes, so the lane kernel is built without that logic.
+        if (lane_iters > 5) lane_iters = 5;
+        if (o.max_iters > lane_iters) {
             // hybrid: lanes for the first lane_iters iterations, survivors resumed one per wavefront
             const size_t qbytes = ((size_t)(batch + 1) * sizeof(int32_t) + 255) & ~(size_t)255;
             char *wsp = (char *)get_workspace(qbytes + (size_t)batch * 56 * sizeof(double), stream);
@@ -204,12 +208,13 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
             double *ws = (double *)(wsp + qbytes);
             hipError_t me = hipMemsetAsync(queue, 0, sizeof(int32_t), s);
             if (me != hipSuccess) return set_err("hipMemsetAsync", me);
-            if (lane_iters < 6) hipLaunchKernelGGL(solve_lane_kernel<false>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, queue, ws);
-            else hipLaunchKernelGGL(solve_lane_kernel<true>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, queue, ws);
+            hipLaunchKernelGGL(solve_lane_kernel, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, queue, ws);
             const int64_t rgrid = batch < 8192 ? batch : 8192;
             hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64 * cvxw::WPB), 0, s, w, o, queue, ws);
         } else {
-            hipLaunchKernelGGL(solve_lane_kernel<true>, dim3((unsigned)grid), dim3(block), 0, s, a, o, 0, nullptr, nullptr);
+            // fewer iterations allowed than the lane phase would run: the wave kernel does the whole solve
+            int64_t wgrid = (batch + cvxw::WPB - 1) / cvxw::WPB;
+            hipLaunchKernelGGL(cvxw::solve_wave_kernel, dim3((unsigned)wgrid), dim3(64 * cvxw::WPB), 0, s, w, o);
         }
     }
     hipError_t e = hipGetLastError();

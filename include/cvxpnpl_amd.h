@@ -58,8 +58,8 @@ typedef struct {
     double rho_tail;    /* penalty from iteration tail_from on (dual rescaled at the switch), default 0.05 */
     int32_t tail_from;  /* default 3; <= 0 never */
     int32_t lane_iters; /* lane and quad layouts: iterations before unfinished problems are handed to one
-                           wavefront each (hybrid schedule); default -1 = lane: by batch size (3, 4 or 5),
-                           quad: 6; 0 = never (lane), wave layout instead (quad) */
+                           wavefront each (hybrid schedule).  <= 0: default (lane: 3, 4 or 5 by batch size;
+                           quad: 6).  The lane phase is capped at 5 iterations. */
     int32_t layout;    /* CVXPNPL_LAYOUT_* */
 } cvxpnpl_opts_t;
 
