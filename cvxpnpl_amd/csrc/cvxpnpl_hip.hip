@@ -34,13 +34,15 @@ struct BatchArgs {
 // for hundreds of lane-serial iterations.
 __global__ void __launch_bounds__(64) solve_lane_kernel(BatchArgs a, cvx::Opts o, int handoff_at, int32_t *queue, double *ws)
 {
+    __shared__ double lds_const[72 * 64];
     int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= a.batch) return;
     cvx::ProblemView pv = cvx::make_view(b, a.n_p, a.p2, a.p3, a.n_l, a.l2, a.l3, a.K, a.K_per_problem);
     cvx::Solution sol;
     double Z[55];
-    // TWIN = false: the hand-off comes before iteration 6, where the twin-candidate logic would start
-    cvx::solve_problem<false>(pv, o, sol, a.Z ? Z : nullptr, handoff_at, ws + b * 56);
+    // TWIN = false: the hand-off comes before iteration 6, where the twin-candidate logic would start.
+    // The cost matrix and the translation map (72 doubles) live in this lane's LDS column, not in registers.
+    cvx::solve_problem<false, cvx::LdsStore>(pv, o, sol, a.Z ? Z : nullptr, handoff_at, ws + b * 56, cvx::LdsStore{lds_const + threadIdx.x});
     if (sol.status == -1) {
         const int q = atomicAdd(&queue[0], 1);
         queue[1 + q] = (int32_t)b;

@@ -42,9 +42,9 @@ CVX_HD bool assemble(const ProblemView &v, double *B, double *Q9)
     return ok && (det == det) && det != 0.0;
 }
 
-template <bool TWIN = true>
+template <bool TWIN = true, class ST = RegStore>
 CVX_HD void solve_problem(const ProblemView &v, const Opts &o, Solution &sol, double *Zout, int handoff_at = 0,
-                          double *handoff = nullptr)
+                          double *handoff = nullptr, ST st = ST())
 {
     double B[27], Q9[45];
     bool ok = assemble(v, B, Q9);
@@ -52,7 +52,7 @@ CVX_HD void solve_problem(const ProblemView &v, const Opts &o, Solution &sol, do
         CVX_UNROLL for (int i = 0; i < 45; ++i) Q9[i] = NAN;
         CVX_UNROLL for (int i = 0; i < 27; ++i) B[i] = NAN;
     }
-    solve_sdp<TWIN>(Q9, B, o, sol, Zout, handoff_at, handoff);
+    solve_sdp<TWIN, ST>(Q9, B, o, sol, Zout, handoff_at, handoff, st);
     if (!ok) { CVX_UNROLL for (int i = 0; i < 3; ++i) sol.t[i] = NAN; }
 }
 

@@ -32,9 +32,11 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define CVX_HD __host__ __device__ __forceinline__
+#define CVX_HDM __host__ __device__ __forceinline__ /* member functions */
 #define CVX_UNROLL _Pragma("unroll")
 #else
 #define CVX_HD static inline
+#define CVX_HDM inline
 #define CVX_UNROLL
 #endif
 
@@ -517,7 +519,31 @@ CVX_HD void eig_pospart(const Eig &e, double *Wp)
 // ---------------------------------------------------------------------------------------
 // SO(3) Newton polish of f(R) = r^T Q r, r = vec_colmajor(R)
 
-CVX_HD void q9_mul(const double *Q9, const double *x, double *y)
+// Where the per-problem constants (normalised cost Qs, translation map B) live during a scalar solve:
+// plain arrays (host build, default) or -- lane-per-problem kernel -- this lane's column of an LDS block,
+// element k of lane l at base[64 k + l] (conflict-free, and 144 registers less state per lane).  Every
+// routine below takes the cost as "anything indexable": a pointer or a StridedView.
+struct StridedView {
+    const double *p;
+    CVX_HDM double operator[](int k) const { return p[k * 64]; }
+};
+struct RegStore {
+    double q[45], b[27];
+    CVX_HDM void setQ(int k, double v) { q[k] = v; }
+    CVX_HDM const double *Q() const { return q; }
+    CVX_HDM void setB(int k, double v) { b[k] = v; }
+    CVX_HDM double B(int k) const { return b[k]; }
+};
+struct LdsStore {
+    double *base; // &block[lane]; 72 * 64 doubles per 64-lane block
+    CVX_HDM void setQ(int k, double v) { base[k * 64] = v; }
+    CVX_HDM StridedView Q() const { return StridedView{base}; }
+    CVX_HDM void setB(int k, double v) { base[(45 + k) * 64] = v; }
+    CVX_HDM double B(int k) const { return base[(45 + k) * 64]; }
+};
+
+template <class QV>
+CVX_HD void q9_mul(QV Q9, const double *x, double *y)
 {
     CVX_UNROLL for (int i = 0; i < 9; ++i) {
         double acc = 0;
@@ -527,7 +553,8 @@ CVX_HD void q9_mul(const double *Q9, const double *x, double *y)
 }
 
 // R is row-major 3x3; r[3j+i] = R[i][j]
-CVX_HD void so3_newton(const double *Q9, double *R, int iters)
+template <class QV>
+CVX_HD void so3_newton(QV Q9, double *R, int iters)
 {
     for (int it = 0; it < iters; ++it) {
         double r[9], Qr[9];
@@ -752,7 +779,8 @@ CVX_HD double round_candidate(const double *v, double *R)
 }
 
 // Newton polish of r^T Qs r on SO(3) from R; pobj = r^T Qs r
-CVX_HD void polish_rotation(const double *Qs, double *R, double &pobj)
+template <class QV>
+CVX_HD void polish_rotation(QV Qs, double *R, double &pobj)
 {
     so3_newton(Qs, R, 6);
     double z[9], Qz[9];
@@ -762,7 +790,8 @@ CVX_HD void polish_rotation(const double *Qs, double *R, double &pobj)
     CVX_UNROLL for (int i = 0; i < 9; ++i) pobj += z[i] * Qz[i];
 }
 
-CVX_HD double polish_candidate(const double *Qs, const double *v, double *R, double &pobj)
+template <class QV>
+CVX_HD double polish_candidate(QV Qs, const double *v, double *R, double &pobj)
 {
     const double d0 = round_candidate(v, R);
     polish_rotation(Qs, R, pobj);
@@ -790,8 +819,8 @@ CVX_HD void twin_candidates(const double *v1, const double *v2, double *zp, doub
 // SYMM: recognise planar scenes (Qs blind to the third column of R), whose relaxation is invariant
 // under D = diag(-I6, I4), and build the correction in the D-even subspace so that it annihilates
 // both twins z and D z at once.
-template <bool SYMM = true>
-CVX_HD void dual_certificate(const double *Qs, const double *W, const double *Wp, double rho, double delta, double d0, Cert &c)
+template <bool SYMM = true, class QV = const double *>
+CVX_HD void dual_certificate(QV Qs, const double *W, const double *Wp, double rho, double delta, double d0, Cert &c)
 {
     c.ok = false;
     double z[10];
@@ -824,8 +853,8 @@ CVX_HD void dual_certificate(const double *Qs, const double *W, const double *Wp
 
 // Qs: 45 packed, trace-normalised.  W, Wp: current ADMM iterate and its PSD part.
 // v: candidate (multiple of [r; 1]), e.g. the unit top eigenvector of Wp.  delta: PSD slack.
-template <bool SYMM = true>
-CVX_HD void certify(const double *Qs, const double *W, const double *Wp, const double *v, double rho, double delta, Cert &c)
+template <bool SYMM = true, class QV = const double *>
+CVX_HD void certify(QV Qs, const double *W, const double *Wp, const double *v, double rho, double delta, Cert &c)
 {
     const double d0 = polish_candidate(Qs, v, c.R, c.pobj);
     dual_certificate<SYMM>(Qs, W, Wp, rho, delta, d0, c);
@@ -853,7 +882,8 @@ struct Solution {
 // v is the unit top eigenvector of Z, rank = #eig(Z) > 1e-3.  R = U V^T of the rank-1
 // ratio (no determinant correction, cvxpnpl.py:510-511); rank > 1 is flagged for the host
 // multi-solution recovery.
-CVX_HD void fallback_pose(const double *Qs, double tr, const double *v, int rank, Solution &sol)
+template <class QV>
+CVX_HD void fallback_pose(QV Qs, double tr, const double *v, int rank, Solution &sol)
 {
     sol.rank = rank;
     double M0[9], iv = 1.0 / v[9];
@@ -880,17 +910,18 @@ CVX_HD void fallback_pose(const double *Qs, double tr, const double *v, int rank
 // schedule: the wave-per-problem kernel resumes it).
 // TWIN = false compiles the two-fold-ambiguity branch out (the lane phase of the hybrid schedule hands
 // off before iteration 6, where that branch starts, and the extra live state costs it registers).
-template <bool TWIN = true>
+template <bool TWIN = true, class ST = RegStore>
 CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution &sol, double *Zout, int handoff_at = 0,
-                      double *handoff = nullptr)
+                      double *handoff = nullptr, ST st = ST())
 {
     double tr = 0;
     CVX_UNROLL for (int i = 0; i < 9; ++i) tr += Q9[qidx(i, i)];
     sol.sweeps = 0; sol.iters = 0; sol.rank = 0;
     bool finite = (tr == tr) && (tr > 0) && (tr < 1e300);
-    double Qs[45];
     double itr = finite ? 1.0 / tr : 0.0;
-    CVX_UNROLL for (int i = 0; i < 45; ++i) { Qs[i] = Q9[i] * itr; finite &= (Qs[i] == Qs[i]); }
+    CVX_UNROLL for (int i = 0; i < 45; ++i) { const double q = Q9[i] * itr; st.setQ(i, q); finite &= (q == q); }
+    CVX_UNROLL for (int i = 0; i < 27; ++i) st.setB(i, B[i]);
+    const auto Qs = st.Q();
     if (!finite) {
         CVX_UNROLL for (int i = 0; i < 9; ++i) sol.R[i] = NAN;
         CVX_UNROLL for (int i = 0; i < 3; ++i) sol.t[i] = NAN;
@@ -1099,7 +1130,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
         CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) r[3 * j + i] = sol.R[i * 3 + j];
         CVX_UNROLL for (int i = 0; i < 3; ++i) {
             double acc = 0;
-            CVX_UNROLL for (int j = 0; j < 9; ++j) acc += B[i * 9 + j] * r[j];
+            CVX_UNROLL for (int j = 0; j < 9; ++j) acc += st.B(i * 9 + j) * r[j];
             sol.t[i] = -acc;
         }
     }
