@@ -502,15 +502,19 @@ __global__ void __launch_bounds__(64, 2) solve_quad_kernel(WaveArgs a, cvx::Opts
             double vloc[10];
 #pragma unroll
             for (int i = 0; i < 10; ++i) vloc[i] = L[Q_M + 22 + i];
-            double Rc[9], pobj = 0.0;
-            const double d0 = cvxw::coop_round(vloc, Rc);
-            double dist2 = 0.0;
+            double Rc[9], pobj = 0.0, d0;
+            bool reuse;
+            {   // does the candidate round to the pose the previous check already polished?  (cvx::rounds_to)
+                double Rp[9];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) { const double dd = Rc[i] - L[Q_M + 12 + i]; dist2 += dd * dd; }
-            const bool reuse = have_prev && dist2 < 0.05;
+                for (int i = 0; i < 9; ++i) Rp[i] = L[Q_M + 12 + i];
+                reuse = have_prev && cvx::rounds_to(vloc, Rp, d0);
+            }
             // the four problems polish together; when none needs it (done, or the rounded candidate is the pose
             // the previous check already polished) the Newton iterations are skipped altogether
             if (__any(!done && !reuse)) {
+                // (problems whose candidate would be reused polish along: same result, no divergence)
+                d0 = cvxw::coop_round(vloc, Rc);
                 // ---- Newton on SO(3) for f(R) = r^T Qs r (cvx::so3_newton)
                 int xsrc[3];
                 double xsgn[3];

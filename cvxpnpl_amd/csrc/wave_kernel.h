@@ -798,17 +798,18 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
 #pragma unroll
                 for (int i = 0; i < 10; ++i) vloc[i] = L[L_V + i];
                 // repeated checks mostly polish to the pose the previous check already had (see
-                // cvx::solve_sdp): reuse it when the rounded candidate is within 0.22 of that rotation
-                const double d0 = coop_round(vloc, Rc);
-                double dist2 = 0;
+                // cvx::solve_sdp): reuse it when the candidate rounds to that rotation (cvx::rounds_to)
+                double d0, Rp[9];
 #pragma unroll
-                for (int i = 0; i < 9; ++i) { const double dd = Rc[i] - L[L_M + 50 + i]; dist2 += dd * dd; }
+                for (int i = 0; i < 9; ++i) Rp[i] = L[L_M + 50 + i];
+                const bool reuse = have_prev && cvx::rounds_to(vloc, Rp, d0);
                 CVXW_PH(PH_TOPSEL);
-                if (have_prev && dist2 < 0.05) {
+                if (reuse) {
 #pragma unroll
-                    for (int i = 0; i < 9; ++i) Rc[i] = L[L_M + 50 + i];
+                    for (int i = 0; i < 9; ++i) Rc[i] = Rp[i];
                     pobj = fprev;
                 } else {
+                    d0 = coop_round(vloc, Rc);
                     coop_polish(L, roles, Qs, Rc, pobj CVXW_PH_ARG);
                 }
                 CVXW_PH(PH_POLISH);
