@@ -157,16 +157,17 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
     int64_t grid = (batch + block - 1) / block;
     if (grid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }
     int layout = opts ? opts->layout : CVXPNPL_LAYOUT_AUTO;
-    // AUTO, by launch size (measured on one MI355X, M poses/s for wave / quad / lane-hybrid, PnP N = 10):
-    //   5 k: 16.5 / 15.3 / 11.8    10 k: 25.3 / 25.5 / 20.9    16 k: 29.0 / 36.4 / 27.9
-    //   32 k: 31.9 / 45.3 / 42.5   50 k: 32.9 / 50.2 / 54.3    125 k: 37.8 / 59.2 / 67.9
+    // AUTO, by launch size (measured on one MI355X, M poses/s for wave / quad / lane-hybrid, PnP N = 10,
+    // profiles/r01/layout_sweep.txt):
+    //   5 k: 16.2 / 15.1 / 11.8    10 k: 26.0 / 25.2 / 22.4    16 k: 29.2 / 36.1 / 31.1
+    //   24 k: 27.6 / 38.1 / 37.7   32 k: 32.4 / 45.3 / 52.3    125 k: 38.6 / 61.2 / 91.1
     // * below 12288 problems a wavefront per problem: every SIMD gets work and a finished problem frees
     //   its slot at once;
-    // * from there four problems per wavefront (one per DPP row): 2.3x fewer instructions per problem;
-    // * from 40960 the lane-hybrid schedule (64 problems per wavefront for the first lane_iters
+    // * from there four problems per wavefront (one per DPP row): 2.2x fewer instructions per problem;
+    // * from 28672 the lane-hybrid schedule (64 problems per wavefront for the first lane_iters
     //   iterations): fewest instructions, but it needs tens of thousands of problems to fill the chip.
     // The unfinished problems of the quad and lane phases are resumed one per wavefront.
-    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 12288 ? CVXPNPL_LAYOUT_WAVE : (batch < 40960 ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
+    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 12288 ? CVXPNPL_LAYOUT_WAVE : (batch < 28672 ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
     cvxw::WaveArgs w;
     w.batch = batch; w.n_p = n_p; w.n_l = n_l; w.K_per_problem = K_per_problem;
     w.p2 = d_pts_2d; w.p3 = d_pts_3d; w.l2 = d_line_2d; w.l3 = d_line_3d; w.K = d_K;
