@@ -1,7 +1,7 @@
 // wave_kernel.h -- wave-per-problem layout: one gfx950 wavefront owns one SDP.
 //
 // The 64 lanes of a wave cooperate on ONE problem; all state lives in registers and in
-// a private 6 KB LDS slice (no inter-wave communication, no __syncthreads):
+// a private 7 KB LDS slice (no inter-wave communication, no __syncthreads):
 //   * "entry lanes"  e = 0..54   own entry (i <= j) of the symmetric 10x10 iterate W
 //                                (vech order of cvxpnpl.py:346-370) -- affine projection,
 //                                ADMM update, PSD reconstruction are one entry per lane;
@@ -12,8 +12,9 @@
 //                                pairing advances by shifting one value per lane to the
 //                                neighbouring group (lane +-10) through LDS;
 //   * "accumulator lanes" 0..59  own one of the 60 Gram accumulators of the assembly.
-// The certificate (SO(3) Newton polish, dual recovery, LDL^T) is serial 3x3 / 10x10
-// algebra: lane 0 runs the scalar routine of solver_core.h on data gathered through LDS.
+// The certificate is cooperative as well (coop_round / coop_polish / coop_dual): 9x9 matrix-vector
+// products one row per lane, dual fit and correction one entry per lane, the 3x3 algebra and the
+// closed-form multipliers replicated in every lane, one LDL^T with pivot rows broadcast through LDS.
 // Control flow (sweeps, iterations, exit) is wave-uniform: no divergence, per-problem
 // early exit frees the SIMD slot for the next wave.
 #pragma once

@@ -177,13 +177,21 @@ def test_full_size_properties_config2_and_3(gpu):
 def test_per_problem_K_and_int_K(gpu):
     from cvxpnpl_amd import synth
 
-    d = synth.make_pnp(64, 8, 0.0, seed=11)
-    Kb = np.repeat(d["K"][None], 64, 0)
-    r1 = _solve(gpu, d, 8, 0)
+    d = synth.make_pnp(70, 8, 0.0, seed=11)
+    Kb = np.repeat(d["K"][None], 70, 0)
     d2 = dict(d)
     d2["K"] = Kb
-    r2 = _solve(gpu, d2, 8, 0)
-    assert np.array_equal(r1["R"], r2["R"]) and np.array_equal(r1["t"], r2["t"])
+    # a different camera per problem: scale the pixels of problem 5 and its K consistently
+    d3 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in d2.items()}
+    S = np.diag([2.0, 0.5, 1.0])
+    d3["K"][5] = S @ d3["K"][5]
+    d3["pts_2d"][5] = d3["pts_2d"][5] * np.array([2.0, 0.5])
+    for layout in LAYOUTS.values():
+        r1 = _solve(gpu, d, 8, 0, layout=layout)
+        r2 = _solve(gpu, d2, 8, 0, layout=layout)
+        assert np.array_equal(r1["R"], r2["R"]) and np.array_equal(r1["t"], r2["t"])
+        r3 = _solve(gpu, d3, 8, 0, layout=layout)
+        assert (r3["status"] == 0).all() and synth.geodesic(r3["R"], d["R_gt"]).max() < TOL_ROT
 
 
 def test_edge_cases(gpu):
@@ -192,15 +200,18 @@ def test_edge_cases(gpu):
     import cvxpnpl_amd as ca
     from cvxpnpl_amd import synth
 
-    # degenerate: one point -> NaN pose, status 3 (reference: LinAlgError / NaN sentinel)
-    d1 = synth.make_pnp(5, 1, 0.0, seed=1)
-    r = _solve(gpu, d1, 1, 0)
-    assert (r["status"] == 3).all() and np.isnan(r["R"]).all() and np.isnan(r["t"]).all()
-    # NaN in one problem does not leak into its neighbours
-    d2 = synth.make_pnp(130, 6, 0.0, seed=2)
-    d2["pts_2d"][64, 0, 0] = np.nan
-    r = _solve(gpu, d2, 6, 0)
-    assert r["status"][64] == 3 and (np.delete(r["status"], 64) == 0).all()
+    for layout in LAYOUTS.values():
+        # degenerate: one point -> NaN pose, status 3 (reference: LinAlgError / NaN sentinel)
+        d1 = synth.make_pnp(5, 1, 0.0, seed=1)
+        r = _solve(gpu, d1, 1, 0, layout=layout)
+        assert (r["status"] == 3).all() and np.isnan(r["R"]).all() and np.isnan(r["t"]).all()
+        # NaN in one problem does not leak into its neighbours (same wavefront, same DPP row neighbours)
+        d2 = synth.make_pnp(130, 6, 0.0, seed=2)
+        d2["pts_2d"][64, 0, 0] = np.nan
+        d2["pts_3d"][3, 2, 1] = np.inf
+        r = _solve(gpu, d2, 6, 0, layout=layout)
+        assert r["status"][64] == 3 and r["status"][3] == 3 and (np.delete(r["status"], [3, 64]) == 0).all()
+        assert synth.geodesic(np.delete(r["R"], [3, 64], 0), np.delete(d2["R_gt"], [3, 64], 0)).max() < TOL_ROT
     # ragged batch sizes around the wavefront size, and empty batch
     for layout in LAYOUTS.values():
         for b in (1, 3, 4, 5, 63, 64, 65):
