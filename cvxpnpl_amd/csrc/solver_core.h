@@ -879,9 +879,17 @@ CVX_HD void certify(QV Qs, const double *W, const double *Wp, const double *v, d
 // ---------------------------------------------------------------------------------------
 // the solve
 
-// certification attempts: at first_check, then spaced check_every * (1 + it / 16) apart --
-// every iteration while most problems finish, sparser for the slow tail.
-CVX_HD int next_check_after(int it, const Opts &o) { return it + o.check_every * (1 + it / 16); }
+// certification attempts: at first_check, then every iteration up to 10 (99.8 % of N = 10 problems finish by
+// then), then spaced more and more widely, ~sqrt(it).  An attempt costs ~0.4 iterations; for a problem that
+// needs N iterations a spacing s costs 0.4 N / s in failed attempts plus s / 2 iterations of overshoot
+// (minimal at s = sqrt(0.8 N)); starting before 10 delays too many ordinary problems.  The slow tail sets
+// the end of every launch: 1.37 -> 1.24 ms at 125 k problems, neutral at 10 k.
+CVX_HD int next_check_after(int it, const Opts &o)
+{
+    int s = 1 + (it >= 10) + (it >= 16) + (it >= 24) + (it >= 36) + (it >= 54) + (it >= 80) + (it >= 104) + (it >= 128);
+    if (it >= 128) s += (it - 128) / 32;
+    return it + o.check_every * s;
+}
 
 struct Solution {
     double R[9];    // row-major, world -> camera, x_c = R X + t
