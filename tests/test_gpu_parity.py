@@ -37,7 +37,8 @@ def _solve(gpu, d, n_p, n_l, **kw):
     return {k: v.cpu().numpy() for k, v in res.items()}
 
 
-CASES = [(10, 0, 0.0, 256), (10, 0, 2.0, 256), (5, 5, 0.0, 128), (5, 5, 1.0, 128), (0, 6, 1.0, 64), (6, 0, 1.0, 64), (4, 0, 1.0, 64)]
+CASES = [(10, 0, 0.0, 256), (10, 0, 2.0, 256), (5, 5, 0.0, 128), (5, 5, 1.0, 128), (0, 6, 1.0, 64), (6, 0, 1.0, 64), (4, 0, 1.0, 64),
+         (20, 9, 1.0, 67)]  # the last one: 38 records = more than one staging chunk in every layout, ragged batch
 LAYOUTS = {"lane": 1, "wave": 2, "quad": 3}  # CVXPNPL_LAYOUT_*
 
 
