@@ -1,8 +1,9 @@
 // solver_core.h -- the per-problem mathematics of the batched absolute-pose SDP solver.
 //
 // One problem = one 10x10, 22-equality Shor-relaxed SDP (reference: cvxpnpl.py:454-520).
-// Everything here is scalar code over one problem's registers; the HIP kernels in
-// kernels.hip instantiate it once per lane (lane-per-problem layout).  It is also
+// Everything here is scalar code over one problem's registers: cvxpnpl_hip.hip instantiates it once per
+// lane (lane-per-problem layout), wave_kernel.h / quad_kernel.h are cooperative re-statements of the same
+// steps that call the small pieces (inv3, polar3, dual_lambda, rounds_to, ...) directly.  It is also
 // compilable by a host C++ compiler so that tests can step the *device algorithm* on a
 // CPU without a GPU (tests/hostsim) -- that build is test-only and never shipped.
 //
