@@ -28,7 +28,9 @@ extern "C" {
 enum {
     CVXPNPL_CERTIFIED = 0,   /* rank-1 pose, certified globally optimal: 0 <= cost - dobj <= eps [no warning] */
     CVXPNPL_RANK_GT1 = 1,    /* rank(Z) > 1 at the 1e-3 threshold of cvxpnpl.py:502: Z is returned, poses come
-                                from cvxpnpl_recover_multi (cvxpnpl.py:507, 221-343) */
+                                from cvxpnpl_recover_multi (cvxpnpl.py:507, 221-343).  R, t hold ONE of the poses
+                                when the pair was certified (exact two-fold ambiguity, e.g. a planar scene),
+                                otherwise the rank-1 rounding of the top eigenvector, which may be NaN: ask for Z */
     CVXPNPL_UNCERTIFIED = 2, /* rank-1 pose, no certificate by max_iters ["not certifiably optimal", :517-519] */
     CVXPNPL_NONFINITE = 3,   /* degenerate input: NaN pose [NaN sentinel :493-498 / LinAlgError] */
     CVXPNPL_REFLECTION = 4   /* uncertified and det(U V^T) < 0; returned as is, like the reference (:510-511) */
