@@ -74,13 +74,37 @@ __device__ const LaneTab kLaneTab = make_lane_tab();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
     } while (0)
 
+// Reductions over the wavefront without the LDS crossbar: a 4-step DPP butterfly inside each row of 16
+// lanes (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: every lane then holds its row's
+// result), then the four rows are combined through v_readlane.  ~25 VALU instructions and no wait on
+// ds_bpermute round trips (the __shfl_xor version: 12 of them per reduction).
+template <int CTRL>
+__device__ __forceinline__ double wave_dpp(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_lane(double x, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane));
+}
 __device__ __forceinline__ double wave_sum(double x)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
-    return x;
+    x += wave_dpp<0xB1>(x);
+    x += wave_dpp<0x4E>(x);
+    x += wave_dpp<0x141>(x);
+    x += wave_dpp<0x140>(x);
+    return (wave_lane(x, 0) + wave_lane(x, 16)) + (wave_lane(x, 32) + wave_lane(x, 48));
 }
-
+__device__ __forceinline__ double wave_max(double x)
+{
+    x = fmax(x, wave_dpp<0xB1>(x));
+    x = fmax(x, wave_dpp<0x4E>(x));
+    x = fmax(x, wave_dpp<0x141>(x));
+    x = fmax(x, wave_dpp<0x140>(x));
+    return fmax(fmax(wave_lane(x, 0), wave_lane(x, 16)), fmax(wave_lane(x, 32), wave_lane(x, 48)));
+}
 
 // ---------------------------------------------------------------------------------------
 // cooperative certificate: constant tables
@@ -436,9 +460,7 @@ __device__ __forceinline__ bool coop_dual(double *L, const Roles &r, double Qs, 
         const int a = lane < 10 ? lane : 0;
         const double sz = dot10(L2 + (C_SF + a * 10) / 2, L2 + C_XV / 2);
         double m = lane < 10 ? fabs(sz) : 0.0;
-#pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) { const double o2 = __shfl_xor(m, sh, 64); m = o2 > m ? o2 : m; }
-        res = m;
+        res = wave_max(m);
         zSz = wave_sum(lane < 10 ? L[C_XV + a] * sz : 0.0);
     }
     CVXW_SYNC();
