@@ -159,15 +159,15 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
     int layout = opts ? opts->layout : CVXPNPL_LAYOUT_AUTO;
     // AUTO, by launch size (measured on one MI355X, M poses/s for wave / quad / lane-hybrid, PnP N = 10,
     // profiles/r01/layout_sweep.txt):
-    //   5 k: 16.2 / 15.1 / 11.8    10 k: 26.0 / 25.2 / 22.4    16 k: 29.2 / 36.1 / 31.1
-    //   24 k: 27.6 / 38.1 / 37.7   32 k: 32.4 / 45.3 / 52.3    125 k: 38.6 / 61.2 / 91.1
+    //   5 k: 17.9 / 17.4 / 13.3    10 k: 26.9 / 27.7 / 22.6    16 k: 30.8 / 37.4 / 32.4
+    //   24 k: 29.9 / 41.9 / 42.1   32 k: 34.4 / 46.9 / 54.5    125 k: 41.0 / 65.5 / 102.1
     // * below 12288 problems a wavefront per problem: every SIMD gets work and a finished problem frees
-    //   its slot at once;
+    //   its slot at once (at 10 k the quad schedule is level with it; the north-star layout is kept);
     // * from there four problems per wavefront (one per DPP row): 2.2x fewer instructions per problem;
-    // * from 28672 the lane-hybrid schedule (64 problems per wavefront for the first lane_iters
+    // * from 24576 the lane-hybrid schedule (64 problems per wavefront for the first lane_iters
     //   iterations): fewest instructions, but it needs tens of thousands of problems to fill the chip.
     // The unfinished problems of the quad and lane phases are resumed one per wavefront.
-    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 12288 ? CVXPNPL_LAYOUT_WAVE : (batch < 28672 ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
+    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 12288 ? CVXPNPL_LAYOUT_WAVE : (batch < 24576 ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
     cvxw::WaveArgs w;
     w.batch = batch; w.n_p = n_p; w.n_l = n_l; w.K_per_problem = K_per_problem;
     w.p2 = d_pts_2d; w.p3 = d_pts_3d; w.l2 = d_line_2d; w.l3 = d_line_3d; w.K = d_K;
