@@ -769,16 +769,18 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
             L[L_M + 2 * jk] = al;
             L[L_M + 2 * jk + 1] = be;
         }
-        const unsigned long long ma = __ballot(wa > 0), mb = __ballot(wb > 0);
         CVXW_SYNC();
-        Wp = 0.0;
+        {   // all ten slots unconditionally (a slot without weight holds w g = 0): twenty independent LDS reads
+            // in flight instead of a chain of branches, each waiting for its own pair of reads
+            double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-        for (int s = 0; s < 10; ++s) {
-            const bool pos = ((s & 1) ? (mb >> (10 * (s >> 1))) : (ma >> (10 * (s >> 1)))) & 1ull;
-            if (pos) { // wave-uniform
-                const double2 yi = L2[(L_Y + 2 * (s * 10 + ei)) / 2], yj = L2[(L_Y + 2 * (s * 10 + ej)) / 2];
-                Wp += yi.y * yj.x;
+            for (int s = 0; s < 10; s += 2) {
+                const double2 yi0 = L2[(L_Y + 2 * (s * 10 + ei)) / 2], yj0 = L2[(L_Y + 2 * (s * 10 + ej)) / 2];
+                const double2 yi1 = L2[(L_Y + 2 * ((s + 1) * 10 + ei)) / 2], yj1 = L2[(L_Y + 2 * ((s + 1) * 10 + ej)) / 2];
+                acc0 += yi0.y * yj0.x;
+                acc1 += yi1.y * yj1.x;
             }
+            Wp = acc0 + acc1;
         }
         }
         ++it;
