@@ -782,7 +782,7 @@ CVX_HD double round_candidate(const double *v, double *R)
 // Does the rank-1 ratio M0 = mat(v[0..8] / v[9]) round to (almost) the rotation Rp?  The polar factor of M0
 // is Rp exactly when Rp^T M0 is symmetric positive definite; |skew part|^2 < 0.1 (tr / 3)^2 keeps it within
 // ~0.16 rad of Rp -- the test costs 40 flops instead of the polar iteration.  d0 = det(M0).
-CVX_HD bool rounds_to(const double *v, const double *Rp, double &d0)
+CVX_HD bool rounds_to(const double *v, const double *Rp, double &d0, double tol = 0.1)
 {
     const double iv = rcp(v[9]);
     double M0[9];
@@ -792,7 +792,7 @@ CVX_HD bool rounds_to(const double *v, const double *Rp, double &d0)
     CVX_UNROLL for (int a = 0; a < 3; ++a)
         CVX_UNROLL for (int b = 0; b < 3; ++b) S[a * 3 + b] = Rp[0 * 3 + a] * M0[0 * 3 + b] + Rp[1 * 3 + a] * M0[1 * 3 + b] + Rp[2 * 3 + a] * M0[2 * 3 + b];
     const double a01 = S[1] - S[3], a02 = S[2] - S[6], a12 = S[5] - S[7], t = S[0] + S[4] + S[8];
-    return d0 > 0 && t > 0 && (a01 * a01 + a02 * a02 + a12 * a12) < (0.1 / 9.0) * t * t;
+    return d0 > 0 && t > 0 && (a01 * a01 + a02 * a02 + a12 * a12) < (tol / 9.0) * t * t;
 }
 
 // Newton polish of r^T Qs r on SO(3) from R; pobj = r^T Qs r
@@ -813,6 +813,23 @@ CVX_HD double polish_candidate(QV Qs, const double *v, double *R, double &pobj)
     const double d0 = round_candidate(v, R);
     polish_rotation(Qs, R, pobj);
     return d0;
+}
+
+// polish_candidate with memory, for the twin candidates: a candidate that rounds to within ~0.05 rad of the
+// rotation ITS OWN slot polished at the previous check (cvx::rounds_to) takes that rotation and its cost
+// instead of a polar + Newton run.  Near-ambiguous problems -- the slowest of every batch -- polish two
+// twins per check and nearly all of them repeat; the caller forces a fresh polish every third check so that
+// a stale reuse cannot persist.
+template <class QV>
+CVX_HD double polish_or_reuse(QV Qs, const double *z, const double *Rk, double fk, bool have, double *R, double &f)
+{
+    double d0;
+    if (have && rounds_to(z, Rk, d0, 0.01)) {
+        CVX_UNROLL for (int i = 0; i < 9; ++i) R[i] = Rk[i];
+        f = fk;
+        return d0;
+    }
+    return polish_candidate(Qs, z, R, f);
 }
 
 // The two points of span{v1, v2} (orthonormal) with last entry 1 and squared norm 4.  For ANY rank-2
@@ -968,6 +985,9 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
     int it = 0, next_check = o.first_check;
     bool done = false, have_prev = false;
     double Rprev[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, fprev = 0;
+    double Rk[2][9], fk[2] = {0, 0}; // the twins polished by the previous check (cvx::polish_or_reuse)
+    bool hk[2] = {false, false};
+    int tw_reused = 0;
     double fp_res = 1e300;
     while (!done) {
         if (handoff_at > 0 && it >= handoff_at) { // W is the iterate after `it` completed iterations
@@ -1045,8 +1065,14 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
             } else {
                 double zp[10], zm[10], fp;
                 twin_candidates(vt, v2, zp, zm);
-                const double dp = polish_candidate(Qs, zp, c.R, fp);
-                const double dm = polish_candidate(Qs, zm, Rm, fm);
+                const bool may = tw_reused < 2; // every third check polishes afresh
+                const double dp = polish_or_reuse(Qs, zp, Rk[0], fk[0], may && hk[0], c.R, fp);
+                const double dm = polish_or_reuse(Qs, zm, Rk[1], fk[1], may && hk[1], Rm, fm);
+                tw_reused = may ? tw_reused + 1 : 0;
+                CVX_UNROLL for (int i = 0; i < 9; ++i) { Rk[0][i] = c.R[i]; Rk[1][i] = Rm[i]; }
+                fk[0] = fp; fk[1] = fm;
+                hk[0] = dp > 0 && (fp == fp);
+                hk[1] = dm > 0 && (fm == fm);
                 double trc = 0;
                 bool fin = (fp == fp) && (fm == fm);
                 CVX_UNROLL for (int i = 0; i < 9; ++i) { trc += c.R[i] * Rm[i]; fin &= (c.R[i] == c.R[i]) && (Rm[i] == Rm[i]); }

@@ -657,6 +657,9 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
     int it = 0, total_sweeps = 0, next_check = o.first_check;
     bool have_prev = false; // L_M + 50.. holds the rotation polished by the previous check
     double fprev = 0.0;
+    bool have_tp = false, have_tm = false; // L_M + 30.. / 40.. hold the twins polished by the previous twin check
+    double f_tp = 0.0, f_tm = 0.0;
+    int tw_reused = 0;
     bool cold = false; // resumed solves have no previous eigenvectors for their first eigen-solve
     if (resume) {
         W = resume[el];
@@ -857,22 +860,49 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
                 double zc[10], fp, fm;
 #pragma unroll
                 for (int i = 0; i < 10; ++i) zc[i] = (c1 + d1) * L[L_V + i] + (c2 + d2) * L[L_V + 10 + i];
-                const double dp = coop_round(zc, Rc);
-                coop_polish(L, roles, Qs, Rc, fp CVXW_PH_ARG);
+                // each twin may take over the rotation its slot polished at the previous check (cvx::polish_or_reuse:
+                // within ~0.05 rad, a fresh polish every third check) -- near-ambiguous problems are the slowest
+                // of every batch and would otherwise run two polar + Newton polishes per check
+                const bool may = tw_reused < 2;
+                double dp, dm, Rold[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Rold[i] = L[L_M + 30 + i];
+                if (may && have_tp && cvx::rounds_to(zc, Rold, dp, 0.01)) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) Rc[i] = Rold[i];
+                    fp = f_tp;
+                } else {
+                    dp = coop_round(zc, Rc);
+                    coop_polish(L, roles, Qs, Rc, fp CVXW_PH_ARG);
+                }
+                CVXW_SYNC();
                 if (lane == 0) {
 #pragma unroll
                     for (int i = 0; i < 9; ++i) L[L_M + 30 + i] = Rc[i];
                 }
 #pragma unroll
                 for (int i = 0; i < 10; ++i) zc[i] = (c1 - d1) * L[L_V + i] + (c2 - d2) * L[L_V + 10 + i];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Rold[i] = L[L_M + 40 + i];
                 CVXW_SYNC();
-                const double dm = coop_round(zc, Rc);
-                coop_polish(L, roles, Qs, Rc, fm CVXW_PH_ARG);
+                if (may && have_tm && cvx::rounds_to(zc, Rold, dm, 0.01)) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) Rc[i] = Rold[i];
+                    fm = f_tm;
+                } else {
+                    dm = coop_round(zc, Rc);
+                    coop_polish(L, roles, Qs, Rc, fm CVXW_PH_ARG);
+                }
+                CVXW_SYNC();
                 if (lane == 0) {
 #pragma unroll
                     for (int i = 0; i < 9; ++i) L[L_M + 40 + i] = Rc[i];
                 }
                 CVXW_SYNC();
+                tw_reused = may ? tw_reused + 1 : 0;
+                f_tp = fp; f_tm = fm;
+                have_tp = dp > 0 && (fp == fp);
+                have_tm = dm > 0 && (fm == fm);
                 double trc = 0;
                 bool fin = (fp == fp) && (fm == fm);
 #pragma unroll

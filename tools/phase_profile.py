@@ -6,6 +6,7 @@ Uses a separate -DCVXW_PROFILE build of the library (tools/microbench/libcvxpnpl
 the product library carries no instrumentation.
 """
 import argparse
+import numpy as np
 import ctypes as C
 import json
 import os
@@ -36,6 +37,7 @@ def main():
     ap.add_argument("--layout", type=int, default=2)
     ap.add_argument("--n", type=int, default=10)
     ap.add_argument("--sigma", type=float, default=2.0)
+    ap.add_argument("--straggler", type=int, default=-1, help="profile 64 copies of problem IDX of the 125 k bench set (a lone slow problem)")
     args = ap.parse_args()
     if args.build:
         return build()
@@ -45,6 +47,10 @@ def main():
     import cvxpnpl_amd as ca
     L = _lib.lib()
     d = synth.make_pnp(args.batch, args.n, args.sigma, seed=42)
+    if args.straggler >= 0:
+        big = synth.make_pnp(125000, 10, 2.0, seed=42)
+        d = {"pts_2d": np.repeat(big["pts_2d"][args.straggler:args.straggler + 1], 64, 0), "pts_3d": np.repeat(big["pts_3d"][args.straggler:args.straggler + 1], 64, 0), "K": big["K"]}
+        args.batch = 64
     dev = {k: torch.as_tensor(d[k], device="cuda") for k in ("pts_2d", "pts_3d", "K")}
     buf = (C.c_ulonglong * 32)()
     import time
