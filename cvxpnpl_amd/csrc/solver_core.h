@@ -818,7 +818,7 @@ CVX_HD double polish_candidate(QV Qs, const double *v, double *R, double &pobj)
 // polish_candidate with memory, for the twin candidates: a candidate that rounds to within ~0.05 rad of the
 // rotation ITS OWN slot polished at the previous check (cvx::rounds_to) takes that rotation and its cost
 // instead of a polar + Newton run.  Near-ambiguous problems -- the slowest of every batch -- polish two
-// twins per check and nearly all of them repeat; the caller forces a fresh polish every third check so that
+// twins per check and nearly all of them repeat; the caller forces a fresh polish every ninth check so that
 // a stale reuse cannot persist.
 template <class QV>
 CVX_HD double polish_or_reuse(QV Qs, const double *z, const double *Rk, double fk, bool have, double *R, double &f)
@@ -1065,7 +1065,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
             } else {
                 double zp[10], zm[10], fp;
                 twin_candidates(vt, v2, zp, zm);
-                const bool may = tw_reused < 2; // every third check polishes afresh
+                const bool may = tw_reused < 8; // every ninth check polishes afresh
                 const double dp = polish_or_reuse(Qs, zp, Rk[0], fk[0], may && hk[0], c.R, fp);
                 const double dm = polish_or_reuse(Qs, zm, Rk[1], fk[1], may && hk[1], Rm, fm);
                 tw_reused = may ? tw_reused + 1 : 0;

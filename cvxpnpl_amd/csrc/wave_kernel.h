@@ -861,9 +861,9 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
 #pragma unroll
                 for (int i = 0; i < 10; ++i) zc[i] = (c1 + d1) * L[L_V + i] + (c2 + d2) * L[L_V + 10 + i];
                 // each twin may take over the rotation its slot polished at the previous check (cvx::polish_or_reuse:
-                // within ~0.05 rad, a fresh polish every third check) -- near-ambiguous problems are the slowest
+                // within ~0.05 rad, a fresh polish every ninth check) -- near-ambiguous problems are the slowest
                 // of every batch and would otherwise run two polar + Newton polishes per check
-                const bool may = tw_reused < 2;
+                const bool may = tw_reused < 8;
                 double dp, dm, Rold[9];
 #pragma unroll
                 for (int i = 0; i < 9; ++i) Rold[i] = L[L_M + 30 + i];
