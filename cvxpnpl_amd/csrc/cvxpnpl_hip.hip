@@ -159,8 +159,8 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
     int layout = opts ? opts->layout : CVXPNPL_LAYOUT_AUTO;
     // AUTO, by launch size (measured on one MI355X, M poses/s for wave / quad / lane-hybrid, PnP N = 10,
     // profiles/r01/layout_sweep.txt):
-    //   5 k: 17.9 / 17.4 / 13.3    10 k: 26.9 / 27.7 / 22.6    16 k: 30.8 / 37.4 / 32.4
-    //   24 k: 29.9 / 41.9 / 42.1   32 k: 34.4 / 46.9 / 54.5    125 k: 41.0 / 65.5 / 102.1
+    //   5 k: 20.4 / 18.2 / 13.7    10 k: 26.7 / 27.9 / 21.7    16 k: 31.2 / 38.8 / 33.3
+    //   24 k: 31.3 / 43.0 / 43.9   32 k: 34.5 / 48.7 / 58.6    125 k: 40.4 / 67.0 / 105.9
     // * below 12288 problems a wavefront per problem: every SIMD gets work and a finished problem frees
     //   its slot at once (at 10 k the quad schedule is level with it; the north-star layout is kept);
     // * from there four problems per wavefront (one per DPP row): 2.2x fewer instructions per problem;
