@@ -89,3 +89,21 @@ def pospart(W55):
     Wp, lam = np.zeros(55), np.zeros(10)
     s = lib().hs_pospart(_p(W), _p(Wp), _p(lam))
     return Wp, lam, s
+
+
+def dual_lambda(R, rhs, symm=False):
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+    out = np.zeros(10)
+    lib().hs_dual_lambda(_p(R), _p(rhs), int(symm), _p(out))
+    return out
+
+
+def rounds_to(v, Rp, tol=0.1):
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    Rp = np.ascontiguousarray(Rp, dtype=np.float64)
+    d0 = C.c_double()
+    lib().hs_rounds_to.restype = C.c_int
+    lib().hs_rounds_to.argtypes = [_dp, _dp, C.c_double, C.POINTER(C.c_double)]
+    ok = lib().hs_rounds_to(_p(v), _p(Rp), float(tol), C.byref(d0))
+    return bool(ok), d0.value

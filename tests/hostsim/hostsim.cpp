@@ -8,6 +8,12 @@ extern "C" {
 
 void hs_default_opts(cvx::Opts *o) { *o = cvx::default_opts(); }
 
+// closed-form multipliers of the dual correction (solver_core.h: dual_lambda)
+void hs_dual_lambda(const double *R9, const double *rhs10, int symm, double *lam10) { cvx::dual_lambda(R9, rhs10, symm != 0, lam10); }
+
+// reuse test of the certificate (solver_core.h: rounds_to); returns 1/0, det of the rank-1 ratio in d0
+int hs_rounds_to(const double *v10, const double *Rp9, double tol, double *d0) { return cvx::rounds_to(v10, Rp9, *d0, tol) ? 1 : 0; }
+
 // same argument meaning as cvxpnpl_solve_batch (include/cvxpnpl_amd.h), host pointers
 int hs_solve_batch(int batch, int n_p, const double *pts_2d, const double *pts_3d, int n_l, const double *line_2d,
                    const double *line_3d, const double *K, int K_per_problem, const cvx::Opts *opts,

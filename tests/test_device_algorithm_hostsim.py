@@ -176,3 +176,72 @@ def test_planar_scenes_certify_the_two_fold_pair_early():
     hs = hostsim.solve_batch(d["pts_2d"], d["pts_3d"], None, None, d["K"])
     assert (hs["status"] == 1).all()
     assert np.median(hs["iters"]) <= 20
+
+
+def _sym_from_row(a):
+    """row of the reference's equality block (coefficients over vech) -> symmetric 10x10 with <A, Z>_F = a . vech(Z)"""
+    M = np.zeros((10, 10))
+    k = 0
+    for i in range(10):
+        for j in range(i, 10):
+            M[i, j] = M[j, i] = a[k] if i == j else a[k] / 2.0
+            k += 1
+    return M
+
+
+def test_closed_form_dual_multipliers_match_reference_constraints(golden):
+    """dual_lambda: the minimum-norm correction dS in span{A_i} with dS z = rhs, computed through the constant
+    10x10 system in the frame of R, equals the dense least-norm solution built from the reference's own
+    _A (cvxpnpl.py:387-451, golden G4) -- for arbitrary rotations."""
+    A = golden["g4_A"][:22]
+    mats = [_sym_from_row(a) for a in A]
+    # orthonormal basis of span{A_i} in the Frobenius inner product
+    V = np.array([m.reshape(-1) for m in mats]).T  # 100 x 22
+    u, sv, _ = np.linalg.svd(V, full_matrices=False)
+    basis = [u[:, k].reshape(10, 10) for k in range(22) if sv[k] > 1e-10 * sv[0]]
+    assert len(basis) == 21  # the 22 rows have one dependency: row sums and column sums of the diagonal block
+    rs = np.random.RandomState(3)
+    for trial in range(6):
+        Rm, _ = np.linalg.qr(rs.normal(size=(3, 3)))
+        if np.linalg.det(Rm) < 0:
+            Rm[:, 0] = -Rm[:, 0]
+        z = np.concatenate([Rm.T.reshape(-1), [1.0]])  # vec_colmajor(R); 1
+        # a consistent right-hand side: rhs = G z with G in the span
+        G = sum(c * b for c, b in zip(rs.normal(size=21), basis))
+        rhs = G @ z
+        # dense: dS = sum c_k B_k, minimise |c| s.t. (sum c_k B_k) z = rhs
+        Mz = np.array([b @ z for b in basis]).T  # 10 x 21, rank 7: its left null space is the tangent space of SO(3) at R
+        assert np.linalg.matrix_rank(Mz, tol=1e-9) == 7
+        c = np.linalg.pinv(Mz, rcond=1e-10) @ rhs
+        dS_ref = sum(ck * b for ck, b in zip(c, basis))
+        assert np.abs(dS_ref @ z - rhs).max() < 1e-12
+        lam = hostsim.dual_lambda(Rm, rhs)
+        E = 0.5 * (np.outer(lam, z) + np.outer(z, lam))
+        dS = unpack55(pack55(E) - hostsim.proj_affine(pack55(E), True))  # P_range(E) = E - P_null(E)
+        np.testing.assert_allclose(dS, dS_ref, atol=1e-12)
+
+
+def test_reuse_test_is_a_polar_factor_test():
+    """rounds_to(v, Rp): true when the polar factor of mat(v[:9] / v[9]) is within ~0.16 rad of Rp."""
+    rs = np.random.RandomState(4)
+
+    def rot(axis, ang):
+        axis = axis / np.linalg.norm(axis)
+        Kx = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        return np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+
+    for trial in range(50):
+        Rp, _ = np.linalg.qr(rs.normal(size=(3, 3)))
+        if np.linalg.det(Rp) < 0:
+            Rp[:, 0] = -Rp[:, 0]
+        ang = rs.uniform(0.0, 0.5)
+        P = np.eye(3) * rs.uniform(0.6, 1.0) + 0.05 * np.diag(rs.normal(size=3))  # symmetric positive definite stretch
+        M0 = Rp @ rot(rs.normal(size=3), ang) @ P
+        s = rs.uniform(0.5, 2.0) * (1 if trial % 2 else -1)
+        v = np.concatenate([M0.T.reshape(-1), [1.0]]) * s  # any multiple of [vec(M0); 1]
+        ok, d0 = hostsim.rounds_to(v, Rp)
+        assert d0 > 0
+        if ang < 0.10:
+            assert ok
+        if ang > 0.25:
+            assert not ok
