@@ -410,25 +410,6 @@ CVX_HD void jacobi_cs(double al, double be, double gam, bool rot, double &c, dou
     s = t * c;
 }
 
-// one rotation of columns p, q; returns gam^2 / (al be), the squared cosine between them
-CVX_HD double eig_rotate(Eig &e, int p, int q)
-{
-    double gam = 0;
-    CVX_UNROLL for (int i = 0; i < 10; ++i) gam += e.G[p][i] * e.G[q][i];
-    double al = e.n2[p], be = e.n2[q];
-    const double g2 = gam * gam, ab = al * be;
-    double c, s, t;
-    jacobi_cs(al, be, gam, g2 > 1e-30 * ab, c, s, t);
-    CVX_UNROLL for (int i = 0; i < 10; ++i) {
-        double gp = e.G[p][i], gq = e.G[q][i];
-        e.G[p][i] = c * gp - s * gq;
-        e.G[q][i] = s * gp + c * gq;
-    }
-    e.n2[p] = al - t * gam;
-    e.n2[q] = be + t * gam;
-    return g2 / ab;
-}
-
 // Round-robin (circle method) pairing: 9 steps of 5 disjoint pairs cover all 45 pairs.  Positions
 // a0..a4 / b0..b4 start as columns 2k / 2k+1; after every step a0 stays and the others move one
 // place along the ring a1 > a2 > a3 > a4 > b4 > b3 > b2 > b1 > b0 > a1 -- the same schedule the
@@ -883,15 +864,6 @@ CVX_HD void dual_certificate(QV Qs, const double *W, const double *Wp, double rh
     CVX_UNROLL for (int i = 0; i < 10; ++i) S[sidx(i, i)] += delta;
     c.min_piv = ldl_min_pivot(S);
     c.ok = (c.min_piv > 0) && (c.res < 1e-10) && (d0 > 0) && (c.pobj == c.pobj);
-}
-
-// Qs: 45 packed, trace-normalised.  W, Wp: current ADMM iterate and its PSD part.
-// v: candidate (multiple of [r; 1]), e.g. the unit top eigenvector of Wp.  delta: PSD slack.
-template <bool SYMM = true, class QV = const double *>
-CVX_HD void certify(QV Qs, const double *W, const double *Wp, const double *v, double rho, double delta, Cert &c)
-{
-    const double d0 = polish_candidate(Qs, v, c.R, c.pobj);
-    dual_certificate<SYMM>(Qs, W, Wp, rho, delta, d0, c);
 }
 
 // ---------------------------------------------------------------------------------------

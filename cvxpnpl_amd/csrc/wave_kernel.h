@@ -64,8 +64,6 @@ constexpr LaneTab make_lane_tab()
     return t;
 }
 
-__device__ const LaneTab kLaneTab = make_lane_tab();
-
 
 #define CVXW_SYNC()                                              \
     do {                                                         \
@@ -261,11 +259,9 @@ __device__ __forceinline__ double coop_ldl(double *L, const Roles &r, double &Me
     return minp;
 }
 
-// Cooperative version of cvx::certify (solver_core.h): identical mathematics, all 64 lanes.
-// Inputs: entry-lane values Qs, W, Wp; unit top eigenvector v (10, LDS pointer); outputs R
-// (row-major, every lane), pobj, zSz.  Returns the wave-uniform verdict c.ok of cvx::certify.
-// Primal half (cvx::polish_candidate, all lanes): candidate v (any multiple of [r; 1]) -> rotation R
-// (every lane), pobj = r^T Qs r; returns the determinant of the rounded matrix.
+// Cooperative certificate = the steps of cvx::solve_sdp's check (solver_core.h), identical mathematics, all
+// 64 lanes: coop_round / coop_polish (primal half: cvx::round_candidate, cvx::polish_rotation) and coop_dual
+// (cvx::dual_certificate).  Inputs are the entry-lane values Qs, W, Wp; R is replicated in every lane.
 // rank-1 rounding (cvxpnpl.py:504-505) and projection to SO(3) (cvx::round_candidate), every lane
 __device__ __forceinline__ double coop_round(const double *v, double *R)
 {
@@ -470,15 +466,6 @@ __device__ __forceinline__ bool coop_dual(double *L, const Roles &r, double Qs, 
     const double minp = coop_ldl(L, r, Se);
     CVXW_PHR(PH_D_LDL2);
     return (minp > 0) && (res < 1e-10) && (d0 > 0) && (pobj == pobj);
-}
-
-// both halves (cvx::certify)
-__device__ __forceinline__ bool coop_certify(double *L, const Roles &r, double Qs, double W, double Wp, const double *v,
-                                             double rho, double delta, double *R, double &pobj, double &zSz CVXW_PH_PARAM)
-{
-    const double d0 = coop_round(v, R);
-    coop_polish(L, r, Qs, R, pobj CVXW_PH_ARG);
-    return coop_dual(L, r, Qs, W, Wp, R, d0, pobj, rho, delta, zSz CVXW_PH_ARG);
 }
 
 struct WaveArgs {
