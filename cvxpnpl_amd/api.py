@@ -122,6 +122,30 @@ def recover_multi(Z55: np.ndarray, B27: np.ndarray, Q45: Optional[np.ndarray] = 
     return [(R[i].copy(), t[i].copy()) for i in range(n)]
 
 
+def recover_multi_batch(res: "BatchResult", B, Q=None, n_threads: int = 0):
+    """All poses of every rank > 1 problem of a batch result (solved with want_Z=True): the host-side cold path
+    (cvxpnpl.py:507 -> :221-343) on all host cores.  B, Q: the outputs of assemble_batch for the same inputs.
+    Returns (R [batch,4,3,3], t [batch,4,3], n_poses [batch]) as numpy arrays; n_poses is 0 for problems whose
+    status is not CVXPNPL_RANK_GT1."""
+    L = _lib.lib()
+    Z = np.ascontiguousarray(res.Z.detach().cpu().numpy() if isinstance(res.Z, torch.Tensor) else res.Z, dtype=np.float64)
+    st = np.ascontiguousarray(res.status.detach().cpu().numpy() if isinstance(res.status, torch.Tensor) else res.status, dtype=np.int32)
+    tonp = lambda x: np.ascontiguousarray(x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else x, dtype=np.float64)  # noqa: E731
+    Bn = tonp(B).reshape(-1, 27)
+    Qn = tonp(Q).reshape(-1, 45) if Q is not None else None
+    n = len(st)
+    if not (len(Z) == n and len(Bn) == n and (Qn is None or len(Qn) == n)):
+        raise ValueError("recover_multi_batch: Z, B, Q and status must describe the same batch")
+    R, t, cnt = np.zeros((n, 4, 3, 3)), np.zeros((n, 4, 3)), np.zeros(n, dtype=np.int32)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    rc = L.cvxpnpl_recover_multi_batch(n, st.ctypes.data_as(ip), Z.ctypes.data_as(dp), Bn.ctypes.data_as(dp),
+                                       Qn.ctypes.data_as(dp) if Qn is not None else None, R.ctypes.data_as(dp), t.ctypes.data_as(dp),
+                                       cnt.ctypes.data_as(ip), int(n_threads))
+    if rc != 0:
+        raise RuntimeError("cvxpnpl_recover_multi_batch: bad arguments")
+    return R, t, cnt
+
+
 def _single(pts_2d, line_2d, pts_3d, line_3d, K, eps, max_iters, verbose) -> List[Tuple[np.ndarray, np.ndarray]]:
     def b(x, tail):
         if x is None:

@@ -105,6 +105,16 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
  */
 int cvxpnpl_recover_multi(const double *Z55, const double *B27, const double *Q45, double *R_out, double *t_out);
 
+/*
+ * The same for a whole batch, on host threads (n_threads <= 0: all cores): problem i is recovered when
+ * status == NULL or status[i] == CVXPNPL_RANK_GT1, skipped (n_poses[i] = 0) otherwise.  HOST pointers:
+ * Z55 [batch][55], B27 [batch][27], Q45 [batch][45] or NULL (copies of d_Z and of the outputs of
+ * cvxpnpl_assemble_batch); R_out [batch][4][9], t_out [batch][4][3], n_poses [batch] (2, 4, 1, or -1 as above).
+ * Returns 0, or -1 for bad arguments.  (the fast batched host path.)
+ */
+int cvxpnpl_recover_multi_batch(int64_t batch, const int32_t *status, const double *Z55, const double *B27, const double *Q45,
+                                double *R_out, double *t_out, int32_t *n_poses, int32_t n_threads);
+
 /* Translation maps B (3x9 per problem, t = -B r; cvxpnpl.py:548) for callers that need them
  * on the host (cvxpnpl_recover_multi).  d_B [batch][27]. */
 int cvxpnpl_assemble_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, const double *d_pts_3d, int32_t n_l,

@@ -113,3 +113,48 @@ def test_planar_scene_two_fold_ambiguity_host_recovery(L):
         assert err < 1e-10, (i, err)
         rough = recover_multi(hs["Z"][i], B)  # unpolished: limited by the first-order solve
         assert min(synth.geodesic(R, d["R_gt"][i]) for R, t in rough) < 1e-2
+
+
+def test_recover_multi_batch_equals_per_problem_recovery(L):
+    """cvxpnpl_recover_multi_batch (host threads over a batch) returns exactly what
+    cvxpnpl_recover_multi returns problem by problem, and skips problems whose status is not RANK_GT1."""
+    import sys
+    import types
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import hostsim
+    from cvxpnpl_amd import synth
+    from cvxpnpl_amd.api import recover_multi, recover_multi_batch
+
+    d = synth.make_pnp(96, 10, 0.0, seed=2)
+    d["pts_3d"][::2, :, 2] = 0.0  # every other scene planar (rank 2), the rest rank 1
+    d["pts_2d"] = synth.project(d["pts_3d"], d["K"], d["R_gt"], d["t_gt"])
+    hs = hostsim.solve_batch(d["pts_2d"], d["pts_3d"], None, None, d["K"], want_Z=True)
+    assert (hs["status"][::2] == 1).all() and (hs["status"][1::2] == 0).all()
+    Bs, Qs = [], []
+    for i in range(96):
+        _, B, Q = hostsim.assemble(d["pts_2d"][i], d["pts_3d"][i], None, None, d["K"])
+        Bs.append(B.reshape(-1))
+        Qs.append(np.array([Q[a, b] for a in range(9) for b in range(a, 9)]))
+    res = types.SimpleNamespace(Z=hs["Z"], status=hs["status"])
+    for nt in (1, 3, 0):
+        R, t, cnt = recover_multi_batch(res, np.array(Bs), np.array(Qs), n_threads=nt)
+        assert np.isin(cnt[::2], (2, 4)).all() and (cnt[::2] == 2).mean() > 0.9 and (cnt[1::2] == 0).all()
+        for i in range(0, 96, 2):
+            poses = recover_multi(hs["Z"][i], Bs[i], Qs[i])
+            assert len(poses) == cnt[i]
+            for k, (Rk, tk) in enumerate(poses):
+                assert np.array_equal(R[i, k], Rk, equal_nan=True) and np.array_equal(t[i, k], tk, equal_nan=True)
+            if cnt[i] == 2:
+                assert min(synth.geodesic(R[i, k], d["R_gt"][i]) for k in range(2)) < 1e-10
+    # status = None: every problem is recovered (rank-1 ones return their single pose)
+    import ctypes as C
+
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    Z = np.ascontiguousarray(hs["Z"])
+    Bn, Qn = np.ascontiguousarray(np.array(Bs)), np.ascontiguousarray(np.array(Qs))
+    R, t, cnt = np.zeros((96, 4, 3, 3)), np.zeros((96, 4, 3)), np.zeros(96, dtype=np.int32)
+    rc = L.cvxpnpl_recover_multi_batch(96, None, Z.ctypes.data_as(dp), Bn.ctypes.data_as(dp), Qn.ctypes.data_as(dp),
+                                       R.ctypes.data_as(dp), t.ctypes.data_as(dp), cnt.ctypes.data_as(ip), 0)
+    assert rc == 0 and (cnt[1::2] == 1).all() and np.isin(cnt[::2], (2, 4)).all()
+    assert max(synth.geodesic(R[i, 0], d["R_gt"][i]) for i in range(1, 96, 2)) < 1e-9

@@ -328,3 +328,9 @@ def test_planar_batch_is_certified_two_fold_in_few_iterations(gpu, orc, layout):
         for R, t in poses:
             assert min(synth.geodesic(R, Ro) + np.linalg.norm(t - to) for Ro, to in ref_poses) < 5e-6
     assert n_cmp >= 5
+    # the batched host path returns the same poses for the whole batch at once
+    Rb, tb, cnt = ca.recover_multi_batch(res, Bt, Qt)
+    assert (cnt == 2).all()
+    for i in range(0, 2000, 80):
+        poses = ca.recover_multi(Z[i], Bt[i], Qt[i])
+        assert all(np.array_equal(Rb[i, k], poses[k][0]) and np.array_equal(tb[i, k], poses[k][1]) for k in range(2))
