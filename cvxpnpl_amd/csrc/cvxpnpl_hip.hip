@@ -159,8 +159,8 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
     int layout = opts ? opts->layout : CVXPNPL_LAYOUT_AUTO;
     // AUTO, by launch size (measured on one MI355X, M poses/s for wave / quad / lane-hybrid, PnP N = 10,
     // profiles/r01/layout_sweep.txt):
-    //   5 k: 20.4 / 18.2 / 13.7    10 k: 26.7 / 27.9 / 21.7    16 k: 31.2 / 38.8 / 33.3
-    //   24 k: 31.3 / 43.0 / 43.9   32 k: 34.5 / 48.7 / 58.6    125 k: 40.4 / 67.0 / 105.9
+    //   5 k: 20.9 / 18.5 / 13.9    10 k: 27.7 / 28.7 / 22.2    16 k: 31.8 / 39.1 / 33.4
+    //   24 k: 31.7 / 43.3 / 43.8   32 k: 34.8 / 49.4 / 59.1    125 k: 40.9 / 67.2 / 107.0
     // * below 12288 problems a wavefront per problem: every SIMD gets work and a finished problem frees
     //   its slot at once (at 10 k the quad schedule is level with it; the north-star layout is kept);
     // * from there four problems per wavefront (one per DPP row): 2.2x fewer instructions per problem;
