@@ -26,8 +26,8 @@ namespace cvxq {
 
 using cvxw::WaveArgs;
 
-// LDS slice per problem, in doubles (even offsets: 16-byte aligned): 3.1 KB, 12.4 KB per wave, so that three
-// waves per SIMD fit the 160 KB of a CU.  388 * 2 dwords = 8 mod 64 banks: the four slices of a wave start
+// LDS slice per problem, in doubles (even offsets: 16-byte aligned): 3.1 KB, 12.4 KB per wave, so that LDS
+// never limits occupancy (12 waves fit the 160 KB of a CU; registers allow 8).  388 * 2 dwords = 8 mod 64 banks: the four slices of a wave start
 // 8 banks apart.  Regions are reused across phases (noted per region).
 constexpr int Q_WF = 0;    // 100  full 10x10: W (warm start), S (certificate); assembly: records, then the 60 Gram sums
 constexpr int Q_QF = 100;  // 100  full Qs, row stride 10, zero last column (certificate mat-vecs); assembly: records
