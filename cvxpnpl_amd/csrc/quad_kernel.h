@@ -354,6 +354,18 @@ __global__ void __launch_bounds__(64, 2) solve_quad_kernel(WaveArgs a, cvx::Opts
     for (int m = 0; m < 4; ++m) finite = finite && (Qs[m] == Qs[m]);
     finite = grp_bits(__ballot(!finite), grp) == 0;
     const double itr = finite ? cvx::rcp(tr) : 0.0;
+    // a planar scene in a general world frame goes to the wave-per-problem kernel at once: it solves in the
+    // canonical frame (cvx::canonicalise_planar), with the D-even certificate and the twin logic
+    bool planar_handoff = false;
+    if (finite) {
+        double T[9], U[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                T[i * 3 + j] = (L[Q_X + cvx::sidx(3 * i, 3 * j)] + L[Q_X + cvx::sidx(3 * i + 1, 3 * j + 1)] + L[Q_X + cvx::sidx(3 * i + 2, 3 * j + 2)]) * itr;
+        planar_handoff = cvx::planar_frame(T, U); // replicated in the row: row-uniform
+    }
     CVXW_SYNC();
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -390,6 +402,17 @@ __global__ void __launch_bounds__(64, 2) solve_quad_kernel(WaveArgs a, cvx::Opts
     bool done = !gvalid || !finite;
     const double tol2 = o.jacobi_tol * o.jacobi_tol;
     CVXW_SYNC();
+    if (!done && planar_handoff) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (w.ok[m]) ws[b * 56 + w.e[m]] = W[m];
+        if (gl == 0) {
+            ws[b * 56 + 55] = 0.0;
+            const int q = atomicAdd(&queue[0], 1);
+            queue[1 + q] = (int32_t)b;
+        }
+        done = true;
+    }
 
     if (gvalid && !finite) { // degenerate input: NaN pose (cvxpnpl.py:493-498)
         if (gl < 9) a.R[b * 9 + gl] = NAN;

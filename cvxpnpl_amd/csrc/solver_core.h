@@ -867,6 +867,119 @@ CVX_HD void dual_certificate(QV Qs, const double *W, const double *Wp, double rh
 }
 
 // ---------------------------------------------------------------------------------------
+// planar scenes in a general world frame
+//
+// When all 3D points / lines lie in one plane with unit normal n the cost does not see R n, the relaxation
+// is exactly two-fold ambiguous, and the certificate needs the D-even correction of dual_certificate -- which
+// is written for n = e3 (Qs blind to the third column of R).  The cost is blind to R n exactly when the
+// partial trace T_ij = sum_a Qs[3i+a][3j+a] (3x3, PSD) has n in its null space.  With U = [u1 u2 n] in SO(3)
+// the substitution R' = R U, r' = (U^T (x) I) r turns the problem into the canonical one: Qs' = P Qs P^T,
+// P = U^T (x) I3; the constraint set is invariant under it (orthonormality and cross-product relations hold
+// for R U iff they hold for R).  The solve then runs in primed variables; R = R' U^T and Z = Pt^T Z' Pt
+// (Pt = blkdiag(P, 1)) go back to the caller, so the change of frame is invisible outside.
+struct Canon {
+    bool on;
+    double U[9]; // row-major, columns u1, u2, n
+};
+
+// T: partial trace of the trace-normalised cost (3x3, PSD, tr T = 1).  True, with U, when the cost is blind
+// to one direction n that is not e3 already.
+CVX_HD bool planar_frame(const double *T, double *U)
+{
+    // cheap reject first: det T = product of the eigenvalues
+    if (!(fabs(det3(T)) < 1e-12)) return false;
+    // null vector of a rank-2 symmetric 3x3: the largest cross product of two rows
+    double c[3][3], n2[3];
+    CVX_UNROLL for (int k = 0; k < 3; ++k) {
+        const int a = (k + 1) % 3, b = (k + 2) % 3;
+        c[k][0] = T[a * 3 + 1] * T[b * 3 + 2] - T[a * 3 + 2] * T[b * 3 + 1];
+        c[k][1] = T[a * 3 + 2] * T[b * 3 + 0] - T[a * 3 + 0] * T[b * 3 + 2];
+        c[k][2] = T[a * 3 + 0] * T[b * 3 + 1] - T[a * 3 + 1] * T[b * 3 + 0];
+        n2[k] = c[k][0] * c[k][0] + c[k][1] * c[k][1] + c[k][2] * c[k][2];
+    }
+    const int kb = (n2[0] >= n2[1] && n2[0] >= n2[2]) ? 0 : (n2[1] >= n2[2] ? 1 : 2);
+    double nb = n2[0], n[3] = {c[0][0], c[0][1], c[0][2]};
+    CVX_UNROLL for (int k = 1; k < 3; ++k)
+        if (kb == k) { nb = n2[k]; n[0] = c[k][0]; n[1] = c[k][1]; n[2] = c[k][2]; }
+    if (!(nb > 1e-12)) return false; // rank < 2: a degenerate configuration, left to the general path
+    const double inb = 1.0 / sqrt(nb);
+    n[0] *= inb; n[1] *= inb; n[2] *= inb;
+    double qf = 0;
+    CVX_UNROLL for (int i = 0; i < 3; ++i) qf += n[i] * (T[i * 3] * n[0] + T[i * 3 + 1] * n[1] + T[i * 3 + 2] * n[2]);
+    if (!(fabs(qf) < 1e-13)) return false;                      // the cost sees every direction: not planar
+    if (fabs(n[0]) < 1e-12 && fabs(n[1]) < 1e-12) return false; // already canonical (plane Z = const)
+    // U = [u1 u2 n]: u1 = e_k x n (k: the smallest |n_k|), u2 = n x u1
+    const int km = (fabs(n[0]) <= fabs(n[1]) && fabs(n[0]) <= fabs(n[2])) ? 0 : (fabs(n[1]) <= fabs(n[2]) ? 1 : 2);
+    const double e[3] = {km == 0 ? 1.0 : 0.0, km == 1 ? 1.0 : 0.0, km == 2 ? 1.0 : 0.0};
+    double u1[3] = {e[1] * n[2] - e[2] * n[1], e[2] * n[0] - e[0] * n[2], e[0] * n[1] - e[1] * n[0]};
+    const double iu = 1.0 / sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+    u1[0] *= iu; u1[1] *= iu; u1[2] *= iu;
+    const double u2[3] = {n[1] * u1[2] - n[2] * u1[1], n[2] * u1[0] - n[0] * u1[2], n[0] * u1[1] - n[1] * u1[0]};
+    CVX_UNROLL for (int i = 0; i < 3; ++i) { U[i * 3] = u1[i]; U[i * 3 + 1] = u2[i]; U[i * 3 + 2] = n[i]; }
+    return true;
+}
+
+// detects the blind direction from the packed cost (45) and, if there is one that is not e3 already,
+// rewrites q in place in the canonical frame
+CVX_HD void canonicalise_planar(double *q, Canon &cn)
+{
+    double T[9];
+    CVX_UNROLL for (int i = 0; i < 3; ++i)
+        CVX_UNROLL for (int j = 0; j < 3; ++j) T[i * 3 + j] = q[qidx(3 * i, 3 * j)] + q[qidx(3 * i + 1, 3 * j + 1)] + q[qidx(3 * i + 2, 3 * j + 2)];
+    cn.on = planar_frame(T, cn.U);
+    if (!cn.on) return;
+    // Qs'[3i+x][3j+y] = sum_kl U[k][i] U[l][j] Qs[3k+x][3l+y]
+    double qn[45];
+    CVX_UNROLL for (int i = 0; i < 3; ++i)
+        CVX_UNROLL for (int j = i; j < 3; ++j)
+            CVX_UNROLL for (int x = 0; x < 3; ++x)
+                CVX_UNROLL for (int y = 0; y < 3; ++y) {
+                    if (i == j && y < x) continue;
+                    double acc = 0;
+                    CVX_UNROLL for (int k = 0; k < 3; ++k)
+                        CVX_UNROLL for (int l = 0; l < 3; ++l) acc += cn.U[k * 3 + i] * cn.U[l * 3 + j] * q[qidx(3 * k + x, 3 * l + y)];
+                    // the blind block is zero up to rounding (~1e-17): made exactly zero, so that the iterates stay
+                    // exactly D-even like for a plane given as Z = 0 (rounding-level asymmetry is amplified by the iteration)
+                    qn[qidx(3 * i + x, 3 * j + y)] = (j == 2) ? 0.0 : acc;
+                }
+    CVX_UNROLL for (int i = 0; i < 45; ++i) q[i] = qn[i];
+}
+
+// R = R' U^T
+CVX_HD void canon_rotation_back(const Canon &cn, double *R)
+{
+    double Rn[9];
+    CVX_UNROLL for (int i = 0; i < 3; ++i)
+        CVX_UNROLL for (int j = 0; j < 3; ++j) Rn[i * 3 + j] = R[i * 3] * cn.U[j * 3] + R[i * 3 + 1] * cn.U[j * 3 + 1] + R[i * 3 + 2] * cn.U[j * 3 + 2];
+    CVX_UNROLL for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+}
+
+// Z = Pt^T Z' Pt (to_canon = false) or Z' = Pt Z Pt^T (to_canon = true), Pt = blkdiag(U^T (x) I3, 1), packed 55
+CVX_HD void canon_congruence(const Canon &cn, double *Z, bool to_canon)
+{
+    // A = U (back) or U^T (to the canonical frame):  out[3i+x][3j+y] = sum_kl A[i][k] A[j][l] Z[3k+x][3l+y]
+    double A[9];
+    CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int k = 0; k < 3; ++k) A[i * 3 + k] = to_canon ? cn.U[k * 3 + i] : cn.U[i * 3 + k];
+    double Zn[55];
+    CVX_UNROLL for (int i = 0; i < 3; ++i)
+        CVX_UNROLL for (int x = 0; x < 3; ++x) {
+            CVX_UNROLL for (int j = i; j < 3; ++j)
+                CVX_UNROLL for (int y = 0; y < 3; ++y) {
+                    if (i == j && y < x) continue;
+                    double acc = 0;
+                    CVX_UNROLL for (int k = 0; k < 3; ++k)
+                        CVX_UNROLL for (int l = 0; l < 3; ++l) acc += A[i * 3 + k] * A[j * 3 + l] * Z[sidx(3 * k + x, 3 * l + y)];
+                    Zn[sidx(3 * i + x, 3 * j + y)] = acc;
+                }
+            double acc = 0;
+            CVX_UNROLL for (int k = 0; k < 3; ++k) acc += A[i * 3 + k] * Z[sidx(3 * k + x, 9)];
+            Zn[sidx(3 * i + x, 9)] = acc;
+        }
+    Zn[sidx(9, 9)] = Z[sidx(9, 9)];
+    CVX_UNROLL for (int i = 0; i < 55; ++i) Z[i] = Zn[i];
+}
+
+// ---------------------------------------------------------------------------------------
 // the solve
 
 // certification attempts: at first_check, then every iteration up to 10 (99.8 % of N = 10 problems finish by
@@ -933,7 +1046,27 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
     sol.sweeps = 0; sol.iters = 0; sol.rank = 0;
     bool finite = (tr == tr) && (tr > 0) && (tr < 1e300);
     double itr = finite ? 1.0 / tr : 0.0;
-    CVX_UNROLL for (int i = 0; i < 45; ++i) { const double q = Q9[i] * itr; st.setQ(i, q); finite &= (q == q); }
+    Canon cn;
+    cn.on = false;
+    {
+        double q[45];
+        CVX_UNROLL for (int i = 0; i < 45; ++i) { q[i] = Q9[i] * itr; finite &= (q[i] == q[i]); }
+        if (TWIN && finite) canonicalise_planar(q, cn);
+        if (!TWIN && finite && handoff) {
+            // first phase of a hybrid schedule: a planar scene in a general frame goes to the wave-per-problem
+            // kernel at once (it solves in the canonical frame, with the D-even certificate and the twin logic)
+            double T[9], U[9];
+            CVX_UNROLL for (int i = 0; i < 3; ++i)
+                CVX_UNROLL for (int j = 0; j < 3; ++j) T[i * 3 + j] = q[qidx(3 * i, 3 * j)] + q[qidx(3 * i + 1, 3 * j + 1)] + q[qidx(3 * i + 2, 3 * j + 2)];
+            if (planar_frame(T, U)) {
+                CVX_UNROLL for (int i = 0; i < 55; ++i) handoff[i] = (i == 54) ? 1.0 : 0.0;
+                handoff[55] = 0.0;
+                sol.status = -1;
+                return;
+            }
+        }
+        CVX_UNROLL for (int i = 0; i < 45; ++i) st.setQ(i, q[i]);
+    }
     CVX_UNROLL for (int i = 0; i < 27; ++i) st.setB(i, B[i]);
     const auto Qs = st.Q();
     if (!finite) {
@@ -1146,6 +1279,10 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
         }
     }
     sol.iters = it;
+    if (cn.on) { // back to the caller's frame
+        canon_rotation_back(cn, sol.R);
+        if (Zout) canon_congruence(cn, Zout, false);
+    }
     // t = -B r (cvxpnpl.py:513)
     {
         double r[9];

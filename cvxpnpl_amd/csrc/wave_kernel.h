@@ -37,7 +37,8 @@ constexpr int L_B = 684;    // 28   translation map B (27)
 constexpr int L_M = 712;    // 64   misc: 0.. slot norms, 16.. R, 25.. cost, dobj, status, rank, 30../40.. twin R's, 50.. previous R
 constexpr int L_V = 776;    // 20   candidate eigenvectors (top, runner-up)
 constexpr int L_VN = 796;   // 100  unit eigenvectors of the previous iterate [position][row] (warm start)
-constexpr int LDSW = 896;
+constexpr int L_U = 896;    // 10   planar scene in a general frame: the rotation U to the canonical frame (row-major)
+constexpr int LDSW = 908;
 
 struct LaneTab {
     signed char ei[64], ej[64], p1[64], p2[64], s0[64], s1[64], s2[64], diag[64];
@@ -630,7 +631,42 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
     bool finite = okK && okG && (tr == tr) && tr > 0 && tr < 1e300;
     finite = !__any(!(finite && (Qe == Qe)));
     const double itr = finite ? cvx::rcp(tr) : 0.0;
-    const double Qs = Qe * itr;
+    double Qs = Qe * itr;
+    // planar scene in a general world frame (cvx::canonicalise_planar): when the cost is blind to R n for a
+    // direction n other than e3, continue in the frame R' = R U whose third axis is n -- Qs' = P Qs P^T with
+    // P = U^T (x) I3 -- so that the D-even dual correction applies; R, Z are taken back at the end.
+    bool canon = false;
+    if (finite) {
+        double T[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                T[i * 3 + j] = (L[L_X + cvx::sidx(3 * i, 3 * j)] + L[L_X + cvx::sidx(3 * i + 1, 3 * j + 1)] + L[L_X + cvx::sidx(3 * i + 2, 3 * j + 2)]) * itr;
+        double U[9];
+        canon = cvx::planar_frame(T, U); // every lane computes the same: wave-uniform
+        if (canon) {
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) L[L_U + i] = U[i];
+            }
+            double acc = 0.0;
+            if (ej < 9) {
+                const int bi = ei / 3, x = ei % 3, bj = ej / 3, y = ej % 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int l = 0; l < 3; ++l) {
+                        const double uki = bi == 0 ? U[k * 3] : (bi == 1 ? U[k * 3 + 1] : U[k * 3 + 2]);
+                        const double ulj = bj == 0 ? U[l * 3] : (bj == 1 ? U[l * 3 + 1] : U[l * 3 + 2]);
+                        acc += uki * ulj * L[L_X + cvx::sidx(3 * k + x, 3 * l + y)];
+                    }
+                if (bj == 2) acc = 0.0; // the blind block, zero up to rounding: made exactly zero (cvx::canonicalise_planar)
+            }
+            Qs = acc * itr;
+        }
+        CVXW_SYNC();
+    }
 
     CVXW_PH(PH_ASSEMBLE);
 #ifdef CVXW_STOP_AFTER_ASSEMBLY // timing ablation (tools/ablate.sh): assembly only
@@ -650,6 +686,18 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
     bool cold = false; // resumed solves have no previous eigenvectors for their first eigen-solve
     if (resume) {
         W = resume[el];
+        if (canon) { // the hand-off iterate is in the caller's frame: W' = Pt W Pt^T
+            double acc = 0.0;
+            if (ej < 9) {
+                const int bi = ei / 3, x = ei % 3, bj = ej / 3, y = ej % 3;
+                for (int k = 0; k < 3; ++k)
+                    for (int l = 0; l < 3; ++l) acc += L[L_U + k * 3 + bi] * L[L_U + l * 3 + bj] * resume[cvx::sidx(3 * k + x, 3 * l + y)];
+            } else if (ei < 9) {
+                const int bi = ei / 3, x = ei % 3;
+                for (int k = 0; k < 3; ++k) acc += L[L_U + k * 3 + bi] * resume[cvx::sidx(3 * k + x, 9)];
+            } else acc = resume[54];
+            W = acc;
+        }
         it = (int)resume[55];
         next_check = it + 1;
         cold = true;
@@ -989,6 +1037,33 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
     }
 
     // ---------------------------------------------------------------- outputs
+    if (canon) { // back to the caller's frame: R = R' U^T for the pose and the twins, Z = Pt^T Z' Pt for an uncertified Z
+        CVXW_SYNC();
+        if (lane < 3) {
+            const int off = lane == 0 ? 16 : (lane == 1 ? 30 : 40);
+            double Rn[9];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    Rn[i * 3 + j] = L[L_M + off + i * 3] * L[L_U + j * 3] + L[L_M + off + i * 3 + 1] * L[L_U + j * 3 + 1] + L[L_M + off + i * 3 + 2] * L[L_U + j * 3 + 2];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) L[L_M + off + i] = Rn[i];
+        }
+        L[L_X + el] = Wp;
+        CVXW_SYNC();
+        double acc = 0.0;
+        if (ej < 9) {
+            const int bi = ei / 3, x = ei % 3, bj = ej / 3, y = ej % 3;
+            for (int k = 0; k < 3; ++k)
+                for (int l = 0; l < 3; ++l) acc += L[L_U + bi * 3 + k] * L[L_U + bj * 3 + l] * L[L_X + cvx::sidx(3 * k + x, 3 * l + y)];
+        } else if (ei < 9) {
+            const int bi = ei / 3, x = ei % 3;
+            for (int k = 0; k < 3; ++k) acc += L[L_U + bi * 3 + k] * L[L_X + cvx::sidx(3 * k + x, 9)];
+        } else acc = L[L_X + 54];
+        Wp = acc;
+        CVXW_SYNC();
+    }
     const bool have_pose = finite && status != cvx::ST_NONFINITE;
     if (lane < 9) a.R[b * 9 + lane] = have_pose ? L[L_M + 16 + lane] : NAN;
     if (lane < 3) { // t = -B r (cvxpnpl.py:513), r = vec_colmajor(R)

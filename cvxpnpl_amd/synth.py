@@ -77,3 +77,23 @@ def geodesic(Ra, Rb):
     D = np.swapaxes(Ra, -1, -2) @ Rb
     s = 0.5 * np.stack([D[..., 2, 1] - D[..., 1, 2], D[..., 0, 2] - D[..., 2, 0], D[..., 1, 0] - D[..., 0, 1]], -1)
     return np.arctan2(np.linalg.norm(s, axis=-1), 0.5 * (np.trace(D, axis1=-2, axis2=-1) - 1.0))
+
+
+def make_planar_pnp(batch, n_p, sigma=0.0, seed=42, general=True, K=K_KINECT):
+    """PnP problems whose 3D points lie in one plane: Z = 0 in the world frame (general=False) or a random
+    plane per problem (general=True: the Z = 0 scene moved by a random rigid transform).  Same dict as make_pnp."""
+    d = make_pnp(batch, n_p, 0.0, seed=seed, K=K)
+    d["pts_3d"][:, :, 2] = 0.0
+    rs = np.random.RandomState(seed + 1)
+    if general:
+        G, _ = np.linalg.qr(rs.normal(size=(batch, 3, 3)))
+        G[np.linalg.det(G) < 0, :, 0] *= -1
+        c = rs.normal(size=(batch, 3))
+        P = np.einsum("bij,bnj->bni", G, d["pts_3d"]) + c[:, None, :]
+        R = np.einsum("bij,bkj->bik", d["R_gt"], G)  # R_gt G^T
+        t = d["t_gt"] - np.einsum("bij,bj->bi", R, c)
+        d["pts_3d"], d["R_gt"], d["t_gt"] = P, R, t
+    d["pts_2d"] = project(d["pts_3d"], d["K"], d["R_gt"], d["t_gt"])
+    if sigma > 0:
+        d["pts_2d"] = d["pts_2d"] + rs.normal(scale=sigma, size=d["pts_2d"].shape)
+    return d

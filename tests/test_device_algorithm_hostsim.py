@@ -245,3 +245,22 @@ def test_reuse_test_is_a_polar_factor_test():
             assert ok
         if ang > 0.25:
             assert not ok
+
+
+def test_planar_scene_in_a_general_frame_is_solved_in_the_canonical_one():
+    """A plane that is not Z = 0: the cost is blind to R n, detected from the partial trace of Qs; the solve runs
+    in the frame whose third axis is n (canonicalise_planar) and R, Z come back in the caller's frame: same
+    behaviour as for Z = 0 -- certified pair after a handful of iterations, both poses recoverable from Z."""
+    from cvxpnpl_amd.api import recover_multi
+
+    d = synth.make_planar_pnp(300, 10, 0.0, seed=3, general=True)
+    hs = hostsim.solve_batch(d["pts_2d"], d["pts_3d"], None, None, d["K"], want_Z=True)
+    assert (hs["status"] == 1).all()
+    assert np.median(hs["iters"]) <= 20
+    for i in range(0, 300, 10):
+        _, B, Q = hostsim.assemble(d["pts_2d"][i], d["pts_3d"][i], None, None, d["K"])
+        poses = recover_multi(hs["Z"][i], B, Q[np.triu_indices(9)])
+        assert len(poses) in (2, 4)
+        assert min(synth.geodesic(R, d["R_gt"][i]) + np.linalg.norm(t - d["t_gt"][i]) for R, t in poses) < 1e-8
+        # the pose returned with status 1 is one of the two twins, in the caller's frame
+        assert min(synth.geodesic(hs["R"][i], R) for R, t in poses) < 1e-8
