@@ -586,7 +586,7 @@ __global__ void __launch_bounds__(64, 2) solve_quad_kernel(WaveArgs a, cvx::Opts
                     const double gn = fabs(g3[0]) + fabs(g3[1]) + fabs(g3[2]);
                     CVXW_SYNC();
                     if (nit >= 2 && !__any(!done && !(gn < 1e-15))) break;
-                    const bool final_step = gn < 1e-6;
+                    const bool final_step = gn < 1e-8;
                     const double trN = N[0] + N[4] + N[8];
                     double H[9];
 #pragma unroll

@@ -550,9 +550,9 @@ CVX_HD void so3_newton(QV Q9, double *R, int iters)
         // converged: projected gradient at rounding level (Q is trace-normalised, |R| = O(1))
         const double gn = fabs(g[0]) + fabs(g[1]) + fabs(g[2]);
         if (it >= 2 && gn < 1e-15) break;
-        // Newton converges quadratically: from |g| < 1e-6 the step below lands at 1e-12, far below what the certificate resolves, so it is
+        // Newton converges quadratically: from |g| < 1e-8 the step below lands at rounding level, so it is
         // the last one (saves the iteration that would only have confirmed it)
-        const bool final_step = gn < 1e-6;
+        const bool final_step = gn < 1e-8;
         // a_k = vec(R [e_k]x): columns (0, c2, -c1), (-c2, 0, c0), (c1, -c0, 0)
         double a[3][9], Qa[3][9];
         CVX_UNROLL for (int i = 0; i < 3; ++i) {

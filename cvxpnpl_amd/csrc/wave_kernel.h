@@ -332,7 +332,7 @@ __device__ __forceinline__ void coop_polish(double *L, const Roles &r, double Qs
         CVXW_SYNC();
         const double gn = fabs(g[0]) + fabs(g[1]) + fabs(g[2]);
         if (it >= 2 && gn < 1e-15) break; // wave-uniform
-        const bool final_step = gn < 1e-6;  // quadratic convergence: this step lands at ~1e-12
+        const bool final_step = gn < 1e-8;  // quadratic convergence: this step lands at rounding level
         const double trN = N[0] + N[4] + N[8];
         double H[9];
 #pragma unroll
