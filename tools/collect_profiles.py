@@ -55,7 +55,7 @@ for run in ("default", "quad_24k", "hybrid_125k"):
         "valu_insts_per_launch": tot("SQ_INSTS_VALU"), "salu_insts_per_launch": tot("SQ_INSTS_SALU"), "lds_insts_per_launch": tot("SQ_INSTS_LDS"),
         "source": f"profiles/{tag}/{run}/pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KB*1024, "
                   "summed over the kernels of one step, FETCH not doubled (narrow accesses)"}
-for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(src, "*.jsonl")) + glob.glob(os.path.join(src, "layout_sweep.txt")):
+for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(src, "*.jsonl")) + glob.glob(os.path.join(src, "layout_sweep.txt")) + glob.glob(os.path.join(src, "planar_general.txt")):
     shutil.copy(f, dst)
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))

@@ -31,5 +31,6 @@ python bench.py --workload pnpl_5p5l_100k --no-cpu-baseline > $out/bench_pnpl_10
 python bench.py --workload pnp_n10_125k --batch 1000000 --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_1m.json 2>/dev/null
 python tools/config5_sweep.py > $out/config5_sweep.jsonl 2>/dev/null
 python tools/planar_timing.py > $out/planar_timing.jsonl 2>/dev/null
+python tools/planar_general.py > $out/planar_general.txt 2>/dev/null
 tools/layout_sweep.sh > $out/layout_sweep.txt 2>/dev/null
 ls $out
