@@ -159,8 +159,8 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
     int layout = opts ? opts->layout : CVXPNPL_LAYOUT_AUTO;
     // AUTO, by launch size (measured on one MI355X, M poses/s for wave / quad / lane-hybrid, PnP N = 10,
     // profiles/r01/layout_sweep.txt):
-    //   5 k: 20.9 / 18.5 / 13.9    10 k: 27.7 / 28.7 / 22.2    16 k: 31.8 / 39.1 / 33.4
-    //   24 k: 31.7 / 43.3 / 43.8   32 k: 34.8 / 49.4 / 59.1    125 k: 40.9 / 67.2 / 107.0
+    //   5 k: 20.2 / 18.1 / 13.4    10 k: 26.5 / 27.6 / 21.3    16 k: 31.0 / 39.0 / 33.1
+    //   24 k: 31.2 / 42.9 / 43.5   32 k: 34.3 / 48.1 / 58.0    125 k: 40.0 / 65.9 / 105.2
     // * below 12288 problems a wavefront per problem: every SIMD gets work and a finished problem frees
     //   its slot at once (at 10 k the quad schedule is level with it; the north-star layout is kept);
     // * from there four problems per wavefront (one per DPP row): 2.2x fewer instructions per problem;
