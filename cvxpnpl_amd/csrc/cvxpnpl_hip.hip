@@ -159,15 +159,15 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
     int layout = opts ? opts->layout : CVXPNPL_LAYOUT_AUTO;
     // AUTO, by launch size (measured on one MI355X, M poses/s for wave / quad / lane-hybrid, PnP N = 10,
     // profiles/r01/layout_sweep.txt):
-    //   5 k: 20.2 / 18.1 / 13.4    10 k: 26.5 / 27.6 / 21.3    16 k: 31.0 / 39.0 / 33.1
-    //   24 k: 31.2 / 42.9 / 43.5   32 k: 34.3 / 48.1 / 58.0    125 k: 40.0 / 65.9 / 105.2
-    // * below 12288 problems a wavefront per problem: every SIMD gets work and a finished problem frees
-    //   its slot at once (at 10 k the quad schedule is level with it; the north-star layout is kept);
+    //   5 k: 21.3 / 19.5 / 12.5    8 k: 23.4 / 28.8 / -       10 k: 28.4 / 30.7 / 22.7    16 k: 31.7 / 42.0 / 34.4
+    //   24 k: 31.9 / 47.1 / 44.6   32 k: 34.6 / 52.9 / 60.6   125 k: 41.0 / 72.9 / 108.4
+    // * below 7168 problems a wavefront per problem: every SIMD gets work and a finished problem frees
+    //   its slot at once;
     // * from there four problems per wavefront (one per DPP row): 2.2x fewer instructions per problem;
-    // * from 24576 the lane-hybrid schedule (64 problems per wavefront for the first lane_iters
+    // * from 28672 the lane-hybrid schedule (64 problems per wavefront for the first lane_iters
     //   iterations): fewest instructions, but it needs tens of thousands of problems to fill the chip.
     // The unfinished problems of the quad and lane phases are resumed one per wavefront.
-    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 12288 ? CVXPNPL_LAYOUT_WAVE : (batch < 24576 ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
+    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 7168 ? CVXPNPL_LAYOUT_WAVE : (batch < 28672 ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
     cvxw::WaveArgs w;
     w.batch = batch; w.n_p = n_p; w.n_l = n_l; w.K_per_problem = K_per_problem;
     w.p2 = d_pts_2d; w.p3 = d_pts_3d; w.l2 = d_line_2d; w.l3 = d_line_3d; w.K = d_K;
