@@ -159,35 +159,30 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
     int layout = opts ? opts->layout : CVXPNPL_LAYOUT_AUTO;
     // AUTO, by launch size (measured on one MI355X, M poses/s for wave / quad / lane-hybrid, PnP N = 10,
     // profiles/r01/layout_sweep.txt):
-    //   5 k: 21.3 / 19.5 / 12.5    8 k: 23.4 / 28.8 / -       10 k: 28.4 / 30.7 / 22.7    16 k: 31.7 / 42.0 / 34.4
-    //   24 k: 31.9 / 47.1 / 44.6   32 k: 34.6 / 52.9 / 60.6   125 k: 41.0 / 72.9 / 108.4
-    // * below 7168 problems a wavefront per problem: every SIMD gets work and a finished problem frees
+    //   2 k: 12.4 / 12.5 / 5.8    4 k: 15.3 / 19.0 / 9.5     10 k: 27.7 / 37.0 / 23.0    16 k: 32.6 / 52.5 / 34.6
+    //   24 k: 32.9 / 52.9 / 45.6  32 k: 35.7 / 60.0 / 60.1   50 k: 38.8 / 66.7 / 80.6    125 k: 41.2 / - / 108.5
+    // * below 3584 problems a wavefront per problem: every SIMD gets work and a finished problem frees
     //   its slot at once;
     // * from there four problems per wavefront (one per DPP row): 2.2x fewer instructions per problem;
-    // * from 28672 the lane-hybrid schedule (64 problems per wavefront for the first lane_iters
+    // * from 32768 the lane-hybrid schedule (64 problems per wavefront for the first lane_iters
     //   iterations): fewest instructions, but it needs tens of thousands of problems to fill the chip.
-    // The unfinished problems of the quad and lane phases are resumed one per wavefront.
-    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 7168 ? CVXPNPL_LAYOUT_WAVE : (batch < 28672 ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
+    // The problems the quad phase leaves open are finished by the same wavefront, those of the lane phase
+    // by a second kernel, one per wavefront in both cases.
+    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 3584 ? CVXPNPL_LAYOUT_WAVE : (batch < 32768 ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
     cvxw::WaveArgs w;
     w.batch = batch; w.n_p = n_p; w.n_l = n_l; w.K_per_problem = K_per_problem;
     w.p2 = d_pts_2d; w.p3 = d_pts_3d; w.l2 = d_line_2d; w.l3 = d_line_3d; w.K = d_K;
     w.R = d_R; w.t = d_t; w.cost = d_cost; w.Z = d_Z; w.status = d_status; w.iters = d_iters; w.work = d_work;
     int quad_iters = opts ? opts->lane_iters : -1;
-    if (quad_iters <= 0) quad_iters = 6;
+    if (quad_iters <= 0) quad_iters = 10; // measured optimum 8-12 at every launch size (tools/quad_tune.sh)
     if (layout == CVXPNPL_LAYOUT_QUAD && !(quad_iters >= 1 && o.max_iters > quad_iters)) layout = CVXPNPL_LAYOUT_WAVE;
     if (layout == CVXPNPL_LAYOUT_QUAD) {
         // four problems per wavefront for the first quad_iters iterations, survivors resumed one per wavefront
-        const size_t qbytes = ((size_t)(batch + 1) * sizeof(int32_t) + 255) & ~(size_t)255;
-        char *wsp = (char *)get_workspace(qbytes + (size_t)batch * 56 * sizeof(double), stream);
-        if (!wsp) { snprintf(g_err, sizeof(g_err), "cvxpnpl: workspace allocation failed"); return -2; }
-        int32_t *queue = (int32_t *)wsp;
-        double *ws = (double *)(wsp + qbytes);
-        hipError_t me = hipMemsetAsync(queue, 0, sizeof(int32_t), s);
-        if (me != hipSuccess) return set_err("hipMemsetAsync", me);
+        // (one kernel: a wavefront finishes its own survivors, no queue and no second launch)
+        double *ws = (double *)get_workspace((size_t)batch * 56 * sizeof(double), stream);
+        if (!ws) { snprintf(g_err, sizeof(g_err), "cvxpnpl: workspace allocation failed"); return -2; }
         const int64_t qgrid = (batch + 3) / 4;
-        hipLaunchKernelGGL(cvxq::solve_quad_kernel, dim3((unsigned)qgrid), dim3(64), 0, s, w, o, quad_iters, queue, ws);
-        const int64_t rgrid = batch < 8192 ? batch : 8192;
-        hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64 * cvxw::WPB), 0, s, w, o, queue, ws);
+        hipLaunchKernelGGL(cvxq::solve_quad_kernel, dim3((unsigned)qgrid), dim3(64), 0, s, w, o, quad_iters, ws);
     } else if (layout == CVXPNPL_LAYOUT_WAVE) {
         int64_t wgrid = (batch + cvxw::WPB - 1) / cvxw::WPB;
         if (wgrid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }

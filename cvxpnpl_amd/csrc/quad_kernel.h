@@ -12,8 +12,9 @@
 //     row_mirror); the four problems of a wave run in lock step, control flow is wave-uniform and a
 //     finished problem just idles until its three neighbours are done.
 // The kernel runs the first `handoff_at` ADMM iterations (certificate attempts from first_check on);
-// the few problems that are not certified by then park their iterate in ws[] and are queued for
-// cvxw::resume_wave_kernel (twin candidates, slow tails and the reference's uncertified exits live there).
+// the few problems that are not certified by then park their iterate in ws[] and the wavefront finishes them
+// itself, one at a time, in the wave-per-problem layout (cvxw::solve_one_wave: twin candidates, slow tails
+// and the reference's uncertified exits live there).
 // Mathematics identical to solver_core.h / wave_kernel.h; see those files for the derivations.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -202,7 +203,26 @@ __device__ __forceinline__ double quad_ldl(double *L, const Own &w, double *Me)
 }
 
 // Four problems per wavefront: problem b = 4 * blockIdx.x + (lane >> 4).
-__global__ void __launch_bounds__(64, 2) solve_quad_kernel(WaveArgs a, cvx::Opts o, int handoff_at, int32_t *queue, double *ws)
+// Second phase: the wavefront finishes the problems it could not certify within handoff_at iterations itself,
+// one after the other in the wave-per-problem layout (low latency per problem; they are the slow / ambiguous
+// ones, twin logic included).  The iterate travels through ws[] (written with park(), read back with
+// device-scope loads: no cache maintenance, only program order).
+// Tried first: a device-wide queue from which idle wavefronts steal parked problems.  The cache line with
+// its head / tail words bounces between the eight XCDs' L2s: 1.6 ms per launch for 2500 wavefronts, measured.
+// Not inlined on purpose: as a separate function the wave-per-problem solver gets a register allocation of
+// its own and leaves that of the quad phase alone; nothing but the kernel arguments is live across the call.
+__device__ __forceinline__ void park(double *p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __noinline__ void finish_own(const WaveArgs &a, const cvx::Opts &o, unsigned parked, const double *ws, double *lds)
+{
+    const int64_t b0 = (int64_t)blockIdx.x * 4;
+    for (int g = 0; g < 4; ++g) { // wave-uniform
+        if (!((parked >> g) & 1u)) continue;
+        cvxw::solve_one_wave(a, o, b0 + g, lds, ws + (b0 + g) * 56);
+        CVXW_SYNC();
+    }
+}
+
+__global__ void __launch_bounds__(64, 2) solve_quad_kernel(WaveArgs a, cvx::Opts o, int handoff_at, double *ws)
 {
     __shared__ __attribute__((aligned(16))) double lds_all[4 * QLDS];
     const int lane = threadIdx.x & 63, gl = lane & 15, grp = lane >> 4;
@@ -400,17 +420,15 @@ __global__ void __launch_bounds__(64, 2) solve_quad_kernel(WaveArgs a, cvx::Opts
     bool have_prev = false;
     double fprev = 0.0;
     bool done = !gvalid || !finite;
+    bool parked = false; // this problem goes to the second phase
     const double tol2 = o.jacobi_tol * o.jacobi_tol;
     CVXW_SYNC();
     if (!done && planar_handoff) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-            if (w.ok[m]) ws[b * 56 + w.e[m]] = W[m];
-        if (gl == 0) {
-            ws[b * 56 + 55] = 0.0;
-            const int q = atomicAdd(&queue[0], 1);
-            queue[1 + q] = (int32_t)b;
-        }
+            if (w.ok[m]) park(ws + b * 56 + w.e[m], W[m]);
+        if (gl == 0) park(ws + b * 56 + 55, 0.0);
+        parked = true;
         done = true;
     }
 
@@ -786,15 +804,21 @@ __global__ void __launch_bounds__(64, 2) solve_quad_kernel(WaveArgs a, cvx::Opts
             if (!done) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
-                    if (w.ok[m]) ws[b * 56 + w.e[m]] = W[m];
-                if (gl == 0) {
-                    ws[b * 56 + 55] = (double)it;
-                    const int q = atomicAdd(&queue[0], 1);
-                    queue[1 + q] = (int32_t)b;
-                }
+                    if (w.ok[m]) park(ws + b * 56 + w.e[m], W[m]);
+                if (gl == 0) park(ws + b * 56 + 55, (double)it);
+                parked = true;
             }
             break;
         }
+    }
+
+    // ---------------------------------------------------------------- second phase (wave per problem)
+    const unsigned long long pm = __ballot(parked);
+    const unsigned pmask = (unsigned)((pm & 1ull) | ((pm >> 15) & 2ull) | ((pm >> 30) & 4ull) | ((pm >> 45) & 8ull));
+    if (pmask) { // wave-uniform
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // every park() acknowledged before the iterate is read back
+        CVXW_SYNC();
+        finish_own(a, o, pmask, ws, lds_all);
     }
 }
 

@@ -685,20 +685,22 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
     int tw_reused = 0;
     bool cold = false; // resumed solves have no previous eigenvectors for their first eigen-solve
     if (resume) {
-        W = resume[el];
+        // device-coherent loads: the iterate may have been parked by a wavefront of this very launch (quad_kernel.h)
+        auto rd = [&](int i) { return __hip_atomic_load(resume + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        W = rd(el);
         if (canon) { // the hand-off iterate is in the caller's frame: W' = Pt W Pt^T
             double acc = 0.0;
             if (ej < 9) {
                 const int bi = ei / 3, x = ei % 3, bj = ej / 3, y = ej % 3;
                 for (int k = 0; k < 3; ++k)
-                    for (int l = 0; l < 3; ++l) acc += L[L_U + k * 3 + bi] * L[L_U + l * 3 + bj] * resume[cvx::sidx(3 * k + x, 3 * l + y)];
+                    for (int l = 0; l < 3; ++l) acc += L[L_U + k * 3 + bi] * L[L_U + l * 3 + bj] * rd(cvx::sidx(3 * k + x, 3 * l + y));
             } else if (ei < 9) {
                 const int bi = ei / 3, x = ei % 3;
-                for (int k = 0; k < 3; ++k) acc += L[L_U + k * 3 + bi] * resume[cvx::sidx(3 * k + x, 9)];
-            } else acc = resume[54];
+                for (int k = 0; k < 3; ++k) acc += L[L_U + k * 3 + bi] * rd(cvx::sidx(3 * k + x, 9));
+            } else acc = rd(54);
             W = acc;
         }
-        it = (int)resume[55];
+        it = (int)rd(55);
         next_check = it + 1;
         cold = true;
         if (o.tail_from > 0 && it >= o.tail_from) { rho = o.rho_tail; irho = 1.0 / rho; }

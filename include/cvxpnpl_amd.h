@@ -38,12 +38,12 @@ enum {
 
 /* kernel layouts (A/B switch; all produce the same results) */
 enum {
-    CVXPNPL_LAYOUT_AUTO = 0, /* by launch size: wave below 7168 problems, quad below 28672, lane (hybrid) from there */
+    CVXPNPL_LAYOUT_AUTO = 0, /* by launch size: wave below 3584 problems, quad below 32768, lane (hybrid) from there */
     CVXPNPL_LAYOUT_LANE = 1, /* one problem per lane, 64 per wavefront, for the first lane_iters iterations;
                                 unfinished problems are then resumed one per wavefront (hybrid schedule) */
     CVXPNPL_LAYOUT_WAVE = 2, /* one problem per wavefront (cooperative lanes) */
     CVXPNPL_LAYOUT_QUAD = 3  /* one problem per DPP row: 16 lanes, four per wavefront, for the first lane_iters
-                                iterations; the unfinished ones are resumed one per wavefront */
+                                iterations; the wavefront then finishes its unfinished ones itself, one at a time */
 };
 
 typedef struct {
@@ -61,7 +61,7 @@ typedef struct {
     int32_t tail_from;  /* default 3; <= 0 never */
     int32_t lane_iters; /* lane and quad layouts: iterations before unfinished problems are handed to one
                            wavefront each (hybrid schedule).  <= 0: default (lane: 4 or 5 by batch size;
-                           quad: 6).  The lane phase is capped at 5 iterations. */
+                           quad: 10).  The lane phase is capped at 5 iterations. */
     int32_t layout;    /* CVXPNPL_LAYOUT_* */
 } cvxpnpl_opts_t;
 
