@@ -5,4 +5,4 @@ variants that solve tens of thousands to millions of independent problems per la
 """
 __version__ = "0.1.0"
 
-from .api import BatchResult, assemble_batch, pnl, pnl_batch, pnp, pnp_batch, pnpl, pnpl_batch, recover_multi, recover_multi_batch  # noqa: F401
+from .api import BatchResult, assemble_batch, pnl, pnl_batch, pnp, pnp_batch, pnpl, pnpl_batch, recover_multi, recover_multi_batch, score_hypotheses  # noqa: F401

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["pnp", "pnl", "pnpl", "pnp_batch", "pnl_batch", "pnpl_batch", "BatchResult"]
+__all__ = ["pnp", "pnl", "pnpl", "pnp_batch", "pnl_batch", "pnpl_batch", "BatchResult", "score_hypotheses"]
 
 
 class BatchResult(dict):
@@ -201,6 +201,44 @@ def assemble_batch(pts_2d, line_2d, pts_3d, line_3d, K, device=None):
     if rc != 0:
         raise RuntimeError(f"cvxpnpl_assemble_batch failed ({rc}): {_lib.last_error()}")
     return Bt, Qt
+
+
+def score_hypotheses(R, t, K, pts_2d, pts_3d, thresh: float = 2.0, status=None, usable=(0, 2), want_mask: bool = False):
+    """Inlier counts of pose hypotheses against one scene (cvxpnpl_score_hypotheses, the HIP scoring kernel).
+
+    R [H,3,3], t [H,3] device tensors (e.g. of a BatchResult); scene pts_2d [M,2], pts_3d [M,3]; K [3,3].
+    status [H] int32 (optional): only hypotheses whose status is in `usable` are scored, the others count 0.
+    Returns count [H] int32, or (count, mask [H,M] uint8) with want_mask."""
+    _require_gpu()
+    L = _lib.lib()
+    dev = R.device if isinstance(R, torch.Tensor) and R.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    Rd = _as_dev(R, dev, (3, 3))
+    td = _as_dev(t, dev, (3,))
+    Kd = _as_dev(K, dev, (3, 3))
+    x = _as_dev(pts_2d, dev, (2,))
+    X = _as_dev(pts_3d, dev, (3,))
+    if Rd.dim() != 3 or td.shape[0] != Rd.shape[0] or Kd.dim() != 2 or x.dim() != 2 or X.dim() != 2 or x.shape[0] != X.shape[0]:
+        raise ValueError("expected R [H,3,3], t [H,3], K [3,3], pts_2d [M,2], pts_3d [M,3]")
+    H, M = Rd.shape[0], X.shape[0]
+    if H == 0:
+        count = torch.empty((0,), dtype=torch.int32, device=dev)
+        return (count, torch.empty((0, M), dtype=torch.uint8, device=dev)) if want_mask else count
+    st = None
+    if status is not None:
+        st = torch.as_tensor(status).to(device=dev, dtype=torch.int32).contiguous()
+        if st.shape != (H,):
+            raise ValueError("status must be [H]")
+    um = 0
+    for s_ in usable:
+        um |= 1 << int(s_)
+    with torch.cuda.device(dev):
+        count = torch.empty((H,), dtype=torch.int32, device=dev)
+        mask = torch.empty((H, M), dtype=torch.uint8, device=dev) if want_mask else None
+        rc = L.cvxpnpl_score_hypotheses(H, _ptr(Rd), _ptr(td), _ptr(st), um, _ptr(Kd), M, _ptr(x), _ptr(X), float(thresh),
+                                        _ptr(count), _ptr(mask), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"cvxpnpl_score_hypotheses failed ({rc}): {_lib.last_error()}")
+    return (count, mask) if want_mask else count
 
 
 def _translation_map(p2, l2, p3, l3, Kn):

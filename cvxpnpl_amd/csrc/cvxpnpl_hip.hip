@@ -13,6 +13,7 @@
 #include "solver_core.h"
 #include "wave_kernel.h"
 #include "quad_kernel.h"
+#include "score_kernel.h"
 
 namespace {
 
@@ -235,6 +236,26 @@ int cvxpnpl_assemble_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, c
     hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((batch + block - 1) / block)), dim3(block), 0, (hipStream_t)stream, a, d_B, d_Q45);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err("assemble_kernel launch", e);
+    return 0;
+}
+
+int cvxpnpl_score_hypotheses(int64_t n_hyp, const double *d_R, const double *d_t, const int32_t *d_status, uint32_t usable_mask,
+                             const double *d_K, int32_t n_corr, const double *d_pts_2d, const double *d_pts_3d, double thresh_px,
+                             int32_t *d_count, uint8_t *d_mask, void *stream)
+{
+    if (n_hyp < 0 || n_corr < 0 || !d_R || !d_t || !d_K || !d_count || (n_corr > 0 && (!d_pts_2d || !d_pts_3d)) || !(thresh_px > 0.0)) {
+        snprintf(g_err, sizeof(g_err), "cvxpnpl_score_hypotheses: bad arguments");
+        return -1;
+    }
+    if (n_hyp == 0) return 0;
+    const int64_t grid = (n_hyp + cvxs::SCORE_BLOCK - 1) / cvxs::SCORE_BLOCK;
+    if (grid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl_score_hypotheses: too many hypotheses for one launch"); return -1; }
+    cvxs::ScoreArgs a;
+    a.n_hyp = n_hyp; a.R = d_R; a.t = d_t; a.status = d_status; a.usable_mask = usable_mask; a.K = d_K;
+    a.n_corr = n_corr; a.p2 = d_pts_2d; a.p3 = d_pts_3d; a.thresh = thresh_px; a.count = d_count; a.mask = d_mask;
+    hipLaunchKernelGGL(cvxs::score_kernel, dim3((unsigned)grid), dim3(cvxs::SCORE_BLOCK), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err("score_kernel launch", e);
     return 0;
 }
 

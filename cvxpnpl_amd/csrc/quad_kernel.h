@@ -211,6 +211,9 @@ __device__ __forceinline__ double quad_ldl(double *L, const Own &w, double *Me)
 // its head / tail words bounces between the eight XCDs' L2s: 1.6 ms per launch for 2500 wavefronts, measured.
 // Not inlined on purpose: as a separate function the wave-per-problem solver gets a register allocation of
 // its own and leaves that of the quad phase alone; nothing but the kernel arguments is live across the call.
+// (The by-reference arguments cost the caller a 200 B/lane copy to scratch.  Re-reading them from the kernarg
+// segment inside the callee instead: the segment pointer is null there; handing that pointer down: scalar
+// loads, but the callee's frame grows from 136 to 588 B -- no gain, not kept.)
 __device__ __forceinline__ void park(double *p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __noinline__ void finish_own(const WaveArgs &a, const cvx::Opts &o, unsigned parked, const double *ws, double *lds)
 {

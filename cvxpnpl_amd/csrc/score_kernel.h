@@ -1,0 +1,89 @@
+// score_kernel.h -- consensus scoring of pose hypotheses (RANSAC consumer of the batched solver,
+// SURVEY.md section 8(f) row 3; the reference has no RANSAC, BASELINE config 5 does).
+//
+// One lane per hypothesis; the scene (M correspondences, 40 B each) is staged through LDS a tile at a
+// time and broadcast to the lanes (ds_read of a wave-uniform address).  Per hypothesis the kernel reads
+// 96 B (R, t) + 4 B (status) and writes 4 B: with the scene in LDS the traffic is the hypotheses, once.
+// Correspondence m is an inlier of hypothesis h when it lies in front of the camera and reprojects
+// within thresh pixels:  X = R P + t,  (u, v, w) = K X,  X_z > 0,  |(u/w, v/w) - x| < thresh.
+// A hypothesis whose pose is not finite, or whose status is not usable, scores 0.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cvxs {
+
+constexpr int SCORE_BLOCK = 256;
+constexpr int SCORE_TILE = 512; // correspondences per LDS tile (20 KB)
+
+struct ScoreArgs {
+    int64_t n_hyp;
+    const double *R, *t;     // [n_hyp][9] row-major, [n_hyp][3]
+    const int32_t *status;   // optional: only CERTIFIED (0) and NOT_CONVERGED-free statuses listed in usable_mask count
+    uint32_t usable_mask;    // bit s set: status s is scored
+    const double *K;         // [9]
+    int32_t n_corr;
+    const double *p2, *p3;   // [n_corr][2], [n_corr][3]
+    double thresh;
+    int32_t *count;          // [n_hyp]
+    uint8_t *mask;           // optional [n_hyp][n_corr]
+};
+
+__global__ void __launch_bounds__(SCORE_BLOCK) score_kernel(ScoreArgs a)
+{
+    __shared__ double scene[SCORE_TILE * 5];
+    const int64_t h = (int64_t)blockIdx.x * SCORE_BLOCK + threadIdx.x;
+    const bool live = h < a.n_hyp;
+    double M[12]; // K R | K t : pixel-space projection;  r2 / t2: depth row
+    double r2[3] = {0, 0, 0}, t2 = 0;
+    bool usable = live;
+    if (live) {
+        double R[9], t[3], K[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { R[i] = a.R[h * 9 + i]; K[i] = a.K[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t[i] = a.t[h * 3 + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) M[i * 4 + j] = K[i * 3] * R[j] + K[i * 3 + 1] * R[3 + j] + K[i * 3 + 2] * R[6 + j];
+            M[i * 4 + 3] = K[i * 3] * t[0] + K[i * 3 + 1] * t[1] + K[i * 3 + 2] * t[2];
+        }
+        r2[0] = R[6]; r2[1] = R[7]; r2[2] = R[8]; t2 = t[2];
+        if (a.status) {
+            const int32_t s = a.status[h];
+            usable = s >= 0 && s < 32 && ((a.usable_mask >> s) & 1u);
+        }
+    }
+    const double th2 = a.thresh * a.thresh;
+    int cnt = 0;
+    for (int base = 0; base < a.n_corr; base += SCORE_TILE) {
+        const int n = a.n_corr - base < SCORE_TILE ? a.n_corr - base : SCORE_TILE;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += SCORE_BLOCK) {
+            const int m = base + i;
+            scene[i * 5 + 0] = a.p3[m * 3 + 0];
+            scene[i * 5 + 1] = a.p3[m * 3 + 1];
+            scene[i * 5 + 2] = a.p3[m * 3 + 2];
+            scene[i * 5 + 3] = a.p2[m * 2 + 0];
+            scene[i * 5 + 4] = a.p2[m * 2 + 1];
+        }
+        __syncthreads();
+        if (live) {
+            for (int i = 0; i < n; ++i) {
+                const double X = scene[i * 5], Y = scene[i * 5 + 1], Z = scene[i * 5 + 2];
+                const double u = M[0] * X + M[1] * Y + M[2] * Z + M[3];
+                const double v = M[4] * X + M[5] * Y + M[6] * Z + M[7];
+                const double w = M[8] * X + M[9] * Y + M[10] * Z + M[11];
+                const double depth = r2[0] * X + r2[1] * Y + r2[2] * Z + t2;
+                const double du = u / w - scene[i * 5 + 3], dv = v / w - scene[i * 5 + 4];
+                const bool in = usable && depth > 0.0 && (du * du + dv * dv < th2); // NaN poses compare false
+                cnt += in ? 1 : 0;
+                if (a.mask) a.mask[h * a.n_corr + base + i] = in ? 1 : 0;
+            }
+        }
+    }
+    if (live) a.count[h] = cnt;
+}
+
+} // namespace cvxs

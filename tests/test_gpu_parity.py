@@ -273,6 +273,63 @@ def test_ransac_wrapper_config5(gpu):
     assert out["status"] == 0
 
 
+def _score_numpy(R, t, K, x, X, thresh, status=None, usable=(0, 2)):
+    """Plain restatement of the inlier rule of include/cvxpnpl_amd.h (cvxpnpl_score_hypotheses); returns
+    (mask [H,M], margin [H,M]) where margin is the distance of the decision from its threshold."""
+    Xc = np.einsum("hij,mj->hmi", R, X) + t[:, None, :]
+    uvw = np.einsum("ij,hmj->hmi", K, Xc)
+    with np.errstate(all="ignore"):
+        uv = uvw[..., :2] / uvw[..., 2:3]
+        err = np.linalg.norm(uv - x[None], axis=-1)
+    mask = (err < thresh) & (Xc[..., 2] > 0)
+    if status is not None:
+        mask &= np.isin(status, usable)[:, None]
+    return mask, np.minimum(np.abs(err - thresh), np.abs(Xc[..., 2]))
+
+
+@pytest.mark.parametrize("n_hyp,n_corr", [(1, 100), (300, 100), (5000, 37), (70, 1300)])
+def test_score_hypotheses_kernel(gpu, n_hyp, n_corr):
+    """HIP scoring kernel vs a numpy restatement of the same rule: identical masks and counts (decisions
+    closer than 1e-9 px to the threshold excepted), statuses filtered, NaN poses score 0, LDS tiling (M > 512)."""
+    import torch
+
+    import cvxpnpl_amd as ca
+    from cvxpnpl_amd import synth
+
+    d = synth.make_ransac(1, n_corr=n_corr, outlier_frac=0.3, sigma=0.5, seed=46 + n_corr)
+    rs = np.random.RandomState(n_hyp)
+    # hypotheses: the true pose perturbed by 0 .. 2 degrees / 0 .. 5 % translation, some wild, some NaN
+    Rg, tg = d["R_gt"], d["t_gt"]
+    w = rs.randn(n_hyp, 3) * rs.uniform(0, 0.03, (n_hyp, 1))
+    th = np.linalg.norm(w, axis=1, keepdims=True) + 1e-300
+    k = w / th
+    Kx = np.zeros((n_hyp, 3, 3))
+    Kx[:, 0, 1], Kx[:, 0, 2], Kx[:, 1, 0], Kx[:, 1, 2], Kx[:, 2, 0], Kx[:, 2, 1] = -k[:, 2], k[:, 1], k[:, 2], -k[:, 0], -k[:, 1], k[:, 0]
+    dR = np.eye(3)[None] + np.sin(th)[..., None] * Kx + (1 - np.cos(th))[..., None] * (Kx @ Kx)
+    R = dR @ Rg[None]
+    t = tg[None] * (1 + rs.randn(n_hyp, 1) * 0.02)
+    status = rs.choice([0, 0, 0, 1, 2, 3, 4], n_hyp).astype(np.int32)
+    if n_hyp > 10:
+        R[3] = synth.random_poses(rs, 1)[0][0]  # unrelated pose
+        R[5, 1, 1] = np.nan
+        t[7, 0] = np.nan
+        t[9] = -tg  # behind the camera
+    cnt, mask = ca.score_hypotheses(torch.as_tensor(R, device=gpu), torch.as_tensor(t, device=gpu), d["K"], d["scene_2d"], d["scene_3d"],
+                                    thresh=2.0, status=torch.as_tensor(status, device=gpu), want_mask=True)
+    ref, margin = _score_numpy(R, t, d["K"], d["scene_2d"], d["scene_3d"], 2.0, status)
+    mask, cnt = mask.cpu().numpy().astype(bool), cnt.cpu().numpy()
+    clear = ~(margin < 1e-9) | ~np.isin(status, (0, 2))[:, None]
+    assert (mask == ref)[clear | ~np.isfinite(margin)].all()
+    assert (cnt == mask.sum(1)).all()
+    assert ref.sum() > 0
+    if n_hyp > 10:
+        assert cnt[5] == 0 and cnt[7] == 0 and cnt[9] == 0
+    # without statuses every finite hypothesis is scored
+    cnt2 = ca.score_hypotheses(torch.as_tensor(R, device=gpu), torch.as_tensor(t, device=gpu), d["K"], d["scene_2d"], d["scene_3d"], thresh=2.0)
+    ref2, _ = _score_numpy(R, t, d["K"], d["scene_2d"], d["scene_3d"], 2.0)
+    assert np.abs(cnt2.cpu().numpy() - ref2.sum(1)).max() <= 1
+
+
 def test_planar_scene_returns_both_poses_through_dropin_api(gpu):
     """A planar scene through cvxpnpl_amd.pnp: two poses, like the reference's rank-2 branch, the true
     one among them."""

@@ -23,6 +23,8 @@ prof default
 prof quad_24k --batch 24000
 prof hybrid_125k --workload pnp_n10_125k
 cd $root
+# condense the counter passes first, so that the bench lines below quote this build's traffic (profiles/pmc_traffic.json)
+python tools/collect_profiles.py $tag > /dev/null 2>&1
 # bench lines of the same build (full default run incl. cpu_baseline; the other configurations without)
 python bench.py > $out/bench_default.json 2> $out/bench_default.err
 python bench.py --batch 24000 --no-cpu-baseline > $out/bench_quad_24k.json 2>/dev/null
