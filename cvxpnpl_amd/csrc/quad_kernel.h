@@ -421,6 +421,7 @@ __global__ void __launch_bounds__(64, 2) solve_quad_kernel(WaveArgs a, cvx::Opts
     for (int i = 0; i < 10; ++i) v[i] = (gl == i) ? 1.0 : 0.0;
     int it = 0, total_sweeps = 0, next_check = o.first_check;
     bool have_prev = false;
+    int reused = 0; // consecutive checks that took over the previous check's pose (cvx::REUSE_MAX, see cvx::solve_sdp)
     double fprev = 0.0;
     bool done = !gvalid || !finite;
     bool parked = false; // this problem goes to the second phase
@@ -552,7 +553,8 @@ __global__ void __launch_bounds__(64, 2) solve_quad_kernel(WaveArgs a, cvx::Opts
                 double Rp[9];
 #pragma unroll
                 for (int i = 0; i < 9; ++i) Rp[i] = L[Q_M + 12 + i];
-                reuse = have_prev && cvx::rounds_to(vloc, Rp, d0);
+                reuse = have_prev && reused < cvx::REUSE_MAX && cvx::rounds_to(vloc, Rp, d0);
+                reused = reuse ? reused + 1 : 0;
             }
             // the four problems polish together; when none needs it (done, or the rounded candidate is the pose
             // the previous check already polished) the Newton iterations are skipped altogether

@@ -987,6 +987,8 @@ CVX_HD void canon_congruence(const Canon &cn, double *Z, bool to_canon)
 // needs N iterations a spacing s costs 0.4 N / s in failed attempts plus s / 2 iterations of overshoot
 // (minimal at s = sqrt(0.8 N)); starting before 10 delays too many ordinary problems.  The slow tail sets
 // the end of every launch: 1.37 -> 1.24 ms at 125 k problems, neutral at 10 k.
+constexpr int REUSE_MAX = 3; // consecutive certificate attempts that may take over the previous attempt's polished pose
+
 CVX_HD int next_check_after(int it, const Opts &o)
 {
     int s = 1 + (it >= 10) + (it >= 16) + (it >= 24) + (it >= 36) + (it >= 54) + (it >= 80) + (it >= 104) + (it >= 128);
@@ -1092,7 +1094,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
     double Rprev[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, fprev = 0;
     double Rk[2][9], fk[2] = {0, 0}; // the twins polished by the previous check (cvx::polish_or_reuse)
     bool hk[2] = {false, false};
-    int tw_reused = 0;
+    int tw_reused = 0, reused = 0;
     double fp_res = 1e300;
     while (!done) {
         if (handoff_at > 0 && it >= handoff_at) { // W is the iterate after `it` completed iterations
@@ -1155,13 +1157,20 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                 // 9 of 10 repeated checks polish to the pose the previous check already had (it was the dual
                 // that was not ready): when the candidate rounds to that rotation (rounds_to: within ~0.16 rad,
                 // 99.9 % of those polish back onto it) reuse it, skipping the polar and the Newton iterations
+                // The shortcut must not outlive its premise: two local minima can lie within the rounding
+                // tolerance of each other, and a pose taken over forever from an early check (or from before a
+                // spell in the twin branch) would then never be certified although the iterate has long
+                // converged to the other one.  So at most REUSE_MAX checks in a row reuse, and the twin branch
+                // invalidates the stored pose.
                 double d0;
-                if (have_prev && rounds_to(vt, Rprev, d0)) {
+                if (have_prev && reused < REUSE_MAX && rounds_to(vt, Rprev, d0)) {
                     CVX_UNROLL for (int i = 0; i < 9; ++i) c.R[i] = Rprev[i];
                     c.pobj = fprev;
+                    ++reused;
                 } else {
                     d0 = round_candidate(vt, c.R);
                     polish_rotation(Qs, c.R, c.pobj);
+                    reused = 0;
                 }
                 dual_certificate<TWIN>(Qs, W, Wp, rho, delta, d0, c);
                 have_prev = d0 > 0 && (c.pobj == c.pobj);
@@ -1169,6 +1178,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                 fprev = c.pobj;
             } else {
                 double zp[10], zm[10], fp;
+                have_prev = false; // (see above)
                 twin_candidates(vt, v2, zp, zm);
                 const bool may = tw_reused < 8; // every ninth check polishes afresh
                 const double dp = polish_or_reuse(Qs, zp, Rk[0], fk[0], may && hk[0], c.R, fp);

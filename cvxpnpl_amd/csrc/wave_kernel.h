@@ -679,6 +679,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
     double W = (lane == 54) ? 1.0 : 0.0, Wp = 0.0;
     int it = 0, total_sweeps = 0, next_check = o.first_check;
     bool have_prev = false; // L_M + 50.. holds the rotation polished by the previous check
+    int reused = 0;         // consecutive checks that took it over (at most cvx::REUSE_MAX, see cvx::solve_sdp)
     double fprev = 0.0;
     bool have_tp = false, have_tm = false; // L_M + 30.. / 40.. hold the twins polished by the previous twin check
     double f_tp = 0.0, f_tm = 0.0;
@@ -867,7 +868,8 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
                 double d0, Rp[9];
 #pragma unroll
                 for (int i = 0; i < 9; ++i) Rp[i] = L[L_M + 50 + i];
-                const bool reuse = have_prev && cvx::rounds_to(vloc, Rp, d0);
+                const bool reuse = have_prev && reused < cvx::REUSE_MAX && cvx::rounds_to(vloc, Rp, d0);
+                reused = reuse ? reused + 1 : 0;
                 CVXW_PH(PH_TOPSEL);
                 if (reuse) {
 #pragma unroll
@@ -889,6 +891,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
                     for (int i = 0; i < 9; ++i) L[L_M + 50 + i] = Rc[i];
                 }
             } else {
+                have_prev = false; // the pose of the last single-candidate check is stale after a spell here
                 // z+- = (c1 +- d1) v1 + (c2 +- d2) v2: last entry 1, squared norm 4
                 const double ta = L[L_V + 9], tb = L[L_V + 19], n2 = ta * ta + tb * tb;
                 const double inv = cvx::rcp(n2), rn = cvx::rsqrt_(n2), rad = 4.0 - inv;

@@ -264,3 +264,22 @@ def test_planar_scene_in_a_general_frame_is_solved_in_the_canonical_one():
         assert min(synth.geodesic(R, d["R_gt"][i]) + np.linalg.norm(t - d["t_gt"][i]) for R, t in poses) < 1e-8
         # the pose returned with status 1 is one of the two twins, in the caller's frame
         assert min(synth.geodesic(hs["R"][i], R) for R, t in poses) < 1e-8
+
+
+STALE_REUSE_CASES = [(9, 1, 2.0, 5012, 100), (5, 0, 0.0, 5005, 91), (0, 5, 2.0, 5023, 18)]
+
+
+@pytest.mark.parametrize("n_p,n_l,sigma,seed,i", STALE_REUSE_CASES)
+def test_pose_reuse_does_not_go_stale(n_p, n_l, sigma, seed, i):
+    """Found by tools/fuzz_parity.py: two local minima within the rounding tolerance of cvx::rounds_to.  A pose
+    polished at an early check (before a spell in the twin branch) used to be taken over by every later
+    check, so the problem ran to res_tol uncertified (status 2 after 218-248 iterations, pose 1e-4 rad off)
+    although the iterate had converged to the certifiable optimum.  The shortcut is now bounded (REUSE_MAX)."""
+    from cvxpnpl_amd import synth
+
+    d = synth.make_pnpl(192, n_p, n_l, sigma, seed=seed)
+    sl = slice(i, i + 1)
+    r = hostsim.solve_batch(d["pts_2d"][sl] if n_p else None, d["pts_3d"][sl] if n_p else None, d["line_2d"][sl] if n_l else None,
+                            d["line_3d"][sl] if n_l else None, d["K"])
+    assert r["status"][0] == 0 and r["iters"][0] < 60
+    assert 0 <= r["cost"][0, 0] - r["cost"][0, 1] <= 1e-9

@@ -273,6 +273,24 @@ def test_ransac_wrapper_config5(gpu):
     assert out["status"] == 0
 
 
+@pytest.mark.parametrize("layout", sorted(LAYOUTS))
+def test_pose_reuse_does_not_go_stale(gpu, orc, layout):
+    """Regression (tools/fuzz_parity.py): problems with two local minima within the rounding tolerance of the
+    pose-reuse shortcut ended uncertified in the wave layout; every layout certifies them and agrees with the
+    oracle (see tests/test_device_algorithm_hostsim.py::test_pose_reuse_does_not_go_stale)."""
+    from cvxpnpl_amd import synth
+
+    for n_p, n_l, sigma, seed, i in [(9, 1, 2.0, 5012, 100), (5, 0, 0.0, 5005, 91), (0, 5, 2.0, 5023, 18)]:
+        d = synth.make_pnpl(192, n_p, n_l, sigma, seed=seed)
+        r = _solve(gpu, d, n_p, n_l, layout=LAYOUTS[layout])
+        assert r["status"][i] == 0, (n_p, n_l, r["status"][i], r["iters"][i])
+        sl = slice(i, i + 1)
+        o = orc.pnpl_batch(d["pts_2d"][sl] if n_p else None, d["line_2d"][sl] if n_l else None, d["pts_3d"][sl] if n_p else None,
+                           d["line_3d"][sl] if n_l else None, d["K"], eps=1e-11, max_iters=200000)
+        assert o["n_poses"][0] == 1
+        assert synth.geodesic(r["R"][sl], o["R"][:, 0])[0] < TOL_ROT
+
+
 def _score_numpy(R, t, K, x, X, thresh, status=None, usable=(0, 2)):
     """Plain restatement of the inlier rule of include/cvxpnpl_amd.h (cvxpnpl_score_hypotheses); returns
     (mask [H,M], margin [H,M]) where margin is the distance of the decision from its threshold."""
