@@ -126,7 +126,7 @@ int cvxpnpl_assemble_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, c
  * SURVEY.md section 8(f) row 3 -- the reference has no RANSAC, this is the consumer of its minimal solves).
  * DEVICE pointers.  d_R [n_hyp][9] row-major, d_t [n_hyp][3] (outputs of cvxpnpl_solve_batch), d_status
  * [n_hyp] or NULL; usable_mask: bit s set = hypotheses of status s are scored, the others get 0 (ignored
- * when d_status is NULL; 0x5 = CERTIFIED | RANK_GT1).  d_K [9]; scene d_pts_2d [n_corr][2] pixels,
+ * when d_status is NULL; 0x5 = CERTIFIED | UNCERTIFIED, the rank-1 poses).  d_K [9]; scene d_pts_2d [n_corr][2] pixels,
  * d_pts_3d [n_corr][3].  Correspondence m is an inlier of hypothesis h when (R P + t)_z > 0 and its
  * reprojection K (R P + t) lies within thresh_px of the measured pixel.  d_count [n_hyp] inlier counts;
  * d_mask [n_hyp][n_corr] (0/1) or NULL.  Non-finite poses score 0.  Returns 0, -1 for bad arguments.
