@@ -1163,14 +1163,15 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                 // converged to the other one.  So at most REUSE_MAX checks in a row reuse, and the twin branch
                 // invalidates the stored pose.
                 double d0;
-                if (have_prev && reused < REUSE_MAX && rounds_to(vt, Rprev, d0)) {
+                // (TWIN = false is the lane phase of the hybrid schedule: at most two checks, nothing to bound)
+                if (have_prev && (!TWIN || reused < REUSE_MAX) && rounds_to(vt, Rprev, d0)) {
                     CVX_UNROLL for (int i = 0; i < 9; ++i) c.R[i] = Rprev[i];
                     c.pobj = fprev;
-                    ++reused;
+                    if (TWIN) ++reused;
                 } else {
                     d0 = round_candidate(vt, c.R);
                     polish_rotation(Qs, c.R, c.pobj);
-                    reused = 0;
+                    if (TWIN) reused = 0;
                 }
                 dual_certificate<TWIN>(Qs, W, Wp, rho, delta, d0, c);
                 have_prev = d0 > 0 && (c.pobj == c.pobj);
