@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="problems in the CPU baseline sample (0 = auto)")
     ap.add_argument("--layout", type=int, default=0, help="kernel layout (0 auto, 1 lane/hybrid, 2 wave, 3 quad/hybrid)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of results when --gpus > 1")
+    ap.add_argument("--force-dist", action="store_true", help="diagnostics: run the RCCL path (process group, packed all_gather) "
+                    "even with one rank, to measure / smoke-test it on a 1-GPU box")
     ap.add_argument("--opt", action="append", default=[], help="solver option override name=value (diagnostics)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the steps are issued round-robin on (1 = the contract's "
                     "back-to-back steps; >1 lets independent batches overlap, reported in config)")
@@ -78,8 +80,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU; cvxpnpl_amd has no CPU fallback"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n_p, n_l, batch, sigma = WORKLOADS[args.workload]
@@ -110,7 +114,7 @@ def main():
 
     from cvxpnpl_amd import dist as cdist
 
-    gather = world > 1 and not args.no_gather
+    gather = dist_on and not args.no_gather
     gathered = torch.empty((world * batch, cdist.PACK), dtype=torch.float64, device=dev) if gather else None
     nstreams = max(1, args.streams)
     streams = [stream] + [torch.cuda.Stream(dev) for _ in range(nstreams - 1)]
@@ -141,7 +145,7 @@ def main():
     def barrier():
         while pending:
             pending.pop()[0].wait()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -168,7 +172,7 @@ def main():
         launch_ms = [ms.value / args.steps]
     for e in ev:
         L.cvxpnpl_event_destroy(e)
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -260,11 +264,31 @@ def main():
             "max_rot_diff_vs_gpu_rad": float(synth.geodesic(Rg, o["R"][:, 0])[both].max()) if both.any() else None,
             "converged_frac": float((o["iters"] < 2500).mean()),
         }
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
+    return out if rank == 0 else None
+
+
+def _only_json_on_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries print there too (RCCL writes its version banner
+    to stdout through C stdio, which a pipe flushes at exit, i.e. AFTER the JSON line): everything the run
+    prints goes to stderr, and only the final line is written to the real stdout."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        out = main()
+    finally:
+        sys.stdout.flush()
+        try:
+            C.CDLL(None).fflush(None)  # C stdio buffers (the RCCL banner) -> stderr, before stdout is restored
+        except OSError:
+            pass
+        os.dup2(real, 1)
+        os.close(real)
+    if out is not None:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
-    main()
+    _only_json_on_stdout()

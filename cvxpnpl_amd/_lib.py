@@ -17,7 +17,7 @@ _ip = C.POINTER(C.c_int32)
 # every symbol include/cvxpnpl_amd.h declares
 EXPORTS = (
     "cvxpnpl_default_opts", "cvxpnpl_solve_batch", "cvxpnpl_recover_multi", "cvxpnpl_recover_multi_batch", "cvxpnpl_assemble_batch",
-    "cvxpnpl_score_hypotheses",
+    "cvxpnpl_score_hypotheses", "cvxpnpl_pack_results",
     "cvxpnpl_event_create", "cvxpnpl_event_record", "cvxpnpl_event_elapsed_ms", "cvxpnpl_event_destroy",
     "cvxpnpl_last_error", "cvxpnpl_version", "cvxpnpl_device_count",
 )
@@ -65,6 +65,8 @@ def lib():
     L.cvxpnpl_recover_multi.restype = C.c_int
     L.cvxpnpl_recover_multi_batch.argtypes = [C.c_int64, _ip, _dp, _dp, _dp, _dp, _dp, _ip, C.c_int32]
     L.cvxpnpl_recover_multi_batch.restype = C.c_int
+    L.cvxpnpl_pack_results.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cvxpnpl_pack_results.restype = C.c_int
     L.cvxpnpl_score_hypotheses.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int32,
                                            C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cvxpnpl_score_hypotheses.restype = C.c_int

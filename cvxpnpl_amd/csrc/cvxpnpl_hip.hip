@@ -63,6 +63,16 @@ __global__ void __launch_bounds__(64) solve_lane_kernel(BatchArgs a, cvx::Opts o
     }
 }
 
+// results of one shard as the 13-doubles-per-pose records the multi-GPU gather exchanges: R (9, row-major), t (3), status
+__global__ void __launch_bounds__(256) pack_kernel(int64_t batch, const double *R, const double *t, const int32_t *status, double *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= batch * 13) return;
+    const int64_t b = i / 13;
+    const int k = (int)(i - b * 13);
+    out[i] = k < 9 ? R[b * 9 + k] : (k < 12 ? t[b * 3 + (k - 9)] : (double)status[b]);
+}
+
 __global__ void __launch_bounds__(64) assemble_kernel(BatchArgs a, double *Bout, double *Qout)
 {
     int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -236,6 +246,18 @@ int cvxpnpl_assemble_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, c
     hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((batch + block - 1) / block)), dim3(block), 0, (hipStream_t)stream, a, d_B, d_Q45);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err("assemble_kernel launch", e);
+    return 0;
+}
+
+int cvxpnpl_pack_results(int64_t batch, const double *d_R, const double *d_t, const int32_t *d_status, double *d_packed, void *stream)
+{
+    if (batch < 0 || !d_R || !d_t || !d_status || !d_packed) { snprintf(g_err, sizeof(g_err), "cvxpnpl_pack_results: bad arguments"); return -1; }
+    if (batch == 0) return 0;
+    const int64_t n = batch * 13, grid = (n + 255) / 256;
+    if (grid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl_pack_results: batch too large for one launch"); return -1; }
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, batch, d_R, d_t, d_status, d_packed);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err("pack_kernel launch", e);
     return 0;
 }
 

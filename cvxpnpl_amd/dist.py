@@ -23,8 +23,24 @@ def shard_range(batch: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def pack_results(R: torch.Tensor, t: torch.Tensor, status: torch.Tensor) -> torch.Tensor:
+    """[n, 13] float64 records (R row-major, t, status) of one shard.  Device tensors: one HIP launch
+    (cvxpnpl_pack_results) on the current stream; host tensors (the gloo tests of the sharding logic): torch ops."""
     n = R.shape[0]
     out = torch.empty((n, PACK), dtype=torch.float64, device=R.device)
+    if R.is_cuda and n > 0:
+        import ctypes as C
+
+        from . import _lib
+
+        Rc, tc, sc = R.contiguous(), t.contiguous(), status.to(torch.int32).contiguous()
+        with torch.cuda.device(R.device):
+            rc = _lib.lib().cvxpnpl_pack_results(n, C.c_void_p(Rc.data_ptr()), C.c_void_p(tc.data_ptr()), C.c_void_p(sc.data_ptr()),
+                                                 C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(R.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"cvxpnpl_pack_results failed ({rc}): {_lib.last_error()}")
+        return out
+    if n == 0:
+        return out
     out[:, :9] = R.reshape(n, 9)
     out[:, 9:12] = t
     out[:, 12] = status.to(torch.float64)

@@ -121,6 +121,10 @@ int cvxpnpl_assemble_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, c
                            const double *d_line_2d, const double *d_line_3d, const double *d_K, int32_t K_per_problem,
                            double *d_B, double *d_Q45, void *stream);
 
+/* Results of one shard as the [batch][13] float64 records the multi-GPU gather exchanges (north-star config 4):
+ * R (9, row-major), t (3), status.  DEVICE pointers; one launch on `stream`.  Returns 0, -1 for bad arguments. */
+int cvxpnpl_pack_results(int64_t batch, const double *d_R, const double *d_t, const int32_t *d_status, double *d_packed, void *stream);
+
 /*
  * Consensus scoring of pose hypotheses against one scene (RANSAC on top of the solver: BASELINE config 5;
  * SURVEY.md section 8(f) row 3 -- the reference has no RANSAC, this is the consumer of its minimal solves).

@@ -44,6 +44,8 @@ def test_bad_arguments_are_rejected_without_gpu(L):
     rc = L.cvxpnpl_solve_batch(4, 0, None, None, 0, None, None, None, 0, C.byref(o), None, None, None, None, None, None, None, None)
     assert rc == -1 and b"bad arguments" in L.cvxpnpl_last_error()
     assert b"gfx950" in L.cvxpnpl_version()
+    rc = L.cvxpnpl_pack_results(8, None, None, None, None, None)
+    assert rc == -1 and b"cvxpnpl_pack_results: bad arguments" in L.cvxpnpl_last_error()
     rc = L.cvxpnpl_score_hypotheses(8, None, None, None, 5, None, 10, None, None, 2.0, None, None, None)
     assert rc == -1 and b"cvxpnpl_score_hypotheses: bad arguments" in L.cvxpnpl_last_error()
 

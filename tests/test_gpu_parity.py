@@ -291,6 +291,29 @@ def test_pose_reuse_does_not_go_stale(gpu, orc, layout):
         assert synth.geodesic(r["R"][sl], o["R"][:, 0])[0] < TOL_ROT
 
 
+def test_pack_results_kernel_matches_host_packing(gpu):
+    """cvxpnpl_pack_results (the [n,13] records the multi-GPU gather exchanges) is bit-identical to the torch
+    packing the gloo tests use on host tensors; ragged size, statuses 0..4, NaN poses kept."""
+    import torch
+
+    from cvxpnpl_amd import dist as cd
+
+    g = torch.Generator().manual_seed(3)
+    n = 1237
+    R = torch.randn((n, 3, 3), generator=g, dtype=torch.float64)
+    t = torch.randn((n, 3), generator=g, dtype=torch.float64)
+    st = torch.randint(0, 5, (n,), generator=g, dtype=torch.int32)
+    R[5] = float("nan")
+    host = cd.pack_results(R, t, st)
+    devp = cd.pack_results(R.to(gpu), t.to(gpu), st.to(gpu))
+    assert devp.shape == (n, cd.PACK) and devp.is_cuda
+    a, b = host.numpy(), devp.cpu().numpy()
+    assert np.array_equal(a, b, equal_nan=True)
+    R2, t2, st2 = cd.unpack_results(devp)
+    assert torch.equal(st2.cpu(), st) and torch.equal(t2.cpu(), t)
+    assert cd.pack_results(R[:0].to(gpu), t[:0].to(gpu), st[:0].to(gpu)).shape == (0, cd.PACK)
+
+
 def _score_numpy(R, t, K, x, X, thresh, status=None, usable=(0, 2)):
     """Plain restatement of the inlier rule of include/cvxpnpl_amd.h (cvxpnpl_score_hypotheses); returns
     (mask [H,M], margin [H,M]) where margin is the distance of the decision from its threshold."""
