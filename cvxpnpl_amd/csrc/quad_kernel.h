@@ -213,7 +213,9 @@ __device__ __forceinline__ double quad_ldl(double *L, const Own &w, double *Me)
 // its own and leaves that of the quad phase alone; nothing but the kernel arguments is live across the call.
 // (The by-reference arguments cost the caller a 200 B/lane copy to scratch.  Re-reading them from the kernarg
 // segment inside the callee instead: the segment pointer is null there; handing that pointer down: scalar
-// loads, but the callee's frame grows from 136 to 588 B -- no gain, not kept.)
+// loads, but the callee's frame grows from 136 to 588 B -- no gain, not kept.  Through LDS (lane 0 stores the
+// block, the callee reads it back, with or without readfirstlane into scalar registers): the kernel's own
+// frame drops to 192 B but the callee's grows to 492 / 552 B -- no gain either.)
 __device__ __forceinline__ void park(double *p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __noinline__ void finish_own(const WaveArgs &a, const cvx::Opts &o, unsigned parked, const double *ws, double *lds)
 {
