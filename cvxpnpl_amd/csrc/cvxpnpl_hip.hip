@@ -33,7 +33,7 @@ struct BatchArgs {
 // Hybrid schedule: a lane that is not finished by then parks its iterate in ws[b] and queues b for
 // resume_wave_kernel, so that one slow problem cannot hold the other 63 lanes (and the whole launch)
 // for hundreds of lane-serial iterations.
-__global__ void __launch_bounds__(64) solve_lane_kernel(BatchArgs a, cvx::Opts o, int handoff_at, int32_t *queue, double *ws)
+__global__ void __launch_bounds__(64) solve_lane_kernel(BatchArgs a, cvx::Opts o, int handoff_at, int32_t *qcount, int32_t *qentries, double *ws)
 {
     __shared__ double lds_const[72 * 64];
     int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -45,8 +45,8 @@ __global__ void __launch_bounds__(64) solve_lane_kernel(BatchArgs a, cvx::Opts o
     // The cost matrix and the translation map (72 doubles) live in this lane's LDS column, not in registers.
     cvx::solve_problem<false, cvx::LdsStore>(pv, o, sol, a.Z ? Z : nullptr, handoff_at, ws + b * 56, cvx::LdsStore{lds_const + threadIdx.x});
     if (sol.status == -1) {
-        const int q = atomicAdd(&queue[0], 1);
-        queue[1 + q] = (int32_t)b;
+        const int q = atomicAdd(qcount, 1);
+        qentries[q] = (int32_t)b;
         return;
     }
 #pragma unroll
@@ -85,13 +85,16 @@ __global__ void __launch_bounds__(64) assemble_kernel(BatchArgs a, double *Bout,
         for (int i = 0; i < 45; ++i) Qout[b * 45 + i] = ok ? Q9[i] : NAN;
 }
 
-// grow-only scratch for the hybrid schedule, one per (device, stream): queue [1 + batch] int32 and
-// parked iterates [batch][56] doubles (only the slots of handed-off problems are touched)
-struct Workspace { void *ptr = nullptr; size_t bytes = 0; };
+// grow-only scratch for the hybrid schedules, one per (device, stream): two alternating queue counters, the queue
+// entries [batch] int32 and the parked iterates [batch][56] doubles (only the slots of parked problems are touched)
+struct Workspace { void *ptr = nullptr; size_t bytes = 0; unsigned calls = 0; };
 std::mutex g_ws_mutex;
+std::mutex g_launch_mutex; // held while a hybrid schedule is enqueued: the counter alternation below follows enqueue order
 std::map<std::pair<int, void *>, Workspace> g_ws;
 
-void *get_workspace(size_t bytes, void *stream)
+// The first 256 bytes of a fresh allocation are zeroed on the stream (the two alternating queue counters of
+// the quad schedule live there); *calls counts the launches that used the allocation (the alternation).
+void *get_workspace(size_t bytes, void *stream, unsigned *calls = nullptr)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
@@ -99,10 +102,13 @@ void *get_workspace(size_t bytes, void *stream)
     Workspace &w = g_ws[std::make_pair(dev, stream)];
     if (w.bytes < bytes) {
         if (w.ptr) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(w.ptr); }
-        w.ptr = nullptr; w.bytes = 0;
+        w.ptr = nullptr; w.bytes = 0; w.calls = 0;
+        if (bytes < 256) bytes = 256;
         if (hipMalloc(&w.ptr, bytes) != hipSuccess) return nullptr;
+        if (hipMemsetAsync(w.ptr, 0, 256, (hipStream_t)stream) != hipSuccess) { (void)hipFree(w.ptr); w.ptr = nullptr; return nullptr; }
         w.bytes = bytes;
     }
+    if (calls) *calls = w.calls++;
     return w.ptr;
 }
 
@@ -189,11 +195,22 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
     if (layout == CVXPNPL_LAYOUT_QUAD && !(quad_iters >= 1 && o.max_iters > quad_iters)) layout = CVXPNPL_LAYOUT_WAVE;
     if (layout == CVXPNPL_LAYOUT_QUAD) {
         // four problems per wavefront for the first quad_iters iterations, survivors resumed one per wavefront
-        // (one kernel: a wavefront finishes its own survivors, no queue and no second launch)
-        double *ws = (double *)get_workspace((size_t)batch * 56 * sizeof(double), stream);
-        if (!ws) { snprintf(g_err, sizeof(g_err), "cvxpnpl: workspace allocation failed"); return -2; }
+        // (a wavefront finishes its own survivors; only planar scenes, recognised before the first iteration,
+        // are queued for the resume kernel behind it -- an empty queue costs that launch a few microseconds.
+        // Two queue counters alternate between launches: the resume kernel of one launch zeroes the counter of
+        // the next, which saves a memset per call.)
+        const size_t qbytes = ((size_t)(batch + 64) * sizeof(int32_t) + 255) & ~(size_t)255;
+        unsigned calls = 0;
+        std::lock_guard<std::mutex> launch_lock(g_launch_mutex);
+        char *wsp = (char *)get_workspace(qbytes + (size_t)batch * 56 * sizeof(double), stream, &calls);
+        if (!wsp) { snprintf(g_err, sizeof(g_err), "cvxpnpl: workspace allocation failed"); return -2; }
+        int32_t *qbase = (int32_t *)wsp; // [0], [32]: the two counters (separate cache lines); [64 ..]: entries
+        int32_t *count = qbase + 32 * (calls & 1u), *next_count = qbase + 32 * ((calls + 1) & 1u), *entries = qbase + 64;
+        double *ws = (double *)(wsp + qbytes);
         const int64_t qgrid = (batch + 3) / 4;
-        hipLaunchKernelGGL(cvxq::solve_quad_kernel, dim3((unsigned)qgrid), dim3(64), 0, s, w, o, quad_iters, ws);
+        hipLaunchKernelGGL(cvxq::solve_quad_kernel, dim3((unsigned)qgrid), dim3(64), 0, s, w, o, quad_iters, count, entries, ws);
+        const int64_t rgrid = batch < 8192 ? batch : 8192;
+        hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64 * cvxw::WPB), 0, s, w, o, (const int32_t *)count, (const int32_t *)entries, ws, next_count);
     } else if (layout == CVXPNPL_LAYOUT_WAVE) {
         int64_t wgrid = (batch + cvxw::WPB - 1) / cvxw::WPB;
         if (wgrid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }
@@ -211,16 +228,17 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
         if (lane_iters > 5) lane_iters = 5;
         if (o.max_iters > lane_iters) {
             // hybrid: lanes for the first lane_iters iterations, survivors resumed one per wavefront
-            const size_t qbytes = ((size_t)(batch + 1) * sizeof(int32_t) + 255) & ~(size_t)255;
-            char *wsp = (char *)get_workspace(qbytes + (size_t)batch * 56 * sizeof(double), stream);
+            const size_t qbytes = ((size_t)(batch + 64) * sizeof(int32_t) + 255) & ~(size_t)255;
+            unsigned calls = 0;
+            std::lock_guard<std::mutex> launch_lock(g_launch_mutex);
+            char *wsp = (char *)get_workspace(qbytes + (size_t)batch * 56 * sizeof(double), stream, &calls);
             if (!wsp) { snprintf(g_err, sizeof(g_err), "cvxpnpl: workspace allocation failed"); return -2; }
-            int32_t *queue = (int32_t *)wsp;
+            int32_t *qbase = (int32_t *)wsp; // alternating counters at [0] and [32], entries from [64] (see the quad schedule)
+            int32_t *count = qbase + 32 * (calls & 1u), *next_count = qbase + 32 * ((calls + 1) & 1u), *entries = qbase + 64;
             double *ws = (double *)(wsp + qbytes);
-            hipError_t me = hipMemsetAsync(queue, 0, sizeof(int32_t), s);
-            if (me != hipSuccess) return set_err("hipMemsetAsync", me);
-            hipLaunchKernelGGL(solve_lane_kernel, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, queue, ws);
+            hipLaunchKernelGGL(solve_lane_kernel, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws);
             const int64_t rgrid = batch < 8192 ? batch : 8192;
-            hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64 * cvxw::WPB), 0, s, w, o, queue, ws);
+            hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64 * cvxw::WPB), 0, s, w, o, (const int32_t *)count, (const int32_t *)entries, ws, next_count);
         } else {
             // fewer iterations allowed than the lane phase would run: the wave kernel does the whole solve
             int64_t wgrid = (batch + cvxw::WPB - 1) / cvxw::WPB;

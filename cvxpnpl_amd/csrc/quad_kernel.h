@@ -14,7 +14,8 @@
 // The kernel runs the first `handoff_at` ADMM iterations (certificate attempts from first_check on);
 // the few problems that are not certified by then park their iterate in ws[] and the wavefront finishes them
 // itself, one at a time, in the wave-per-problem layout (cvxw::solve_one_wave: twin candidates, slow tails
-// and the reference's uncertified exits live there).
+// and the reference's uncertified exits live there).  Planar scenes are the exception: recognised before the
+// first iteration, they are queued for cvxw::resume_wave_kernel, launched behind this kernel.
 // Mathematics identical to solver_core.h / wave_kernel.h; see those files for the derivations.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -227,7 +228,7 @@ __device__ __noinline__ void finish_own(const WaveArgs &a, const cvx::Opts &o, u
     }
 }
 
-__global__ void __launch_bounds__(64, 2) solve_quad_kernel(WaveArgs a, cvx::Opts o, int handoff_at, double *ws)
+__global__ void __launch_bounds__(64, 2) solve_quad_kernel(WaveArgs a, cvx::Opts o, int handoff_at, int32_t *qcount, int32_t *qentries, double *ws)
 {
     __shared__ __attribute__((aligned(16))) double lds_all[4 * QLDS];
     const int lane = threadIdx.x & 63, gl = lane & 15, grp = lane >> 4;
@@ -429,12 +430,19 @@ __global__ void __launch_bounds__(64, 2) solve_quad_kernel(WaveArgs a, cvx::Opts
     bool parked = false; // this problem goes to the second phase
     const double tol2 = o.jacobi_tol * o.jacobi_tol;
     CVXW_SYNC();
-    if (!done && planar_handoff) {
+    if (!done && (planar_handoff || symm)) {
+        // A planar scene (general or canonical frame) is two-fold ambiguous: rank 2, nothing for this layout to
+        // certify, and the slow ones among them run for hundreds of iterations.  They go to the queue of
+        // cvxw::resume_wave_kernel (launched behind this kernel), one wavefront each, scheduled dynamically:
+        // finishing them here, four in a row per wavefront, was 1.6x slower on a planar batch.
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-            if (w.ok[m]) park(ws + b * 56 + w.e[m], W[m]);
-        if (gl == 0) park(ws + b * 56 + 55, 0.0);
-        parked = true;
+            if (w.ok[m]) ws[b * 56 + w.e[m]] = W[m];
+        if (gl == 0) {
+            ws[b * 56 + 55] = 0.0;
+            const int q = atomicAdd(qcount, 1);
+            qentries[q] = (int32_t)b;
+        }
         done = true;
     }
 

@@ -1112,15 +1112,17 @@ __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx
     solve_one_wave(a, o, b, lds_all[wib], nullptr);
 }
 
-// Second phase of the hybrid schedule: the problems the lane-layout kernel did not finish within
-// its iteration cap, listed in queue[1 .. queue[0]], each resumed by one wavefront.
-__global__ void __launch_bounds__(64 * WPB, 2) resume_wave_kernel(WaveArgs a, cvx::Opts o, const int32_t *queue, const double *ws)
+// Second phase of the hybrid schedules: the problems the first kernel parked, entries[0 .. *count), each resumed
+// by one wavefront.  zero_next (optional): the counter the NEXT launch on this stream will use (quad schedule).
+__global__ void __launch_bounds__(64 * WPB, 2) resume_wave_kernel(WaveArgs a, cvx::Opts o, const int32_t *count_p, const int32_t *entries, const double *ws,
+                                                                   int32_t *zero_next)
 {
     __shared__ __attribute__((aligned(16))) double lds_all[WPB][LDSW];
     const int wib = threadIdx.x >> 6;
-    const int count = queue[0];
+    const int count = *count_p;
+    if (zero_next && blockIdx.x == 0 && threadIdx.x == 0) *zero_next = 0;
     for (int q = blockIdx.x * WPB + wib; q < count; q += gridDim.x * WPB) { // wave-uniform
-        const int64_t b = queue[1 + q];
+        const int64_t b = entries[q];
         solve_one_wave(a, o, b, lds_all[wib], ws + b * 56);
         CVXW_SYNC();
     }

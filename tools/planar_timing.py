@@ -16,7 +16,7 @@ for batch, sigma in ((10000, 0.0), (10000, 1.0)):
     rs = np.random.RandomState(5)
     d["pts_2d"] = synth.project(d["pts_3d"], d["K"], d["R_gt"], d["t_gt"]) + rs.normal(scale=sigma, size=d["pts_2d"].shape)
     dev = {k: torch.as_tensor(v, device="cuda") for k, v in d.items() if k in ("pts_2d", "pts_3d", "K")}
-    for layout in (1, 2):
+    for layout in (1, 2, 3, 0):
         ca.pnp_batch(dev["pts_2d"], dev["pts_3d"], dev["K"], layout=layout)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
