@@ -216,12 +216,10 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
         if (wgrid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }
         hipLaunchKernelGGL(cvxw::solve_wave_kernel, dim3((unsigned)wgrid), dim3(64 * cvxw::WPB), 0, s, w, o);
     } else {
-        // hand-off point of the hybrid schedule (<= 0: by batch size): small launches leave spare SIMDs, so the
-        // lanes hand over right after the first certificate attempt (iteration 4) and the waves do more; big
-        // launches keep the cheap lane layout for 5 iterations (measured optimum from 24 k problems; 6 and 7
-        // are slower: 110 / 105 / 100 M poses/s at 125 k).
+        // hand-off point of the hybrid schedule (<= 0: default): right after the first certificate attempt, which
+        // comes at iteration 5 (opts.first_check) -- 6 and 7 are slower: 110 / 105 / 100 M poses/s at 125 k.
         int lane_iters = opts ? opts->lane_iters : -1;
-        if (lane_iters <= 0) lane_iters = batch < 24576 ? 4 : 5;
+        if (lane_iters <= 0) lane_iters = 5;
         // The lane phase never runs past 5 iterations: from the sixth on the few problems still open are the
         // slow / ambiguous ones (twin candidates, tails), which belong to the wave-per-problem kernel -- one of
         // them would hold 63 idle lanes, so the lane kernel is built without that logic.

@@ -70,7 +70,7 @@ CVX_HD Opts default_opts()
 {
     Opts o;
     o.eps = 1e-9; o.max_iters = 2500; o.rho = 0.1; o.alpha = 1.4;
-    o.first_check = 4; o.check_every = 1; o.res_tol = 1e-5; o.jacobi_sweeps = 12; o.jacobi_tol = 6e-2; o.warm_start = 1; o.rho_tail = 0.05; o.tail_from = 3;
+    o.first_check = 5; o.check_every = 1; o.res_tol = 1e-5; o.jacobi_sweeps = 12; o.jacobi_tol = 6e-2; o.warm_start = 1; o.rho_tail = 0.05; o.tail_from = 3;
     return o;
 }
 

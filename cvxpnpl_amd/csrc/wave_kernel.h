@@ -702,7 +702,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
             W = acc;
         }
         it = (int)rd(55);
-        next_check = it + 1;
+        next_check = it + 1 > o.first_check ? it + 1 : o.first_check;
         cold = true;
         if (o.tail_from > 0 && it >= o.tail_from) { rho = o.rho_tail; irho = 1.0 / rho; }
     }

@@ -51,7 +51,7 @@ typedef struct {
     int32_t max_iters; /* iteration cap; reference `max_iters` (cvxpnpl.py:528), default 2500 */
     double rho;        /* ADMM penalty on the trace-normalised cost, default 0.1 */
     double alpha;      /* over-relaxation, default 1.4 */
-    int32_t first_check; /* first certification attempt after this many iterations, default 4 */
+    int32_t first_check; /* first certification attempt after this many iterations, default 5 */
     int32_t check_every; /* then every this many, default 1 */
     double res_tol;    /* fixed-point residual at which an uncertifiable problem stops, default 1e-5 */
     int32_t jacobi_sweeps; /* cap on Jacobi sweeps per PSD projection, default 12 */
@@ -60,7 +60,7 @@ typedef struct {
     double rho_tail;    /* penalty from iteration tail_from on (dual rescaled at the switch), default 0.05 */
     int32_t tail_from;  /* default 3; <= 0 never */
     int32_t lane_iters; /* lane and quad layouts: iterations before unfinished problems are handed to one
-                           wavefront each (hybrid schedule).  <= 0: default (lane: 4 or 5 by batch size;
+                           wavefront each (hybrid schedule).  <= 0: default (lane: 5;
                            quad: 10).  The lane phase is capped at 5 iterations. */
     int32_t layout;    /* CVXPNPL_LAYOUT_* */
 } cvxpnpl_opts_t;
