@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--workload", default="pnp_n10_10k", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override problems per GPU per step")
     ap.add_argument("--sigma", type=float, default=None, help="pixel noise of the synthetic problems")
+    ap.add_argument("--seed", type=int, default=42, help="seed of the synthetic problems (diagnostics: the default is the judged workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="skip the extra two-stream (overlapped batches) measurement")
     ap.add_argument("--cpu-sample", type=int, default=0, help="problems in the CPU baseline sample (0 = auto)")
@@ -92,7 +93,7 @@ def main():
     L = _lib.lib()
 
     # synthetic inputs, resident in HBM before the timed region (distinct per rank)
-    d = synth.make_pnpl(batch, n_p, n_l, sigma, seed=42 + 1000 * rank)
+    d = synth.make_pnpl(batch, n_p, n_l, sigma, seed=args.seed + 1000 * rank)
     tt = lambda x: torch.as_tensor(x, device=dev).contiguous()  # noqa: E731
     p2, p3 = (tt(d["pts_2d"]), tt(d["pts_3d"])) if n_p else (None, None)
     l2, l3 = (tt(d["line_2d"]), tt(d["line_3d"])) if n_l else (None, None)

@@ -70,7 +70,7 @@ CVX_HD Opts default_opts()
 {
     Opts o;
     o.eps = 1e-9; o.max_iters = 2500; o.rho = 0.1; o.alpha = 1.4;
-    o.first_check = 5; o.check_every = 1; o.res_tol = 1e-5; o.jacobi_sweeps = 12; o.jacobi_tol = 6e-2; o.warm_start = 1; o.rho_tail = 0.05; o.tail_from = 3;
+    o.first_check = 5; o.check_every = 2; o.res_tol = 1e-5; o.jacobi_sweeps = 12; o.jacobi_tol = 6e-2; o.warm_start = 1; o.rho_tail = 0.05; o.tail_from = 3;
     return o;
 }
 
@@ -982,11 +982,18 @@ CVX_HD void canon_congruence(const Canon &cn, double *Z, bool to_canon)
 // ---------------------------------------------------------------------------------------
 // the solve
 
-// certification attempts: at first_check, then every iteration up to 10 (99.8 % of N = 10 problems finish by
-// then), then spaced more and more widely, ~sqrt(it).  An attempt costs ~0.4 iterations; for a problem that
-// needs N iterations a spacing s costs 0.4 N / s in failed attempts plus s / 2 iterations of overshoot
-// (minimal at s = sqrt(0.8 N)); starting before 10 delays too many ordinary problems.  The slow tail sets
-// the end of every launch: 1.37 -> 1.24 ms at 125 k problems, neutral at 10 k.
+// certification attempts: at first_check (5), then with a spacing of check_every (2) iterations up to 10, then
+// spaced more and more widely, ~sqrt(it): 5 7 9 11 15 19 25 ...  An attempt costs about one iteration -- of the
+// whole wavefront: in the quad and lane layouts the other problems of the wavefront wait for it.  For a problem
+// that needs N iterations a spacing s costs N / s failed attempts plus s / 2 iterations of overshoot.  Measured
+// over 8 problem sets per size (tools/schedule_tune.sh, M poses/s, first_check : check_every):
+//     problems/launch    4:1     5:1     5:2     5:3
+//     2 k (wave)          -     10.3    13.1    13.9
+//     10 k (quad)        34.9   37.3    38.1    37.5
+//     24 k (quad)         -     53.1    57.2    57.3
+//     125 k (lane)        -    114.0   119.7   121.9
+// An attempt at iteration 4 fails for 40 % of the problems (13 % of the quad wavefronts end there); the slow
+// tail, which sets the end of every launch, gains most from the sparser attempts.
 constexpr int REUSE_MAX = 3; // consecutive certificate attempts that may take over the previous attempt's polished pose
 
 CVX_HD int next_check_after(int it, const Opts &o)

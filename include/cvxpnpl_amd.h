@@ -52,7 +52,7 @@ typedef struct {
     double rho;        /* ADMM penalty on the trace-normalised cost, default 0.1 */
     double alpha;      /* over-relaxation, default 1.4 */
     int32_t first_check; /* first certification attempt after this many iterations, default 5 */
-    int32_t check_every; /* then every this many, default 1 */
+    int32_t check_every; /* then every this many (widening ~sqrt(iteration) from iteration 10 on), default 2 */
     double res_tol;    /* fixed-point residual at which an uncertifiable problem stops, default 1e-5 */
     int32_t jacobi_sweeps; /* cap on Jacobi sweeps per PSD projection, default 12 */
     double jacobi_tol; /* eigen-solve ends after a sweep whose largest column cosine is below this, default 6e-2 */
