@@ -176,8 +176,8 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
     int layout = opts ? opts->layout : CVXPNPL_LAYOUT_AUTO;
     // AUTO, by launch size (measured on one MI355X, M poses/s for wave / quad / lane-hybrid, PnP N = 10,
     // profiles/r01/layout_sweep.txt):
-    //   2 k: 12.4 / 12.5 / 5.8    4 k: 15.3 / 19.0 / 9.5     10 k: 27.7 / 37.0 / 23.0    16 k: 32.6 / 52.5 / 34.6
-    //   24 k: 32.9 / 52.9 / 45.6  32 k: 35.7 / 60.0 / 60.1   50 k: 38.8 / 66.7 / 80.6    125 k: 41.2 / - / 108.5
+    //   2 k: 17.2 / 14.1 / 5.7    5 k: 24.1 / 28.0 / 13.6    10 k: 28.1 / 39.2 / 25.3    16 k: 32.7 / 53.2 / 38.3
+    //   24 k: 33.5 / 56.8 / 54.9  32 k: 34.3 / 65.3 / 66.9   50 k: 37.9 / 71.0 / 90.0    125 k: 40.5 / 84.2 / 120.6
     // * below 3584 problems a wavefront per problem: every SIMD gets work and a finished problem frees
     //   its slot at once;
     // * from there four problems per wavefront (one per DPP row): 2.2x fewer instructions per problem;
