@@ -212,11 +212,11 @@ __device__ __forceinline__ double quad_ldl(double *L, const Own &w, double *Me)
 // its head / tail words bounces between the eight XCDs' L2s: 1.6 ms per launch for 2500 wavefronts, measured.
 // Not inlined on purpose: as a separate function the wave-per-problem solver gets a register allocation of
 // its own and leaves that of the quad phase alone; nothing but the kernel arguments is live across the call.
-// (The by-reference arguments cost the caller a 200 B/lane copy to scratch.  Re-reading them from the kernarg
-// segment inside the callee instead: the segment pointer is null there; handing that pointer down: scalar
-// loads, but the callee's frame grows from 136 to 588 B -- no gain, not kept.  Through LDS (lane 0 stores the
-// block, the callee reads it back, with or without readfirstlane into scalar registers): the kernel's own
-// frame drops to 192 B but the callee's grows to 492 / 552 B -- no gain either.)
+// (The arguments go by reference to copies the caller makes inside the branch that calls: handing down the
+// kernel's own a / o made every wavefront of the grid write them to its scratch frame at kernel entry, 190 B per
+// lane = 30 MB of HBM writes per 10 k launch and 4 % of its time.  Also tried: re-reading them from the kernarg
+// segment inside the callee (the segment pointer is null there); handing that pointer down (scalar loads, but the
+// callee's frame grows from 136 to 588 B); through LDS, with or without readfirstlane (callee frame 492 / 552 B).)
 __device__ __forceinline__ void park(double *p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __noinline__ void finish_own(const WaveArgs &a, const cvx::Opts &o, unsigned parked, const double *ws, double *lds)
 {
@@ -833,7 +833,11 @@ __global__ void __launch_bounds__(64, 2) solve_quad_kernel(WaveArgs a, cvx::Opts
     if (pmask) { // wave-uniform
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // every park() acknowledged before the iterate is read back
         CVXW_SYNC();
-        finish_own(a, o, pmask, ws, lds_all);
+        // copies made HERE: taking the address of the kernel's own a / o would make every wavefront of the grid
+        // spill them to its scratch frame at kernel entry (190 B per lane, 30 MB per 10 k launch)
+        const WaveArgs a2 = a;
+        const cvx::Opts o2 = o;
+        finish_own(a2, o2, pmask, ws, lds_all);
     }
 }
 
