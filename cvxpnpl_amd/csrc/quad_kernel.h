@@ -694,7 +694,7 @@ __global__ void __launch_bounds__(64, 2) solve_quad_kernel(WaveArgs a, cvx::Opts
             {
                 double T[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) { S[m] = rho * (Wp[m] - W[m]); T[m] = S[m] - (w.ej[m] < 9 ? Qs[m] : 0.0); }
+                for (int m = 0; m < 4; ++m) { S[m] = rho * (Wp[m] - W[m]); T[m] = S[m] - (w.ej[m] < 9 ? L[Q_QF + w.ei[m] * 10 + w.ej[m]] : 0.0); }
                 quad_proj(L, w, T, 0.0);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
@@ -787,7 +787,7 @@ __global__ void __launch_bounds__(64, 2) solve_quad_kernel(WaveArgs a, cvx::Opts
         {
             double X[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) X[m] = 2.0 * Wp[m] - W[m] - irho * (w.ej[m] < 9 ? Qs[m] : 0.0);
+            for (int m = 0; m < 4; ++m) X[m] = 2.0 * Wp[m] - W[m] - irho * (w.ej[m] < 9 ? L[Q_QF + w.ei[m] * 10 + w.ej[m]] : 0.0); // (the cost entries stay in LDS: 8 registers less to carry through the loop)
             quad_proj(L, w, X, 1.0);
             double r2 = 0.0;
 #pragma unroll
