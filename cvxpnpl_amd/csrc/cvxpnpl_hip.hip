@@ -181,11 +181,11 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
     // * below 3584 problems a wavefront per problem: every SIMD gets work and a finished problem frees
     //   its slot at once;
     // * from there four problems per wavefront (one per DPP row): 2.2x fewer instructions per problem;
-    // * from 32768 the lane-hybrid schedule (64 problems per wavefront for the first lane_iters
+    // * from 38912 the lane-hybrid schedule (8 problem sets per size: 36 k 70.8 quad / 68.7 lane, 40 k 69.2 / 75.0) (64 problems per wavefront for the first lane_iters
     //   iterations): fewest instructions, but it needs tens of thousands of problems to fill the chip.
     // The problems the quad phase leaves open are finished by the same wavefront, those of the lane phase
     // by a second kernel, one per wavefront in both cases.
-    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 3584 ? CVXPNPL_LAYOUT_WAVE : (batch < 32768 ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
+    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 3584 ? CVXPNPL_LAYOUT_WAVE : (batch < 38912 ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
     cvxw::WaveArgs w;
     w.batch = batch; w.n_p = n_p; w.n_l = n_l; w.K_per_problem = K_per_problem;
     w.p2 = d_pts_2d; w.p3 = d_pts_3d; w.l2 = d_line_2d; w.l3 = d_line_3d; w.K = d_K;
