@@ -18,6 +18,7 @@ _ip = C.POINTER(C.c_int32)
 EXPORTS = (
     "cvxpnpl_default_opts", "cvxpnpl_solve_batch", "cvxpnpl_recover_multi", "cvxpnpl_recover_multi_batch", "cvxpnpl_assemble_batch",
     "cvxpnpl_score_hypotheses", "cvxpnpl_pack_results",
+    "cvxpnpl_workspace_bytes", "cvxpnpl_set_workspace", "cvxpnpl_release_workspace",
     "cvxpnpl_event_create", "cvxpnpl_event_record", "cvxpnpl_event_elapsed_ms", "cvxpnpl_event_destroy",
     "cvxpnpl_last_error", "cvxpnpl_version", "cvxpnpl_device_count",
 )
@@ -70,6 +71,12 @@ def lib():
     L.cvxpnpl_score_hypotheses.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int32,
                                            C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cvxpnpl_score_hypotheses.restype = C.c_int
+    L.cvxpnpl_workspace_bytes.argtypes = [C.c_int64]
+    L.cvxpnpl_workspace_bytes.restype = C.c_size_t
+    L.cvxpnpl_set_workspace.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.cvxpnpl_set_workspace.restype = C.c_int
+    L.cvxpnpl_release_workspace.argtypes = [C.c_void_p, C.c_int32]
+    L.cvxpnpl_release_workspace.restype = C.c_int
     L.cvxpnpl_event_create.restype = C.c_void_p
     L.cvxpnpl_event_record.argtypes = [C.c_void_p, C.c_void_p]
     L.cvxpnpl_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]

@@ -20,7 +20,13 @@ __all__ = ["pnp", "pnl", "pnpl", "pnp_batch", "pnl_batch", "pnpl_batch", "BatchR
 class BatchResult(dict):
     """R [B,3,3], t [B,3], status [B] int32, iters [B] int32, cost [B,2] (||Ar||^2, dobj),
     work [B,2] (rank, sweeps) and optionally Z [B,55]; torch tensors on the input device."""
-    __getattr__ = dict.__getitem__
+
+    def __getattr__(self, name):
+        # AttributeError (not KeyError) for missing names: hasattr(), copy.deepcopy() and pickle rely on it
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name) from None
 
 
 def _require_gpu():
@@ -37,6 +43,27 @@ def _as_dev(x, device, shape_tail):
     if tuple(x.shape[-len(shape_tail):]) != tuple(shape_tail):
         raise ValueError(f"expected trailing shape {shape_tail}, got {tuple(x.shape)}")
     return x
+
+
+def _pair_2d(pts_2d, line_2d, device, batch, n_p, n_l):
+    """The 2D halves of the correspondences, checked against the 3D halves: both members of a pair present,
+    same [batch, n] leading shape."""
+    p2 = l2 = None
+    if n_p:
+        if pts_2d is None:
+            raise ValueError("pts_3d given without pts_2d")
+        p2 = _as_dev(pts_2d, device, (2,))
+        if p2.numel() != batch * n_p * 2:
+            raise ValueError(f"pts_2d {tuple(p2.shape)} does not match pts_3d [{batch},{n_p},3]")
+        p2 = p2.reshape(batch, n_p, 2)
+    if n_l:
+        if line_2d is None:
+            raise ValueError("line_3d given without line_2d")
+        l2 = _as_dev(line_2d, device, (2, 2))
+        if l2.numel() != batch * n_l * 4:
+            raise ValueError(f"line_2d {tuple(l2.shape)} does not match line_3d [{batch},{n_l},2,3]")
+        l2 = l2.reshape(batch, n_l, 2, 2)
+    return p2, l2
 
 
 def _ptr(t):
@@ -68,10 +95,11 @@ def pnpl_batch(pts_2d, line_2d, pts_3d, line_3d, K, eps: float = 1e-9, max_iters
     if n_p == 0 and n_l == 0:
         raise ValueError("need at least one point or line correspondence ([B,n,3] points / [B,n,2,3] lines)")
     batch = (p3 if n_p else l3).shape[0]
-    p2 = _as_dev(pts_2d, device, (2,)).reshape(batch, n_p, 2) if n_p else None
+    p2, l2 = _pair_2d(pts_2d, line_2d, device, batch, n_p, n_l)
     p3 = p3.reshape(batch, n_p, 3) if n_p else None
-    l2 = _as_dev(line_2d, device, (2, 2)).reshape(batch, n_l, 2, 2) if n_l else None
     l3 = l3.reshape(batch, n_l, 2, 3) if n_l else None
+    if n_p and n_l and l3.shape[0] != batch:
+        raise ValueError(f"points and lines describe different batches ({batch} vs {l3.shape[0]})")
     Kd = _as_dev(K, device, (3, 3))
     per = int(Kd.dim() == 3)
     if per and Kd.shape[0] != batch:
@@ -128,6 +156,8 @@ def recover_multi_batch(res: "BatchResult", B, Q=None, n_threads: int = 0):
     Returns (R [batch,4,3,3], t [batch,4,3], n_poses [batch]) as numpy arrays; n_poses is 0 for problems whose
     status is not CVXPNPL_RANK_GT1."""
     L = _lib.lib()
+    if getattr(res, "Z", None) is None:
+        raise ValueError("recover_multi_batch needs the SDP solutions: solve with want_Z=True")
     Z = np.ascontiguousarray(res.Z.detach().cpu().numpy() if isinstance(res.Z, torch.Tensor) else res.Z, dtype=np.float64)
     st = np.ascontiguousarray(res.status.detach().cpu().numpy() if isinstance(res.status, torch.Tensor) else res.status, dtype=np.int32)
     tonp = lambda x: np.ascontiguousarray(x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else x, dtype=np.float64)  # noqa: E731
@@ -156,7 +186,9 @@ def _single(pts_2d, line_2d, pts_3d, line_3d, K, eps, max_iters, verbose) -> Lis
     p2, p3 = b(pts_2d, (2,)), b(pts_3d, (3,))
     l2, l3 = b(line_2d, (2, 2)), b(line_3d, (2, 3))
     Kn = np.asarray(K, dtype=np.float64)
-    res = pnpl_batch(p2, l2, p3, l3, Kn, eps=eps, max_iters=max_iters, want_Z=True)
+    # res_tol = 0: an uncertifiable problem runs to max_iters like the reference's solve (the batch entry points
+    # stop such problems at the fixed-point residual opts.res_tol instead)
+    res = pnpl_batch(p2, l2, p3, l3, Kn, eps=eps, max_iters=max_iters, want_Z=True, res_tol=0.0)
     status = int(res.status[0])
     if status == 3:  # cvxpnpl.py:493-498
         if verbose:
@@ -165,7 +197,11 @@ def _single(pts_2d, line_2d, pts_3d, line_3d, K, eps, max_iters, verbose) -> Lis
     if status == 1:  # rank > 1: cvxpnpl.py:507
         Bt, Qt = _translation_map(p2, l2, p3, l3, Kn)
         poses = recover_multi(res.Z[0].cpu().numpy(), Bt, Qt)
-        warnings.warn("The solution is not certifiably optimal.")
+        # cvxpnpl.py:516-519: warn unless |cost - dobj| <= eps.  A certified twin pair (exact two-fold ambiguity,
+        # e.g. a planar scene) carries its certified lower bound in cost[1]; an uncertified exit has NaN there.
+        # (the kernel writes a finite dobj only with 0 <= cost - dobj <= max(eps, 8e-13 tr Q) established)
+        if not np.isfinite(float(res.cost[0, 1])):
+            warnings.warn("The solution is not certifiably optimal.")
         return poses
     if status != 0:  # cvxpnpl.py:517-519
         warnings.warn("The solution is not certifiably optimal.")
@@ -177,7 +213,7 @@ def _single(pts_2d, line_2d, pts_3d, line_3d, K, eps, max_iters, verbose) -> Lis
 
 def assemble_batch(pts_2d, line_2d, pts_3d, line_3d, K, device=None):
     """Device-side constraint assembly only (cvxpnpl.py:432-452): returns (B [batch,27], Q [batch,45]),
-    the translation map t = B r and the packed 9x9 cost r^T Q r, as float64 device tensors.  What
+    the translation map t = -B r and the packed 9x9 cost r^T Q r, as float64 device tensors.  What
     the rank > 1 recovery (recover_multi) needs next to Z."""
     _require_gpu()
     L = _lib.lib()
@@ -189,8 +225,7 @@ def assemble_batch(pts_2d, line_2d, pts_3d, line_3d, K, device=None):
     if n_p == 0 and n_l == 0:
         raise ValueError("need at least one point or line correspondence ([B,n,3] points / [B,n,2,3] lines)")
     batch = (p3 if n_p else l3).shape[0]
-    p2 = _as_dev(pts_2d, dev, (2,)).reshape(batch, n_p, 2) if n_p else None
-    l2 = _as_dev(line_2d, dev, (2, 2)).reshape(batch, n_l, 2, 2) if n_l else None
+    p2, l2 = _pair_2d(pts_2d, line_2d, dev, batch, n_p, n_l)
     Kd = _as_dev(K, dev, (3, 3))
     per = int(Kd.dim() == 3)
     with torch.cuda.device(dev):

@@ -17,8 +17,6 @@
 
 namespace {
 
-thread_local char g_err[512] = "";
-
 struct BatchArgs {
     int64_t batch;
     int n_p, n_l, K_per_problem;
@@ -85,31 +83,65 @@ __global__ void __launch_bounds__(64) assemble_kernel(BatchArgs a, double *Bout,
         for (int i = 0; i < 45; ++i) Qout[b * 45 + i] = ok ? Q9[i] : NAN;
 }
 
-// grow-only scratch for the hybrid schedules, one per (device, stream): two alternating queue counters, the queue
-// entries [batch] int32 and the parked iterates [batch][56] doubles (only the slots of parked problems are touched)
-struct Workspace { void *ptr = nullptr; size_t bytes = 0; unsigned calls = 0; };
+// Scratch of the hybrid schedules, one per (device, stream): [0, 256) the queue counter, then the queue entries
+// (int32, -1 = empty; batch + RESUME_GRID_MAX of them) and the parked iterates [batch][56] doubles (only the
+// slots of parked problems are touched).  Either the library's own allocation (grow-only while in use, freed by
+// cvxpnpl_release_workspace) or memory the caller registered with cvxpnpl_set_workspace (e.g. from torch's
+// caching allocator).  The queue is self-cleaning (cvxw::resume_wave_kernel): it is initialised once.
+// Offsets depend on the CAPACITY (problems) of the allocation, not on the batch of a launch, so that launches of
+// different sizes agree on where the queue ends and the iterates begin.
+struct Workspace { void *ptr = nullptr; size_t bytes = 0; int64_t cap = 0; bool owned = true; };
 std::mutex g_ws_mutex;
-std::mutex g_launch_mutex; // held while a hybrid schedule is enqueued: the counter alternation below follows enqueue order
 std::map<std::pair<int, void *>, Workspace> g_ws;
+thread_local char g_err[512] = "";
 
-// The first 256 bytes of a fresh allocation are zeroed on the stream (the two alternating queue counters of
-// the quad schedule live there); *calls counts the launches that used the allocation (the alternation).
-void *get_workspace(size_t bytes, void *stream, unsigned *calls = nullptr)
+size_t hybrid_queue_bytes(int64_t cap) { return 256 + (((size_t)(cap + cvxw::RESUME_GRID_MAX) * sizeof(int32_t) + 255) & ~(size_t)255); }
+size_t hybrid_ws_bytes(int64_t cap) { return hybrid_queue_bytes(cap) + (size_t)cap * 56 * sizeof(double); }
+int64_t hybrid_capacity(size_t bytes) // largest capacity whose layout fits
+{
+    const size_t fixed = 256 + 256 + (size_t)cvxw::RESUME_GRID_MAX * sizeof(int32_t);
+    if (bytes <= fixed) return 0;
+    int64_t cap = (int64_t)((bytes - fixed) / (sizeof(int32_t) + 56 * sizeof(double)));
+    while (cap > 0 && hybrid_ws_bytes(cap) > bytes) --cap;
+    return cap;
+}
+
+// counter zero, every queue entry -1 (0xFF bytes), on the stream; the parked iterates need no initialisation
+bool init_workspace(void *p, int64_t cap, void *stream)
+{
+    if (hipMemsetAsync(p, 0xFF, hybrid_queue_bytes(cap), (hipStream_t)stream) != hipSuccess) return false;
+    return hipMemsetAsync(p, 0, 256, (hipStream_t)stream) == hipSuccess;
+}
+
+struct WsView { int32_t *count, *entries; double *parked; };
+
+bool get_workspace(int64_t batch, void *stream, WsView &v)
 {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess) { snprintf(g_err, sizeof(g_err), "cvxpnpl: hipGetDevice failed"); return false; }
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     Workspace &w = g_ws[std::make_pair(dev, stream)];
-    if (w.bytes < bytes) {
+    if (w.cap < batch) {
+        if (!w.owned) {
+            snprintf(g_err, sizeof(g_err), "cvxpnpl: the registered workspace holds %lld problems, the launch has %lld (cvxpnpl_workspace_bytes)",
+                     (long long)w.cap, (long long)batch);
+            return false;
+        }
         if (w.ptr) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(w.ptr); }
-        w.ptr = nullptr; w.bytes = 0; w.calls = 0;
-        if (bytes < 256) bytes = 256;
-        if (hipMalloc(&w.ptr, bytes) != hipSuccess) return nullptr;
-        if (hipMemsetAsync(w.ptr, 0, 256, (hipStream_t)stream) != hipSuccess) { (void)hipFree(w.ptr); w.ptr = nullptr; return nullptr; }
-        w.bytes = bytes;
+        w.ptr = nullptr; w.bytes = 0; w.cap = 0;
+        const size_t bytes = hybrid_ws_bytes(batch);
+        if (hipMalloc(&w.ptr, bytes) != hipSuccess || !init_workspace(w.ptr, batch, stream)) {
+            if (w.ptr) (void)hipFree(w.ptr);
+            w.ptr = nullptr;
+            snprintf(g_err, sizeof(g_err), "cvxpnpl: workspace allocation failed (%zu bytes)", bytes);
+            return false;
+        }
+        w.bytes = bytes; w.cap = batch;
     }
-    if (calls) *calls = w.calls++;
-    return w.ptr;
+    v.count = (int32_t *)w.ptr;
+    v.entries = (int32_t *)((char *)w.ptr + 256);
+    v.parked = (double *)((char *)w.ptr + hybrid_queue_bytes(w.cap));
+    return true;
 }
 
 int set_err(const char *what, hipError_t e)
@@ -197,20 +229,15 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
         // four problems per wavefront for the first quad_iters iterations, survivors resumed one per wavefront
         // (a wavefront finishes its own survivors; only planar scenes, recognised before the first iteration,
         // are queued for the resume kernel behind it -- an empty queue costs that launch a few microseconds.
-        // Two queue counters alternate between launches: the resume kernel of one launch zeroes the counter of
-        // the next, which saves a memset per call.)
-        const size_t qbytes = ((size_t)(batch + 64) * sizeof(int32_t) + 255) & ~(size_t)255;
-        unsigned calls = 0;
-        std::lock_guard<std::mutex> launch_lock(g_launch_mutex);
-        char *wsp = (char *)get_workspace(qbytes + (size_t)batch * 56 * sizeof(double), stream, &calls);
-        if (!wsp) { snprintf(g_err, sizeof(g_err), "cvxpnpl: workspace allocation failed"); return -2; }
-        int32_t *qbase = (int32_t *)wsp; // [0], [32]: the two counters (separate cache lines); [64 ..]: entries
-        int32_t *count = qbase + 32 * (calls & 1u), *next_count = qbase + 32 * ((calls + 1) & 1u), *entries = qbase + 64;
-        double *ws = (double *)(wsp + qbytes);
+        // The resume kernel leaves the queue counter at zero for the next launch: no memset per call.)
+        WsView wv;
+        if (!get_workspace(batch, stream, wv)) return -2;
+        int32_t *count = wv.count, *entries = wv.entries;
+        double *ws = wv.parked;
         const int64_t qgrid = (batch + 3) / 4;
         hipLaunchKernelGGL(cvxq::solve_quad_kernel, dim3((unsigned)qgrid), dim3(64), 0, s, w, o, quad_iters, count, entries, ws);
-        const int64_t rgrid = batch < 8192 ? batch : 8192;
-        hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64 * cvxw::WPB), 0, s, w, o, (const int32_t *)count, (const int32_t *)entries, ws, next_count);
+        const int64_t rgrid = batch < cvxw::RESUME_GRID_MAX ? batch : cvxw::RESUME_GRID_MAX;
+        hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64 * cvxw::WPB), 0, s, w, o, count, entries, (const double *)ws);
     } else if (layout == CVXPNPL_LAYOUT_WAVE) {
         int64_t wgrid = (batch + cvxw::WPB - 1) / cvxw::WPB;
         if (wgrid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }
@@ -226,17 +253,13 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
         if (lane_iters > 5) lane_iters = 5;
         if (o.max_iters > lane_iters) {
             // hybrid: lanes for the first lane_iters iterations, survivors resumed one per wavefront
-            const size_t qbytes = ((size_t)(batch + 64) * sizeof(int32_t) + 255) & ~(size_t)255;
-            unsigned calls = 0;
-            std::lock_guard<std::mutex> launch_lock(g_launch_mutex);
-            char *wsp = (char *)get_workspace(qbytes + (size_t)batch * 56 * sizeof(double), stream, &calls);
-            if (!wsp) { snprintf(g_err, sizeof(g_err), "cvxpnpl: workspace allocation failed"); return -2; }
-            int32_t *qbase = (int32_t *)wsp; // alternating counters at [0] and [32], entries from [64] (see the quad schedule)
-            int32_t *count = qbase + 32 * (calls & 1u), *next_count = qbase + 32 * ((calls + 1) & 1u), *entries = qbase + 64;
-            double *ws = (double *)(wsp + qbytes);
+            WsView wv;
+            if (!get_workspace(batch, stream, wv)) return -2;
+            int32_t *count = wv.count, *entries = wv.entries;
+            double *ws = wv.parked;
             hipLaunchKernelGGL(solve_lane_kernel, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws);
-            const int64_t rgrid = batch < 8192 ? batch : 8192;
-            hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64 * cvxw::WPB), 0, s, w, o, (const int32_t *)count, (const int32_t *)entries, ws, next_count);
+            const int64_t rgrid = batch < cvxw::RESUME_GRID_MAX ? batch : cvxw::RESUME_GRID_MAX;
+            hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64 * cvxw::WPB), 0, s, w, o, count, entries, (const double *)ws);
         } else {
             // fewer iterations allowed than the lane phase would run: the wave kernel does the whole solve
             int64_t wgrid = (batch + cvxw::WPB - 1) / cvxw::WPB;
@@ -294,6 +317,38 @@ int cvxpnpl_score_hypotheses(int64_t n_hyp, const double *d_R, const double *d_t
     hipLaunchKernelGGL(cvxs::score_kernel, dim3((unsigned)grid), dim3(cvxs::SCORE_BLOCK), 0, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err("score_kernel launch", e);
+    return 0;
+}
+
+size_t cvxpnpl_workspace_bytes(int64_t max_batch) { return max_batch > 0 ? hybrid_ws_bytes(max_batch) : 0; }
+
+int cvxpnpl_set_workspace(void *d_workspace, size_t bytes, void *stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { snprintf(g_err, sizeof(g_err), "cvxpnpl: hipGetDevice failed"); return -2; }
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    Workspace &w = g_ws[std::make_pair(dev, stream)];
+    if (w.ptr && w.owned) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(w.ptr); }
+    w = Workspace();
+    if (!d_workspace) return 0; // back to the library's own allocation
+    const int64_t cap = hybrid_capacity(bytes);
+    if (cap <= 0) { snprintf(g_err, sizeof(g_err), "cvxpnpl_set_workspace: %zu bytes hold no problem (cvxpnpl_workspace_bytes)", bytes); g_ws.erase(std::make_pair(dev, stream)); return -1; }
+    if (!init_workspace(d_workspace, cap, stream)) { g_ws.erase(std::make_pair(dev, stream)); return set_err("cvxpnpl_set_workspace", hipGetLastError()); }
+    w.ptr = d_workspace; w.bytes = bytes; w.cap = cap; w.owned = false;
+    return 0;
+}
+
+int cvxpnpl_release_workspace(void *stream, int32_t all_streams)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { snprintf(g_err, sizeof(g_err), "cvxpnpl: hipGetDevice failed"); return -2; }
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    for (auto it = g_ws.begin(); it != g_ws.end();) {
+        if (it->first.first == dev && (all_streams || it->first.second == stream)) {
+            if (it->second.ptr && it->second.owned) { (void)hipStreamSynchronize((hipStream_t)it->first.second); (void)hipFree(it->second.ptr); }
+            it = g_ws.erase(it);
+        } else ++it;
+    }
     return 0;
 }
 

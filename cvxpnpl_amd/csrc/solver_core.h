@@ -819,7 +819,7 @@ CVX_HD double polish_or_reuse(QV Qs, const double *z, const double *Rk, double f
 // (cvxpnpl.py:303-315).  Degenerates gracefully to the rank-1 ratio when v2 carries no weight.
 CVX_HD void twin_candidates(const double *v1, const double *v2, double *zp, double *zm)
 {
-    const double a = v1[9], b = v2[9], n2 = a * a + b * b;
+    const double a = v1[9], b = v2[9], n2r = a * a + b * b, n2 = n2r > 1e-60 ? n2r : 1e-60;
     const double inv = rcp(n2), rn = rsqrt_(n2);
     const double rad = 4.0 - inv;
     const double sq = rad > 0 ? sqrt_(rad) : 0.0;
@@ -1015,28 +1015,49 @@ struct Solution {
 };
 
 // reference-style recovery from an uncertified ADMM iterate Z = Wp (cvxpnpl.py:499-513):
-// v is the unit top eigenvector of Z, rank = #eig(Z) > 1e-3.  R = U V^T of the rank-1
-// ratio (no determinant correction, cvxpnpl.py:510-511); rank > 1 is flagged for the host
-// multi-solution recovery.
+// v is the unit top eigenvector of Z, v2 the runner-up, rank = #eig(Z) > 1e-3.  Rank 1: R = U V^T of the
+// rank-1 ratio (no determinant correction, cvxpnpl.py:510-511).  Rank > 1 is flagged for the multi-solution
+// recovery (cvxpnpl.py:506-507), and R, t then hold ONE candidate pose, never NaN while Z is finite: the
+// rank-1 ratio of the top eigenvector is meaningless there (for an exact two-fold ambiguity it is z1 - z2
+// with last entry 0), so the pose is the better of the two rank-2 candidates of the top-2 eigenspace
+// (twin_candidates: what the reference's rank-2 branch, cvxpnpl.py:303-315, computes for a rank-2 Z) --
+// proper rotations before reflections, then the lower cost.
 template <class QV>
-CVX_HD void fallback_pose(QV Qs, double tr, const double *v, int rank, Solution &sol)
+CVX_HD double rounded_cost(QV Qs, const double *z, double *R, bool &fin)
 {
-    sol.rank = rank;
-    double M0[9], iv = 1.0 / v[9];
-    CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) M0[i * 3 + j] = v[3 * j + i] * iv;
-    polar3(M0, sol.R, 12);
+    double M0[9], iv = 1.0 / z[9];
+    CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) M0[i * 3 + j] = z[3 * j + i] * iv;
+    polar3(M0, R, 12);
     double r[9], Qr[9];
-    CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) r[3 * j + i] = sol.R[i * 3 + j];
+    CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) r[3 * j + i] = R[i * 3 + j];
     q9_mul(Qs, r, Qr);
     double c = 0;
-    CVX_UNROLL for (int i = 0; i < 9; ++i) c += r[i] * Qr[i];
+    fin = true;
+    CVX_UNROLL for (int i = 0; i < 9; ++i) { c += r[i] * Qr[i]; fin &= (R[i] == R[i]); }
+    fin &= (c == c);
+    return c;
+}
+
+template <class QV>
+CVX_HD void fallback_pose(QV Qs, double tr, const double *v, const double *v2, int rank, Solution &sol)
+{
+    sol.rank = rank;
+    bool okf;
+    double c = rounded_cost(Qs, v, sol.R, okf);
+    if (rank > 1) {
+        double zp[10], zm[10], Rp[9], Rm[9];
+        twin_candidates(v, v2, zp, zm);
+        bool okp, okm;
+        const double fp = rounded_cost(Qs, zp, Rp, okp), fm = rounded_cost(Qs, zm, Rm, okm);
+        const bool pp = okp && det3(Rp) > 0, pm = okm && det3(Rm) > 0;
+        const bool take_m = okm && (!okp || (pm && !pp) || (pm == pp && fm < fp));
+        if (okp || okm) {
+            CVX_UNROLL for (int i = 0; i < 9; ++i) sol.R[i] = take_m ? Rm[i] : Rp[i];
+            c = take_m ? fm : fp;
+        }
+    }
     sol.cost = tr * c;
     sol.dobj = NAN;
-    bool okf = true;
-    CVX_UNROLL for (int i = 0; i < 9; ++i) okf &= (sol.R[i] == sol.R[i]);
-    // rank > 1 first: the rank-1 ratio is meaningless then (for an exact two-fold ambiguity the top
-    // eigenvector is z1 - z2 with last entry 0, so R above is NaN) -- the poses come from Z through the
-    // multi-solution recovery, like the reference's branch at cvxpnpl.py:506-507
     sol.status = rank > 1 ? ST_RANK_GT1 : (!okf ? ST_NONFINITE : (rank != 1 ? ST_RANK_GT1 : (det3(sol.R) < 0 ? ST_REFLECTION : ST_UNCERTIFIED)));
 }
 
@@ -1223,7 +1244,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
             if (ambiguous) {
                 CVX_UNROLL for (int i = 0; i < 9; ++i) sol.R[i] = c.R[i];
                 sol.cost = tr * c.pobj;
-                sol.dobj = NAN;
+                sol.dobj = tr * (c.pobj - c.zSz - 4.0 * delta); // the pair IS certified: both twins attain this bound to eps
                 sol.status = ST_RANK_GT1;
                 sol.rank = 2;
                 if (Zout) {
@@ -1252,7 +1273,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                 int rank = 0;
                 const double thr = (e.sigma + 1e-3) * (e.sigma + 1e-3); // eigenvalue > 1e-3 (cvxpnpl.py:501) without the roots
                 CVX_UNROLL for (int j = 0; j < 10; ++j) rank += e.n2[j] > thr;
-                fallback_pose(Qs, tr, vt, rank, sol);
+                fallback_pose(Qs, tr, vt, v2, rank, sol);
                 if (Zout) { CVX_UNROLL for (int i = 0; i < 55; ++i) Zout[i] = Wp[i]; }
                 done = true;
             }

@@ -967,7 +967,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
                 if (lane == 0) {
 #pragma unroll
                     for (int i = 0; i < 9; ++i) L[L_M + 16 + i] = Rc[i];
-                    L[L_M + 25] = tr * pobj; L[L_M + 26] = NAN;
+                    L[L_M + 25] = tr * pobj; L[L_M + 26] = tr * (pobj - zSz - 4.0 * delta); // certified pair: its lower bound
                     L[L_M + 27] = (double)cvx::ST_RANK_GT1; L[L_M + 28] = 2.0;
                 }
             }
@@ -980,30 +980,53 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
                 }
             } else if (last && !ambiguous) {
                 // cold path: the reference's recovery from the uncertified iterate (cvx::fallback_pose):
-                // R = U V^T of the rank-1 ratio (no determinant fix), cost = r^T Q r via the LDS copy of Qs
-                double M0[9], Rf[9];
-                const double iv = cvx::rcp(L[L_V + 9]);
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) M0[i * 3 + j] = L[L_V + 3 * j + i] * iv;
-                cvx::polar3(M0, Rf, 12);
+                // R = U V^T of the rank-1 ratio (no determinant fix), cost = r^T Q r via the LDS copy of Qs;
+                // rank > 1: the better of the two rank-2 candidates of the top-2 eigenspace instead (never NaN
+                // while Z is finite, see cvx::fallback_pose)
                 coop_store_qf(L, roles, Qs); // (a reused pose skipped the polish that would have stored it)
-                if (lane < 10) L[C_XV + lane] = lane == 9 ? 1.0 : Rf[0]; // placeholder, overwritten below
-                CVXW_SYNC();
-                if (lane == 0) {
+                auto rounded_cost = [&](const double *z, double *Rr, bool &fin) { // cvx::rounded_cost, every lane
+                    double M0[9];
+                    const double iv = 1.0 / z[9];
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) L[C_XV + 3 * j + i] = Rf[i * 3 + j];
-                }
-                CVXW_SYNC();
-                double part = 0.0;
-                if (lane < 9) part = L[C_XV + lane] * dot10(reinterpret_cast<double2 *>(L) + (C_QF + lane * 10) / 2, reinterpret_cast<double2 *>(L) + C_XV / 2);
-                const double fc = wave_sum(part);
-                bool okf = true;
+                        for (int j = 0; j < 3; ++j) M0[i * 3 + j] = z[3 * j + i] * iv;
+                    cvx::polar3(M0, Rr, 12);
+                    CVXW_SYNC();
+                    if (lane == 0) {
 #pragma unroll
-                for (int i = 0; i < 9; ++i) okf &= (Rf[i] == Rf[i]);
+                        for (int i = 0; i < 3; ++i)
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) L[C_XV + 3 * j + i] = Rr[i * 3 + j];
+                        L[C_XV + 9] = 1.0;
+                    }
+                    CVXW_SYNC();
+                    double part = 0.0;
+                    if (lane < 9) part = L[C_XV + lane] * dot10(reinterpret_cast<double2 *>(L) + (C_QF + lane * 10) / 2, reinterpret_cast<double2 *>(L) + C_XV / 2);
+                    const double c = wave_sum(part);
+                    fin = (c == c);
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) fin = fin && (Rr[i] == Rr[i]);
+                    return c;
+                };
+                double v1[10], v2[10], Rf[9];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) { v1[i] = L[L_V + i]; v2[i] = L[L_V + 10 + i]; }
+                bool okf;
+                double fc = rounded_cost(v1, Rf, okf);
+                if (rank > 1) { // wave-uniform
+                    double zp[10], zm[10], Rp[9], Rm[9];
+                    cvx::twin_candidates(v1, v2, zp, zm);
+                    bool okp, okm;
+                    const double fp = rounded_cost(zp, Rp, okp), fm = rounded_cost(zm, Rm, okm);
+                    const bool pp = okp && cvx::det3(Rp) > 0, pm = okm && cvx::det3(Rm) > 0;
+                    const bool take_m = okm && (!okp || (pm && !pp) || (pm == pp && fm < fp));
+                    if (okp || okm) {
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) Rf[i] = take_m ? Rm[i] : Rp[i];
+                        fc = take_m ? fm : fp;
+                    }
+                }
                 const int fst = rank > 1 ? cvx::ST_RANK_GT1
                                          : (!okf ? cvx::ST_NONFINITE : (rank != 1 ? cvx::ST_RANK_GT1 : (cvx::det3(Rf) < 0 ? cvx::ST_REFLECTION : cvx::ST_UNCERTIFIED)));
                 if (lane == 0) {
@@ -1112,18 +1135,25 @@ __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx
     solve_one_wave(a, o, b, lds_all[wib], nullptr);
 }
 
-// Second phase of the hybrid schedules: the problems the first kernel parked, entries[0 .. *count), each resumed
-// by one wavefront.  zero_next (optional): the counter the NEXT launch on this stream will use (quad schedule).
-__global__ void __launch_bounds__(64 * WPB, 2) resume_wave_kernel(WaveArgs a, cvx::Opts o, const int32_t *count_p, const int32_t *entries, const double *ws,
-                                                                   int32_t *zero_next)
+// Second phase of the hybrid schedules: the problems the first kernel parked, one wavefront each.  The queue is
+// self-cleaning: entries[] is -1 wherever nothing is queued; the first kernel appends problem indices at
+// atomicAdd(count) positions, a resume block walks q = blockIdx.x, + gridDim.x, ... until it meets a -1, and
+// puts -1 back over every entry it consumes; block 0 zeroes the counter (no block of this kernel reads it).
+// So every launch leaves the queue as it found it -- no host-side bookkeeping, no memset per launch, nothing
+// that a failed launch or a hipGraph replay could desynchronise -- and every index is range checked, so a
+// corrupted workspace cannot turn into an out-of-bounds write.  entries[] has RESUME_GRID_MAX spare slots.
+constexpr int RESUME_GRID_MAX = 8192;
+__global__ void __launch_bounds__(64 * WPB, 2) resume_wave_kernel(WaveArgs a, cvx::Opts o, int32_t *count_p, int32_t *entries, const double *ws)
 {
     __shared__ __attribute__((aligned(16))) double lds_all[WPB][LDSW];
     const int wib = threadIdx.x >> 6;
-    const int count = *count_p;
-    if (zero_next && blockIdx.x == 0 && threadIdx.x == 0) *zero_next = 0;
-    for (int q = blockIdx.x * WPB + wib; q < count; q += gridDim.x * WPB) { // wave-uniform
-        const int64_t b = entries[q];
-        solve_one_wave(a, o, b, lds_all[wib], ws + b * 56);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count_p = 0;
+    for (int64_t q = (int64_t)blockIdx.x * WPB + wib; q < a.batch + RESUME_GRID_MAX; q += (int64_t)gridDim.x * WPB) { // wave-uniform
+        const int32_t b = entries[q];
+        if (b < 0) break;
+        if ((threadIdx.x & 63) == 0) entries[q] = -1;
+        if (b >= a.batch) continue;
+        solve_one_wave(a, o, b, lds_all[wib], ws + (int64_t)b * 56);
         CVXW_SYNC();
     }
 }

@@ -27,7 +27,14 @@ def ransac_pnp(pts_2d, pts_3d, K, n_hyp: int = 4096, thresh: float = 2.0, max_it
     pts_2d [M,2], pts_3d [M,3] (numpy or torch), K [3,3].  Returns dict with R [3,3], t [3],
     inliers [M] bool, n_inliers, status of the final solve, n_certified hypotheses.
     """
-    device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
+    if device is None:  # like pnpl_batch: the device of a CUDA input, else the current device
+        for a in (pts_3d, pts_2d, K):
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                device = a.device
+                break
+        else:
+            device = torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
     x = torch.as_tensor(pts_2d, dtype=torch.float64, device=device)
     X = torch.as_tensor(pts_3d, dtype=torch.float64, device=device)
     Kd = torch.as_tensor(K, dtype=torch.float64, device=device)

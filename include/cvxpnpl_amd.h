@@ -18,6 +18,7 @@
 #ifndef CVXPNPL_AMD_H
 #define CVXPNPL_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -30,7 +31,8 @@ enum {
     CVXPNPL_RANK_GT1 = 1,    /* rank(Z) > 1 at the 1e-3 threshold of cvxpnpl.py:502: Z is returned, poses come
                                 from cvxpnpl_recover_multi (cvxpnpl.py:507, 221-343).  R, t hold ONE of the poses
                                 when the pair was certified (exact two-fold ambiguity, e.g. a planar scene),
-                                otherwise the rank-1 rounding of the top eigenvector, which may be NaN: ask for Z */
+                                otherwise the better of the two rank-2 candidates of the top-2 eigenspace of Z (what cvxpnpl.py:303-315
+                                computes for a rank-2 Z): finite whenever Z is; ask for Z to get all the poses */
     CVXPNPL_UNCERTIFIED = 2, /* rank-1 pose, no certificate by max_iters ["not certifiably optimal", :517-519] */
     CVXPNPL_NONFINITE = 3,   /* degenerate input: NaN pose [NaN sentinel :493-498 / LinAlgError] */
     CVXPNPL_REFLECTION = 4   /* uncertified and det(U V^T) < 0; returned as is, like the reference (:510-511) */
@@ -138,6 +140,19 @@ int cvxpnpl_pack_results(int64_t batch, const double *d_R, const double *d_t, co
 int cvxpnpl_score_hypotheses(int64_t n_hyp, const double *d_R, const double *d_t, const int32_t *d_status, uint32_t usable_mask,
                              const double *d_K, int32_t n_corr, const double *d_pts_2d, const double *d_pts_3d, double thresh_px,
                              int32_t *d_count, uint8_t *d_mask, void *stream);
+
+/*
+ * Scratch of the lane / quad schedules (queue of parked problems + their iterates).  By default the library
+ * keeps one grow-only hipMalloc allocation per (device, stream).  A caller that wants the memory under its own
+ * allocator (e.g. torch's caching allocator) registers a DEVICE buffer of at least
+ * cvxpnpl_workspace_bytes(largest batch) bytes for the launches it will issue on `stream`; the call initialises
+ * the buffer on that stream (the queue cleans itself after every launch).  d_workspace = NULL unregisters.
+ * cvxpnpl_release_workspace frees the library's own allocation of `stream` (all_streams != 0: of every stream
+ * of the current device) after synchronising with it.  Return 0, -1 bad arguments, -2 HIP error.
+ */
+size_t cvxpnpl_workspace_bytes(int64_t max_batch);
+int cvxpnpl_set_workspace(void *d_workspace, size_t bytes, void *stream);
+int cvxpnpl_release_workspace(void *stream, int32_t all_streams);
 
 /* HIP-event timing on the launch stream (for bench.py: torch.cuda.Event only sees torch's
  * current stream).  handles are opaque. */
