@@ -65,7 +65,15 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="solver option override name=value (diagnostics)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the steps are issued round-robin on (1 = the contract's "
                     "back-to-back steps; >1 lets independent batches overlap, reported in config)")
+    ap.add_argument("--pmc", default="auto", choices=("auto", "run", "off"), help="roofline.traffic: auto = measure with rocprofv3 --pmc child passes "
+                    "when rocprofv3 is on PATH, else a hash-matched committed profile; run = measure or nothing; off = committed profile only")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the profiled child of --pmc: solve steps + calibration copies only
+    ap.add_argument("--backend", default="auto", choices=("auto", "nccl", "gloo"), help="process-group backend for --gpus > 1: nccl (= RCCL) when "
+                    "every rank has a GPU of its own; auto falls back to gloo when ranks have to share a device (diagnostics on a 1-GPU box)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return _spawn_ranks(args.gpus)
 
     import torch
     import torch.distributed as dist
@@ -77,15 +85,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with {args.gpus} ranks, or without a launcher (bench.py starts them)")
     assert torch.cuda.is_available(), "bench.py needs a GPU; cvxpnpl_amd has no CPU fallback"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    shared = world > n_dev  # more ranks than GPUs (diagnostics on a small box): ranks share devices, RCCL cannot run
+    torch.cuda.set_device(local_rank % n_dev)
+    dev = torch.device("cuda", local_rank % n_dev)
     dist_on = world > 1 or args.force_dist
+    backend = None
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = args.backend if args.backend != "auto" else ("gloo" if shared else "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     n_p, n_l, batch, sigma = WORKLOADS[args.workload]
     batch = args.batch or batch
@@ -178,6 +193,19 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    if args.pmc_child:
+        # known-size copies with 4, 8 and 16 bytes per lane: what FETCH_SIZE / WRITE_SIZE report for them calibrates the
+        # counters for this access width (MI355X guide, HBM section: only the wide streaming read is calibrated there)
+        nbytes = 64 << 20
+        src = torch.ones(nbytes // 8, dtype=torch.float64, device=dev)
+        dst = torch.empty_like(src)
+        for width in (4, 8, 16):
+            rc = L.cvxpnpl_calibration_copy(ptr(src), ptr(dst), nbytes, width, sh)
+            if rc != 0:
+                raise RuntimeError(_lib.last_error())
+        torch.cuda.synchronize(dev)
+        return None
+
     overlapped = None
     if nstreams == 1 and world == 1 and not args.no_overlap:
         # same K steps issued round-robin on two HIP streams: independent batches overlap, which
@@ -217,7 +245,9 @@ def main():
         "config": {"workload": args.workload, "n_points": n_p, "n_lines": n_l, "problems_per_gpu_per_step": batch,
                    "pixel_noise_sigma": sigma, "eps": opts.eps, "max_iters": opts.max_iters,
                    "streams": nstreams,
-                   "parallelism": f"batch-sharded x{world}" + (", RCCL all_gather of results" if gather else "")},
+                   "parallelism": f"batch-sharded x{world}" + (", RCCL all_gather of results" if gather else ""),
+                   "collective": ({"backend": backend + (" (RCCL)" if backend == "nccl" else " (ranks share a device: diagnostics, not RCCL)"),
+                                   "ranks": dist.get_world_size(), "devices": min(world, n_dev)} if dist_on else None)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                      "traffic": None, "kernel": _kernel_name(opts.layout, batch), "mean_launch_ms": 1e3 * mean_launch_s,
                      "algorithmic_bytes_per_problem": algorithmic_bytes(n_p, n_l),
@@ -226,18 +256,27 @@ def main():
                    "mean_iters": float(it.mean()), "max_iters_seen": int(it.max()),
                    "mean_jacobi_sweeps": float(wk[:, 1].mean())},
     }
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):  # HBM bytes per launch from the rocprofv3 --pmc passes (profiles/README.md)
-        pmc = json.load(open(pmc_path)).get(f"{args.workload}:{batch}")
+    # HBM bytes and VALU instructions per launch: measured in THIS run (rocprofv3 --pmc child passes of this very
+    # command, a few steps each) when rocprofv3 is there; otherwise a committed profile of the same library build
+    # (profiles/pmc_traffic.json entries are stamped with the library's hash; a stale entry is refused).
+    if rank == 0 and world == 1 and not args.pmc_child:
+        pmc = None
+        if args.pmc != "off":
+            pmc = _measure_pmc(args)
+        if pmc is None and args.pmc != "run":
+            pmc = _pmc_from_profile(f"{args.workload}:{batch}")
         if pmc:
             out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
             out["roofline"]["traffic_source"] = pmc["source"]
+            out["roofline"]["traffic_detail"] = {k: pmc[k] for k in ("fetch_bytes", "write_bytes", "calibration") if k in pmc}
             if pmc.get("valu_insts_per_launch"):
                 # what actually binds: VALU issue.  One wave64 VALU instruction occupies a SIMD for 4 cycles
                 # (fp64 FMA is full rate on gfx950); 256 CUs x 4 SIMDs at the 2.4 GHz peak engine clock.
                 n = pmc["valu_insts_per_launch"]
                 out["roofline"]["valu"] = {"insts_per_launch": n, "insts_per_pose": n / batch,
                                            "issue_frac": n * 4.0 / (1024 * 2.4e9 * mean_launch_s), "source": "SQ_INSTS_VALU, same PMC passes"}
+        else:
+            out["roofline"]["traffic_source"] = "none: rocprofv3 not available and no profile of this library build committed"
     if overlapped:
         out["overlapped"] = overlapped
     if sigma == 0.0:
@@ -264,10 +303,169 @@ def main():
                       f"OpenMP over problems, {dt:.1f} s",
             "max_rot_diff_vs_gpu_rad": float(synth.geodesic(Rg, o["R"][:, 0])[both].max()) if both.any() else None,
             "converged_frac": float((o["iters"] < 2500).mean()),
+            "what": "the reference's path restated (explicit C, N, A; SCS's published HSDE-ADMM, dense, no equilibration / acceleration): "
+                    "a stand-in for cvxpnpl + scs, which is not installable here; real SCS is likely 10-100x faster than this port",
+        }
+        # beside it: THIS solver's algorithm (solver_core.h compiled for the host with g++, OpenMP over problems) on all
+        # host cores -- the ratio to `value` isolates what the GPU adds over the same arithmetic on the host
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import hostsim
+
+        hostsim.build()
+        hs_n = min(batch, max(sample * 16, 8192))
+        hsl = slice(0, hs_n)
+        hargs = (d["pts_2d"][hsl] if n_p else None, d["pts_3d"][hsl] if n_p else None, d["line_2d"][hsl] if n_l else None,
+                 d["line_3d"][hsl] if n_l else None, d["K"])
+        hostsim.solve_batch(*[a[:64] if (a is not None and a.ndim > 2) else a for a in hargs])  # warm the thread pool
+        t0 = time.perf_counter()
+        h = hostsim.solve_batch(*hargs)
+        dth = time.perf_counter() - t0
+        bothh = (st[:hs_n] == 0) & (h["status"] == 0)
+        out["cpu_baseline_same_algorithm"] = {
+            "value": hs_n / dth, "unit": "poses/s", "cores": nthreads, "kind": "same-algorithm",
+            "sample": f"first {hs_n} problems of the same batch, same options, g++ -O2 host build of the device algorithm header, "
+                      f"OpenMP over problems, {dth:.2f} s",
+            "max_rot_diff_vs_gpu_rad": float(synth.geodesic(R[:hs_n].cpu().numpy(), h["R"])[bothh].max()) if bothh.any() else None,
+            "certified_frac": float((h["status"] == 0).mean()),
         }
     if dist_on:
         dist.destroy_process_group()
     return out if rank == 0 else None
+
+
+def _lib_hash():
+    import hashlib
+
+    from cvxpnpl_amd import _lib
+    return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+
+
+def _pmc_from_profile(key):
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    e = json.load(open(path)).get(key)
+    if not e or e.get("lib_sha16") != _lib_hash():
+        return None  # no entry, or one measured on another build of the kernels
+    return e
+
+
+def _kname(raw):
+    """kernel name without return type, anonymous-namespace prefix and argument list (template arguments kept)"""
+    n = raw.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0].strip()
+
+
+def _pmc_pass(counters, child_args, tmp):
+    """one rocprofv3 --pmc pass over a child run of this script; {kernel: {counter: [value per dispatch]}}"""
+    import collections
+    import csv
+    import glob
+    import subprocess
+
+    out_dir = os.path.join(tmp, "_".join(counters))
+    cmd = ["rocprofv3", "--pmc"] + counters + ["--output-format", "csv", "-d", out_dir, "-o", "p", "--",
+           sys.executable, os.path.abspath(__file__)] + child_args
+    env = dict(os.environ, TMPDIR=tmp)
+    r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=600)
+    files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+    if r.returncode != 0 or not files:
+        print(f"bench.py: rocprofv3 pass {counters} failed ({r.returncode}): {r.stderr[-400:]}", file=sys.stderr)
+        return None
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            per[(_kname(row["Kernel_Name"]), row["Dispatch_Id"])][row["Counter_Name"]] += float(row["Counter_Value"])
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for (k, _), d in per.items():
+        for c, v in d.items():
+            acc[k][c].append(v)
+    return acc
+
+
+def _measure_pmc(args):
+    """HBM bytes (FETCH_SIZE + WRITE_SIZE, separate passes: they do not fit one on gfx950) and VALU instructions per
+    launch of the solve kernels, from rocprofv3 --pmc passes over a short child run of the same workload; counter
+    calibration from known-size copies in the same passes.  None when rocprofv3 is not available."""
+    import shutil
+    import tempfile
+
+    if not shutil.which("rocprofv3"):
+        return None
+    steps, warm = 6, 2
+    child = ["--pmc-child", "--steps", str(steps), "--warmup", str(warm), "--workload", args.workload, "--layout", str(args.layout),
+             "--seed", str(args.seed), "--no-cpu-baseline", "--no-overlap", "--pmc", "off"]
+    if args.batch:
+        child += ["--batch", str(args.batch)]
+    if args.sigma is not None:
+        child += ["--sigma", str(args.sigma)]
+    for kv in args.opt:
+        child += ["--opt", kv]
+    tmp = tempfile.mkdtemp(prefix="cvxpnpl_pmc_")
+    try:
+        res = {}
+        for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"]):
+            acc = _pmc_pass(counters, child, tmp)
+            if acc is None:
+                return None
+            for k, d in acc.items():
+                res.setdefault(k, {}).update(d)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    solve = {k: v for k, v in res.items() if "solve_" in k or "resume_" in k}
+    calib = {k: v for k, v in res.items() if "calibration_copy" in k}
+    if not solve:
+        return None
+
+    def per_step(name):  # sum over the kernels of one step of the mean per launch (warm-up launches included: same work)
+        return sum(sum(v[name]) / len(v[name]) for v in solve.values() if name in v)
+
+    # calibration: a copy of B bytes must show B bytes fetched and B written (rocprofv3 reports KB)
+    nbytes = float(64 << 20)
+    cal = {}
+    for k, v in calib.items():
+        w = "4" if "<4>" in k else ("16" if "<16>" in k else "8")
+        cal[w] = {"fetch_reported_over_true": (sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"])) * 1024 / nbytes if "FETCH_SIZE" in v else None,
+                  "write_reported_over_true": (sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])) * 1024 / nbytes if "WRITE_SIZE" in v else None}
+    ref = cal.get("8", {})
+    ff = ref.get("fetch_reported_over_true") or 1.0
+    wf = ref.get("write_reported_over_true") or 1.0
+    fetch, write = per_step("FETCH_SIZE") * 1024 / ff, per_step("WRITE_SIZE") * 1024 / wf
+    return {"hbm_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
+            "valu_insts_per_launch": per_step("SQ_INSTS_VALU"), "salu_insts_per_launch": per_step("SQ_INSTS_SALU"),
+            "lds_insts_per_launch": per_step("SQ_INSTS_LDS"), "waves_per_launch": per_step("SQ_WAVES"),
+            "calibration": {"bytes_per_lane": cal, "applied": "8 (the width of this path's global accesses): reported / true",
+                            "fetch_factor": ff, "write_factor": wf},
+            "lib_sha16": _lib_hash(),
+            "source": f"measured in this run: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_INSTS_* (3 separate child passes of this command, "
+                      f"{steps + warm} launches each), KB*1024, divided by the factor the same passes report for a known 64 MiB copy "
+                      "with 8-byte accesses, summed over the kernels of one step"}
+
+
+def _spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves -- the same command under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 at a free port) -- and hand rank 0's
+    JSON line through.  Returns the parsed line."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=sys.stderr, env=env, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{"):
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        raise SystemExit(f"bench.py: the {n}-rank run failed (exit {proc.returncode})")
+    return json.loads(line)
 
 
 def _only_json_on_stdout():

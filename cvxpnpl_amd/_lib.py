@@ -18,7 +18,7 @@ _ip = C.POINTER(C.c_int32)
 EXPORTS = (
     "cvxpnpl_default_opts", "cvxpnpl_solve_batch", "cvxpnpl_recover_multi", "cvxpnpl_recover_multi_batch", "cvxpnpl_assemble_batch",
     "cvxpnpl_score_hypotheses", "cvxpnpl_pack_results",
-    "cvxpnpl_workspace_bytes", "cvxpnpl_set_workspace", "cvxpnpl_release_workspace",
+    "cvxpnpl_workspace_bytes", "cvxpnpl_set_workspace", "cvxpnpl_release_workspace", "cvxpnpl_calibration_copy",
     "cvxpnpl_event_create", "cvxpnpl_event_record", "cvxpnpl_event_elapsed_ms", "cvxpnpl_event_destroy",
     "cvxpnpl_last_error", "cvxpnpl_version", "cvxpnpl_device_count",
 )
@@ -77,6 +77,8 @@ def lib():
     L.cvxpnpl_set_workspace.restype = C.c_int
     L.cvxpnpl_release_workspace.argtypes = [C.c_void_p, C.c_int32]
     L.cvxpnpl_release_workspace.restype = C.c_int
+    L.cvxpnpl_calibration_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+    L.cvxpnpl_calibration_copy.restype = C.c_int
     L.cvxpnpl_event_create.restype = C.c_void_p
     L.cvxpnpl_event_record.argtypes = [C.c_void_p, C.c_void_p]
     L.cvxpnpl_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]

@@ -163,6 +163,21 @@ cvx::Opts to_core(const cvxpnpl_opts_t *opts)
 
 } // namespace
 
+// diagnostics: a copy with W bytes per lane and a known byte count, against which bench.py calibrates rocprofv3's
+// FETCH_SIZE / WRITE_SIZE for this path's access widths (the MI355X guide calibrates only wide streaming reads)
+namespace cvxd {
+template <int W>
+__global__ void __launch_bounds__(256) calibration_copy_kernel(const char *src, char *dst, int64_t nbytes)
+{
+    const int64_t n = nbytes / W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        if (W == 4) reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[i];
+        if (W == 8) reinterpret_cast<double *>(dst)[i] = reinterpret_cast<const double *>(src)[i];
+        if (W == 16) reinterpret_cast<double2 *>(dst)[i] = reinterpret_cast<const double2 *>(src)[i];
+    }
+}
+} // namespace cvxd
+
 extern "C" {
 
 void cvxpnpl_default_opts(cvxpnpl_opts_t *opts)
@@ -350,6 +365,20 @@ int cvxpnpl_release_workspace(void *stream, int32_t all_streams)
         } else ++it;
     }
     return 0;
+}
+
+int cvxpnpl_calibration_copy(const void *d_src, void *d_dst, int64_t nbytes, int32_t bytes_per_lane, void *stream)
+{
+    if (!d_src || !d_dst || nbytes <= 0 || (bytes_per_lane != 4 && bytes_per_lane != 8 && bytes_per_lane != 16) || nbytes % 16) {
+        snprintf(g_err, sizeof(g_err), "cvxpnpl_calibration_copy: bad arguments");
+        return -1;
+    }
+    const dim3 grid(4096), block(256);
+    if (bytes_per_lane == 4) hipLaunchKernelGGL(cvxd::calibration_copy_kernel<4>, grid, block, 0, (hipStream_t)stream, (const char *)d_src, (char *)d_dst, nbytes);
+    if (bytes_per_lane == 8) hipLaunchKernelGGL(cvxd::calibration_copy_kernel<8>, grid, block, 0, (hipStream_t)stream, (const char *)d_src, (char *)d_dst, nbytes);
+    if (bytes_per_lane == 16) hipLaunchKernelGGL(cvxd::calibration_copy_kernel<16>, grid, block, 0, (hipStream_t)stream, (const char *)d_src, (char *)d_dst, nbytes);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : set_err("calibration_copy_kernel launch", e);
 }
 
 void *cvxpnpl_event_create(void)

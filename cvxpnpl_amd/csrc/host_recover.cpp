@@ -228,8 +228,12 @@ extern "C" int cvxpnpl_recover_multi(const double *Z55, const double *B27, const
         // used) with the largest last entry, not blindly from the top one -- for an exact two-fold
         // ambiguity the eigenvalues are equal, the basis of the eigenspace is arbitrary and the top
         // vector's last entry can be ~0 (the reference divides by it and returns NaN poses).
-        int piv = 9;
-        for (int c = 10 - k; c < 10; ++c) if (std::fabs(V[9][c]) > std::fabs(V[9][piv])) piv = c;
+        // (the top one, like the reference, whenever its last entry is usable: results then agree with the
+        // reference's to rounding also for an inconsistent system, where the least-squares steps of the rank-4
+        // branch depend on the parametrisation)
+        int big = 9;
+        for (int c = 10 - k; c < 10; ++c) if (std::fabs(V[9][c]) > std::fabs(V[9][big])) big = c;
+        const int piv = std::fabs(V[9][9]) > 1e-3 * std::fabs(V[9][big]) ? 9 : big;
         double Vt[10][4];
         for (int i = 0; i < 10; ++i) Vt[i][k - 1] = V[i][piv] / V[9][piv];
         int a = 0;

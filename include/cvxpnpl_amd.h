@@ -154,6 +154,11 @@ size_t cvxpnpl_workspace_bytes(int64_t max_batch);
 int cvxpnpl_set_workspace(void *d_workspace, size_t bytes, void *stream);
 int cvxpnpl_release_workspace(void *stream, int32_t all_streams);
 
+/* Diagnostics: copy nbytes (a multiple of 16) from d_src to d_dst with 4, 8 or 16 bytes per lane -- a kernel of known
+ * HBM traffic, against which bench.py calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE counters for this path's access
+ * widths.  DEVICE pointers.  Returns 0, -1 bad arguments, -2 HIP error. */
+int cvxpnpl_calibration_copy(const void *d_src, void *d_dst, int64_t nbytes, int32_t bytes_per_lane, void *stream);
+
 /* HIP-event timing on the launch stream (for bench.py: torch.cuda.Event only sees torch's
  * current stream).  handles are opaque. */
 void *cvxpnpl_event_create(void);

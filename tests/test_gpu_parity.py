@@ -42,27 +42,122 @@ CASES = [(10, 0, 0.0, 256), (10, 0, 2.0, 256), (5, 5, 0.0, 128), (5, 5, 1.0, 128
 LAYOUTS = {"lane": 1, "wave": 2, "quad": 3}  # CVXPNPL_LAYOUT_*
 
 
+_ORACLE_CACHE = {}
+
+
+def _oracle_case(orc, d, n_p, n_l, key):
+    """the oracle's converged solve of EVERY problem of a case (shared by the three layouts)"""
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = orc.pnpl_batch(d["pts_2d"] if n_p else None, d["line_2d"] if n_l else None, d["pts_3d"] if n_p else None,
+                                            d["line_3d"] if n_l else None, d["K"], eps=1e-11, max_iters=200000)
+    return _ORACLE_CACHE[key]
+
+
+def _reference_A_B(orc, d, i, n_p, n_l):
+    """A (m x 9), B (3 x 9) of problem i the way cvxpnpl.pnp / pnl / pnpl build them (cvxpnpl.py:545-549, :577-580, :619-624)"""
+    Cs, Ns = [], []
+    if n_p:
+        (c1, c2, c3), (n1, n2, n3) = orc.point_constraints(d["pts_2d"][i], d["pts_3d"][i], d["K"] if d["K"].ndim == 2 else d["K"][i])
+        Cs += [c1, c2, c3]
+        Ns += [n1, n2, n3]
+    if n_l:
+        cl, nl = orc.line_constraints(d["line_2d"][i], d["line_3d"][i], d["K"] if d["K"].ndim == 2 else d["K"][i])
+        Cs.append(cl)
+        Ns.append(nl)
+    B, A = orc.eliminate(np.vstack(Cs), np.vstack(Ns))
+    return A, B
+
+
+def _check_uncertified_exits(orc, d, r, n_p, n_l, idx):
+    """Problems that left WITHOUT a certificate (status 1, 2, 4) follow the reference's recovery (cvxpnpl.py:499-513)
+    from the very Z the kernel returned: the oracle's restatement of that recovery, fed with the GPU's Z, must give
+    the GPU's pose.  Rank 1 (status 2 / 4): the same single pose, reflections included, to 1e-9.  Rank > 1 (status 1):
+    the pose is finite and orthogonal, t = -B r, and the reference-style multi-solution recovery of the product
+    (host side, unpolished) returns the oracle's poses."""
+    import cvxpnpl_amd as ca
+
+    n_cmp = 0
+    for i in idx:
+        st = int(r["status"][i])
+        A, B = _reference_A_B(orc, d, i, n_p, n_l)
+        poses, ost, ork = orc.recover(r["Z"][i], 0.0, A, B)
+        R, t = r["R"][i], r["t"][i]
+        assert np.isfinite(R).all() and np.isfinite(t).all(), (i, st)
+        assert np.abs(R @ R.T - np.eye(3)).max() < 1e-9
+        assert np.abs(t + B @ R.T.reshape(9)).max() < 1e-9 * max(1.0, np.abs(t).max())  # t = -B r, r = vec_colmajor(R)
+        if st in (2, 4):
+            assert ork == 1 and len(poses) == 1, (i, st, ork)
+            assert geodesic_np(R, poses[0][0]) < 1e-9 and np.abs(t - poses[0][1]).max() < 1e-9 * max(1.0, np.abs(t).max()), (i, st)
+            assert (np.linalg.det(R) < 0) == (st == 4)
+            n_cmp += 1
+        else:
+            assert st == 1 and ork > 1, (i, st, ork)
+            if any(not np.isfinite(Ro).all() for Ro, _ in poses):
+                continue  # the reference divides by a ~0 eigenvector entry there (DESIGN.md section 1.4)
+            mine = ca.recover_multi(r["Z"][i], B.reshape(27))
+            assert len(mine) == len(poses), (i, len(mine), len(poses))
+            for Rm, tm in mine:
+                assert min(geodesic_np(Rm, Ro) + np.abs(tm - to).max() for Ro, to in poses) < 1e-6, i
+            n_cmp += 1
+    return n_cmp
+
+
+def geodesic_np(Ra, Rb):
+    from cvxpnpl_amd import synth
+
+    return float(synth.geodesic(Ra[None], Rb[None])[0])
+
+
 @pytest.mark.parametrize("layout", sorted(LAYOUTS))
 @pytest.mark.parametrize("n_p,n_l,sigma,batch", CASES)
 def test_hip_vs_oracle(gpu, orc, n_p, n_l, sigma, batch, layout):
+    """EVERY problem of the case against the oracle's converged solve; the certified fraction is asserted from the
+    campaign numbers (profiles/r01/fuzz_parity.txt: 122 843 / 122 880), not merely 'most'."""
     from cvxpnpl_amd import synth
 
     d = synth.make_pnpl(batch, n_p, n_l, sigma, seed=200 + n_p + 7 * n_l)
-    r = _solve(gpu, d, n_p, n_l, layout=LAYOUTS[layout])
-    nb = min(batch, 48)
-    o = orc.pnpl_batch(d["pts_2d"][:nb] if n_p else None, d["line_2d"][:nb] if n_l else None, d["pts_3d"][:nb] if n_p else None,
-                       d["line_3d"][:nb] if n_l else None, d["K"], eps=1e-11, max_iters=200000)
-    ok = (r["status"][:nb] == 0) & (o["n_poses"] == 1)
-    assert ok.mean() > (0.5 if n_p == 4 else 0.9)
-    geo = synth.geodesic(r["R"][:nb], o["R"][:, 0])
-    terr = np.linalg.norm(r["t"][:nb] - o["t"][:, 0], axis=1) / np.linalg.norm(o["t"][:, 0], axis=1)
+    r = _solve(gpu, d, n_p, n_l, layout=LAYOUTS[layout], want_Z=True)
+    o = _oracle_case(orc, d, n_p, n_l, (n_p, n_l, sigma, batch))
+    cert = r["status"] == 0
+    one = o["n_poses"] == 1
+    ok = cert & one
+    # minimal sets (n = 4) are often not tight; everything else certifies -- at most one straggler per case
+    assert cert.sum() >= (0.5 * batch if n_p + n_l <= 4 else batch - 1), np.bincount(r["status"])
+    # a certified pose is THE optimum of the relaxation: the oracle, where it converged to one pose, found the same
+    assert (cert & ~one).sum() <= max(1, batch // 50), ((cert & ~one).sum(), batch)
+    geo = synth.geodesic(r["R"], o["R"][:, 0])
+    terr = np.linalg.norm(r["t"] - o["t"][:, 0], axis=1) / np.linalg.norm(o["t"][:, 0], axis=1)
     assert geo[ok].max() < TOL_ROT and terr[ok].max() < TOL_T, (geo[ok].max(), terr[ok].max())
-    c = r["cost"][r["status"] == 0]
+    c = r["cost"][cert]
     assert (c[:, 0] - c[:, 1] >= -1e-15).all() and (c[:, 0] - c[:, 1] <= 1e-9).all()
+    # every exit without a certificate: the reference's recovery of the returned Z
+    _check_uncertified_exits(orc, d, r, n_p, n_l, np.where(np.isin(r["status"], (1, 2, 4)))[0][:40])
+    assert not np.isin(r["status"], (3,)).any()
     if sigma == 0.0:
-        cert = r["status"] == 0
         assert cert.mean() > 0.98
         assert synth.geodesic(r["R"], d["R_gt"])[cert].max() < TOL_ROT
+
+
+@pytest.mark.parametrize("layout", sorted(LAYOUTS))
+def test_uncertified_exits_follow_reference_recovery(gpu, orc, layout):
+    """cvxpnpl.py:499-513 on the GPU: solves cut short (max_iters 2 .. 12, no certificate yet) must return what the
+    reference's recovery makes of the same Z -- rank-1 poses incl. reflections (status 2 / 4) bit-for-bit to 1e-9,
+    rank > 1 flagged with a finite candidate pose and the multi-solution recovery matching the oracle's."""
+    from cvxpnpl_amd import synth
+
+    seen = {1: 0, 2: 0, 4: 0}
+    for n_p, n_l, sigma, seed in ((10, 0, 2.0, 71), (5, 5, 1.0, 72), (4, 0, 1.0, 73), (0, 6, 1.0, 74)):
+        d = synth.make_pnpl(96, n_p, n_l, sigma, seed=seed)
+        for max_iters in (2, 3, 4, 6, 8, 12):
+            # first_check beyond the cap: the only certificate attempt is the one of the last iteration
+            r = _solve(gpu, d, n_p, n_l, layout=LAYOUTS[layout], max_iters=max_iters, first_check=1000, want_Z=True)
+            assert (r["iters"] <= max_iters).all()
+            idx = np.where(np.isin(r["status"], (1, 2, 4)))[0]
+            _check_uncertified_exits(orc, d, r, n_p, n_l, idx[:24])
+            for s_ in seen:
+                seen[s_] += int((r["status"] == s_).sum())
+            assert not (r["status"] == 3).any()
+    assert seen[1] > 50 and seen[2] > 50, seen  # both branches exercised (reflections are rare: reported, not required)
 
 
 def test_hip_equals_host_build_of_device_algorithm(gpu):
@@ -483,3 +578,41 @@ def test_planar_scene_in_a_general_frame(gpu, layout):
     assert max(err) < 1e-7
     Rone = res.R.cpu().numpy()
     assert max(min(synth.geodesic(Rone[i], R[i, k]) for k in range(2)) for i in sel) < 1e-7  # the returned pose is one of the twins
+
+
+def test_ransac_default_device_and_workspace_entry_points(gpu):
+    """ransac_pnp without `device` (advisor finding: the default used to raise), and the workspace entry points:
+    a caller-registered (torch-allocated) workspace gives the same results as the library's own, a too-small one is
+    refused, release frees the cached allocation."""
+    import ctypes as C
+
+    import torch
+
+    from cvxpnpl_amd import _lib, synth
+    from cvxpnpl_amd.ransac import ransac_pnp
+
+    d = synth.make_ransac(1, n_corr=60, outlier_frac=0.3, sigma=0.5, seed=5)
+    out = ransac_pnp(d["scene_2d"], d["scene_3d"], d["K"], n_hyp=1024)  # numpy in, no device
+    assert out["n_inliers"] >= 0.9 * int(d["inlier"].sum())
+    out2 = ransac_pnp(torch.as_tensor(d["scene_2d"], device=gpu), torch.as_tensor(d["scene_3d"], device=gpu), d["K"], n_hyp=1024)
+    assert out2["R"].device == gpu
+    L = _lib.lib()
+    dd = synth.make_planar_pnp(700, 8, 0.5, seed=21, general=True)  # planar: every problem goes through the queue
+    stream = C.c_void_p(torch.cuda.current_stream(gpu).cuda_stream)
+    ref = _solve(gpu, dd, 8, 0, layout=LAYOUTS["quad"], max_iters=200)
+    need = L.cvxpnpl_workspace_bytes(700)
+    assert need > 700 * 56 * 8
+    buf = torch.empty(need, dtype=torch.uint8, device=gpu)
+    assert L.cvxpnpl_set_workspace(C.c_void_p(buf.data_ptr()), need, stream) == 0
+    for layout in ("quad", "lane", "quad"):
+        r = _solve(gpu, dd, 8, 0, layout=LAYOUTS[layout], max_iters=200)
+        assert (r["status"] == ref["status"]).mean() > 0.995
+    big = synth.make_pnp(5000, 6, 1.0, seed=3)
+    with pytest.raises(RuntimeError, match="workspace"):
+        _solve(gpu, big, 6, 0, layout=LAYOUTS["quad"])
+    assert L.cvxpnpl_set_workspace(C.c_void_p(0), 0, stream) == 0  # back to the library's own allocation
+    r = _solve(gpu, big, 6, 0, layout=LAYOUTS["quad"])
+    assert (r["status"] == 0).mean() > 0.99
+    assert L.cvxpnpl_release_workspace(stream, 1) == 0
+    r2 = _solve(gpu, big, 6, 0, layout=LAYOUTS["quad"])
+    assert np.array_equal(r["R"], r2["R"])

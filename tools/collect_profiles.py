@@ -23,7 +23,7 @@ def counters(run):
     for f in glob.glob(os.path.join(src, run, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
         per = collections.defaultdict(lambda: collections.defaultdict(float))
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
             if "rocclr" in k:
                 continue
             per[(k, r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
