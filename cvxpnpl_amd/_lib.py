@@ -16,13 +16,14 @@ _ip = C.POINTER(C.c_int32)
 
 # every symbol include/cvxpnpl_amd.h declares
 EXPORTS = (
-    "cvxpnpl_default_opts", "cvxpnpl_solve_batch", "cvxpnpl_recover_multi", "cvxpnpl_recover_multi_batch", "cvxpnpl_assemble_batch",
+    "cvxpnpl_default_opts", "cvxpnpl_solve_batch", "cvxpnpl_solve_cost_batch", "cvxpnpl_recover_multi", "cvxpnpl_recover_multi_batch", "cvxpnpl_assemble_batch",
     "cvxpnpl_score_hypotheses", "cvxpnpl_pack_results",
     "cvxpnpl_workspace_bytes", "cvxpnpl_set_workspace", "cvxpnpl_release_workspace", "cvxpnpl_calibration_copy",
     "cvxpnpl_event_create", "cvxpnpl_event_record", "cvxpnpl_event_elapsed_ms", "cvxpnpl_event_destroy",
     "cvxpnpl_last_error", "cvxpnpl_version", "cvxpnpl_device_count",
 )
 
+VARIANT_FULL, VARIANT_RC = 0, 1
 STATUS_NAMES = {0: "certified", 1: "rank>1", 2: "uncertified", 3: "nonfinite", 4: "reflection"}
 
 
@@ -32,6 +33,7 @@ class Opts(C.Structure):
         ("eps", C.c_double), ("max_iters", C.c_int32), ("rho", C.c_double), ("alpha", C.c_double),
         ("first_check", C.c_int32), ("check_every", C.c_int32), ("res_tol", C.c_double),
         ("jacobi_sweeps", C.c_int32), ("jacobi_tol", C.c_double), ("warm_start", C.c_int32), ("rho_tail", C.c_double), ("tail_from", C.c_int32), ("lane_iters", C.c_int32), ("layout", C.c_int32),
+        ("variant", C.c_int32),
     ]
 
 
@@ -59,6 +61,9 @@ def lib():
                                       C.c_void_p, C.c_int32, C.POINTER(Opts), C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cvxpnpl_solve_batch.restype = C.c_int
+    L.cvxpnpl_solve_cost_batch.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(Opts), C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cvxpnpl_solve_cost_batch.restype = C.c_int
     L.cvxpnpl_assemble_batch.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cvxpnpl_assemble_batch.restype = C.c_int

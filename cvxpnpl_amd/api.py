@@ -14,7 +14,8 @@ import torch
 
 from . import _lib
 
-__all__ = ["pnp", "pnl", "pnpl", "pnp_batch", "pnl_batch", "pnpl_batch", "BatchResult", "score_hypotheses"]
+__all__ = ["pnp", "pnl", "pnpl", "pnp_batch", "pnl_batch", "pnpl_batch", "BatchResult", "score_hypotheses",
+           "solve_cost_batch", "solve_relaxation", "solve_relaxation_rc", "pack_cost"]
 
 
 class BatchResult(dict):
@@ -106,13 +107,7 @@ def pnpl_batch(pts_2d, line_2d, pts_3d, line_3d, K, eps: float = 1e-9, max_iters
         raise ValueError("K must be [3,3] or [batch,3,3]")
     opts = _lib.default_opts(eps=float(eps), max_iters=int(max_iters), **solver_opts)
     with torch.cuda.device(device):
-        R = torch.empty((batch, 3, 3), dtype=torch.float64, device=device)
-        t = torch.empty((batch, 3), dtype=torch.float64, device=device)
-        status = torch.empty((batch,), dtype=torch.int32, device=device)
-        iters = torch.empty((batch,), dtype=torch.int32, device=device)
-        cost = torch.empty((batch, 2), dtype=torch.float64, device=device)
-        work = torch.empty((batch, 2), dtype=torch.int32, device=device)
-        Z = torch.empty((batch, 55), dtype=torch.float64, device=device) if want_Z else None
+        R, t, status, iters, cost, work, Z = _alloc_outputs(batch, device, want_Z)
         stream = torch.cuda.current_stream(device).cuda_stream
         rc = L.cvxpnpl_solve_batch(batch, n_p, _ptr(p2), _ptr(p3), n_l, _ptr(l2), _ptr(l3), _ptr(Kd), per, C.byref(opts),
                                    _ptr(R), _ptr(t), _ptr(status), _ptr(iters), _ptr(cost), _ptr(Z), _ptr(work),
@@ -176,6 +171,82 @@ def recover_multi_batch(res: "BatchResult", B, Q=None, n_threads: int = 0):
     return R, t, cnt
 
 
+def _alloc_outputs(batch, device, want_Z):
+    R = torch.empty((batch, 3, 3), dtype=torch.float64, device=device)
+    t = torch.empty((batch, 3), dtype=torch.float64, device=device)
+    status = torch.empty((batch,), dtype=torch.int32, device=device)
+    iters = torch.empty((batch,), dtype=torch.int32, device=device)
+    cost = torch.empty((batch, 2), dtype=torch.float64, device=device)
+    work = torch.empty((batch, 2), dtype=torch.int32, device=device)
+    Z = torch.empty((batch, 55), dtype=torch.float64, device=device) if want_Z else None
+    return R, t, status, iters, cost, work, Z
+
+
+_IU9 = np.triu_indices(9)
+
+
+def pack_cost(Q):
+    """[..., 9, 9] symmetric (A^T A, cvxpnpl.py:475) -> [..., 45]: the upper triangle row by row, the layout of
+    cvxpnpl_solve_cost_batch's d_Q45 (and of assemble_batch's second output).  numpy or torch."""
+    return Q[..., _IU9[0], _IU9[1]]
+
+
+def solve_cost_batch(Q45, B27, eps: float = 1e-9, max_iters: int = 2500, want_Z: bool = False, variant: int = _lib.VARIANT_FULL,
+                     device=None, **solver_opts) -> BatchResult:
+    """The batched solve at the seam of the reference's _solve_relaxation(A, B, ...) (cvxpnpl.py:454-460): the caller
+    brings Q45 [B,45] (packed A^T A, see pack_cost / assemble_batch) and B27 [B,27] or [B,3,9] (t = -B r) instead of
+    correspondences.  variant=VARIANT_RC solves the reference's 16-equality ablation (benchmarks/toolkit/methods/rc.py)."""
+    _require_gpu()
+    L = _lib.lib()
+    if device is None:
+        device = Q45.device if isinstance(Q45, torch.Tensor) and Q45.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    Qd = _as_dev(Q45, device, (45,))
+    batch = Qd.shape[0] if Qd.dim() == 2 else 1
+    Qd = Qd.reshape(batch, 45)
+    Bd = torch.as_tensor(np.ascontiguousarray(B27, dtype=np.float64)) if not isinstance(B27, torch.Tensor) else B27
+    Bd = Bd.to(device=device, dtype=torch.float64).contiguous()
+    if Bd.numel() != batch * 27:
+        raise ValueError(f"B {tuple(Bd.shape)} does not match {batch} problems x (3 x 9)")
+    Bd = Bd.reshape(batch, 27)
+    opts = _lib.default_opts(eps=float(eps), max_iters=int(max_iters), variant=int(variant), **solver_opts)
+    with torch.cuda.device(device):
+        R, t, status, iters, cost, work, Z = _alloc_outputs(batch, device, want_Z)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        rc = L.cvxpnpl_solve_cost_batch(batch, _ptr(Qd), _ptr(Bd), C.byref(opts), _ptr(R), _ptr(t), _ptr(status), _ptr(iters),
+                                        _ptr(cost), _ptr(Z), _ptr(work), C.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError(f"cvxpnpl_solve_cost_batch failed ({rc}): {_lib.last_error()}")
+    out = BatchResult(R=R, t=t, status=status, iters=iters, cost=cost, work=work)
+    if want_Z:
+        out["Z"] = Z
+    return out
+
+
+def _poses_of_single(res, Bt, Qt, verbose, certify_warning=True) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """List[(R, t)] of a one-problem BatchResult, with the reference's NaN sentinel (cvxpnpl.py:493-498), rank > 1
+    branch (:507) and "not certifiably optimal" warning (:516-519)."""
+    status = int(res.status[0])
+    if status == 3:  # cvxpnpl.py:493-498
+        if verbose:
+            warnings.warn("The SDP solver did not return a valid solution. Increasing max_iters might solve the issue.")
+        return [(np.full((3, 3), np.nan), np.full(3, np.nan))]
+    if status == 1:  # rank > 1: cvxpnpl.py:507
+        poses = recover_multi(res.Z[0].cpu().numpy(), Bt, Qt)
+        # cvxpnpl.py:516-519: warn unless |cost - dobj| <= eps.  A certified twin pair (exact two-fold ambiguity,
+        # e.g. a planar scene) carries its certified lower bound in cost[1]; an uncertified exit has NaN there.
+        # (the kernel writes a finite dobj only with 0 <= cost - dobj <= max(eps, 8e-13 tr Q) established)
+        if certify_warning and not np.isfinite(float(res.cost[0, 1])):
+            warnings.warn("The solution is not certifiably optimal.")
+        return poses
+    if status != 0 and certify_warning:  # cvxpnpl.py:517-519
+        warnings.warn("The solution is not certifiably optimal.")
+    if verbose:
+        print(f"cvxpnpl_amd: status={_lib.STATUS_NAMES[status]} iters={int(res.iters[0])} "
+              f"cost={float(res.cost[0, 0]):.3e} dobj={float(res.cost[0, 1]):.3e}")
+    return [(res.R[0].cpu().numpy(), res.t[0].cpu().numpy())]
+
+
 def _single(pts_2d, line_2d, pts_3d, line_3d, K, eps, max_iters, verbose) -> List[Tuple[np.ndarray, np.ndarray]]:
     def b(x, tail):
         if x is None:
@@ -189,26 +260,29 @@ def _single(pts_2d, line_2d, pts_3d, line_3d, K, eps, max_iters, verbose) -> Lis
     # res_tol = 0: an uncertifiable problem runs to max_iters like the reference's solve (the batch entry points
     # stop such problems at the fixed-point residual opts.res_tol instead)
     res = pnpl_batch(p2, l2, p3, l3, Kn, eps=eps, max_iters=max_iters, want_Z=True, res_tol=0.0)
-    status = int(res.status[0])
-    if status == 3:  # cvxpnpl.py:493-498
-        if verbose:
-            warnings.warn("The SDP solver did not return a valid solution. Increasing max_iters might solve the issue.")
-        return [(np.full((3, 3), np.nan), np.full(3, np.nan))]
-    if status == 1:  # rank > 1: cvxpnpl.py:507
+    Bt = Qt = None
+    if int(res.status[0]) == 1:
         Bt, Qt = _translation_map(p2, l2, p3, l3, Kn)
-        poses = recover_multi(res.Z[0].cpu().numpy(), Bt, Qt)
-        # cvxpnpl.py:516-519: warn unless |cost - dobj| <= eps.  A certified twin pair (exact two-fold ambiguity,
-        # e.g. a planar scene) carries its certified lower bound in cost[1]; an uncertified exit has NaN there.
-        # (the kernel writes a finite dobj only with 0 <= cost - dobj <= max(eps, 8e-13 tr Q) established)
-        if not np.isfinite(float(res.cost[0, 1])):
-            warnings.warn("The solution is not certifiably optimal.")
-        return poses
-    if status != 0:  # cvxpnpl.py:517-519
-        warnings.warn("The solution is not certifiably optimal.")
-    if verbose:
-        print(f"cvxpnpl_amd: status={_lib.STATUS_NAMES[status]} iters={int(res.iters[0])} "
-              f"cost={float(res.cost[0, 0]):.3e} dobj={float(res.cost[0, 1]):.3e}")
-    return [(res.R[0].cpu().numpy(), res.t[0].cpu().numpy())]
+    return _poses_of_single(res, Bt, Qt, verbose)
+
+
+def solve_relaxation(A: np.ndarray, B: np.ndarray, eps: float = 1e-9, max_iters: int = 2500, verbose: bool = False,
+                     variant: int = _lib.VARIANT_FULL) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """Drop-in for the reference's private _solve_relaxation(A, B, eps, max_iters, verbose) (cvxpnpl.py:454-520),
+    the seam its benchmark harness calls directly (benchmarks/toolkit/methods/pnp.py:4): A (m x 9) with A r = 0,
+    B (3 x 9) with t = -B r.  The cost A^T A is formed here (cvxpnpl.py:475) and solved on the GPU."""
+    A = np.asarray(A, dtype=np.float64)
+    Bn = np.ascontiguousarray(B, dtype=np.float64).reshape(27)
+    Q45 = np.ascontiguousarray(pack_cost(A.T @ A))
+    res = solve_cost_batch(Q45[None], Bn[None], eps=eps, max_iters=max_iters, want_Z=True, variant=variant, res_tol=0.0)
+    # the reference's rc variant returns its poses without the certificate check (rc.py:118-131)
+    return _poses_of_single(res, Bn, Q45, verbose, certify_warning=(variant == _lib.VARIANT_FULL))
+
+
+def solve_relaxation_rc(A: np.ndarray, B: np.ndarray, eps: float = 1e-9, max_iters: int = 2500, verbose: bool = False):
+    """Drop-in for _solve_relaxation_rc (benchmarks/toolkit/methods/rc.py:67-131): the relaxation without the six
+    row-orthonormality equalities."""
+    return solve_relaxation(A, B, eps=eps, max_iters=max_iters, verbose=verbose, variant=_lib.VARIANT_RC)
 
 
 def assemble_batch(pts_2d, line_2d, pts_3d, line_3d, K, device=None):

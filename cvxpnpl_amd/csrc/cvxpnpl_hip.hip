@@ -23,6 +23,7 @@ struct BatchArgs {
     const double *p2, *p3, *l2, *l3, *K;
     double *R, *t, *cost, *Z;
     int32_t *status, *iters, *work;
+    const double *Q45, *B27; // cost entry (cvxpnpl_solve_cost_batch)
 };
 
 // ---------------------------------------------------------------------------------------
@@ -37,6 +38,7 @@ __global__ void __launch_bounds__(64) solve_lane_kernel(BatchArgs a, cvx::Opts o
     int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= a.batch) return;
     cvx::ProblemView pv = cvx::make_view(b, a.n_p, a.p2, a.p3, a.n_l, a.l2, a.l3, a.K, a.K_per_problem);
+    if (a.Q45) { pv.Q45 = a.Q45 + b * 45; pv.B27 = a.B27 + b * 27; }
     cvx::Solution sol;
     double Z[55];
     // TWIN = false: the hand-off comes before iteration 6, where the twin-candidate logic would start.
@@ -94,6 +96,12 @@ struct Workspace { void *ptr = nullptr; size_t bytes = 0; int64_t cap = 0; bool 
 std::mutex g_ws_mutex;
 std::map<std::pair<int, void *>, Workspace> g_ws;
 thread_local char g_err[512] = "";
+
+void launch_wave(int64_t wgrid, hipStream_t s, const cvxw::WaveArgs &w, const cvx::Opts &o)
+{
+    if (o.variant == cvx::VAR_RC) hipLaunchKernelGGL(cvxw::solve_wave_kernel<cvx::VAR_RC>, dim3((unsigned)wgrid), dim3(64 * cvxw::WPB), 0, s, w, o);
+    else hipLaunchKernelGGL(cvxw::solve_wave_kernel<cvx::VAR_FULL>, dim3((unsigned)wgrid), dim3(64 * cvxw::WPB), 0, s, w, o);
+}
 
 size_t hybrid_queue_bytes(int64_t cap) { return 256 + (((size_t)(cap + cvxw::RESUME_GRID_MAX) * sizeof(int32_t) + 255) & ~(size_t)255); }
 size_t hybrid_ws_bytes(int64_t cap) { return hybrid_queue_bytes(cap) + (size_t)cap * 56 * sizeof(double); }
@@ -157,6 +165,7 @@ cvx::Opts to_core(const cvxpnpl_opts_t *opts)
         o.eps = opts->eps; o.max_iters = opts->max_iters; o.rho = opts->rho; o.alpha = opts->alpha;
         o.first_check = opts->first_check; o.check_every = opts->check_every; o.res_tol = opts->res_tol;
         o.jacobi_sweeps = opts->jacobi_sweeps; o.jacobi_tol = opts->jacobi_tol; o.warm_start = opts->warm_start; o.rho_tail = opts->rho_tail; o.tail_from = opts->tail_from;
+        o.variant = opts->variant;
     }
     return o;
 }
@@ -185,7 +194,7 @@ void cvxpnpl_default_opts(cvxpnpl_opts_t *opts)
     cvx::Opts o = cvx::default_opts();
     opts->eps = o.eps; opts->max_iters = o.max_iters; opts->rho = o.rho; opts->alpha = o.alpha;
     opts->first_check = o.first_check; opts->check_every = o.check_every; opts->res_tol = o.res_tol;
-    opts->jacobi_sweeps = o.jacobi_sweeps; opts->jacobi_tol = o.jacobi_tol; opts->warm_start = o.warm_start; opts->rho_tail = o.rho_tail; opts->tail_from = o.tail_from; opts->lane_iters = -1; opts->layout = CVXPNPL_LAYOUT_AUTO;
+    opts->jacobi_sweeps = o.jacobi_sweeps; opts->jacobi_tol = o.jacobi_tol; opts->warm_start = o.warm_start; opts->rho_tail = o.rho_tail; opts->tail_from = o.tail_from; opts->lane_iters = -1; opts->layout = CVXPNPL_LAYOUT_AUTO; opts->variant = CVXPNPL_VARIANT_FULL;
 }
 
 static int check_args(int64_t batch, int32_t n_p, const double *p2, const double *p3, int32_t n_l, const double *l2,
@@ -198,23 +207,16 @@ static int check_args(int64_t batch, int32_t n_p, const double *p2, const double
     return 0;
 }
 
-int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, const double *d_pts_3d, int32_t n_l,
-                        const double *d_line_2d, const double *d_line_3d, const double *d_K, int32_t K_per_problem,
-                        const cvxpnpl_opts_t *opts, double *d_R, double *d_t, int32_t *d_status, int32_t *d_iters,
-                        double *d_cost, double *d_Z, int32_t *d_work, void *stream)
+// the launches of one solve: layout policy + kernels (shared by the correspondence entry and the cost entry)
+static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *stream)
 {
-    if (batch == 0) return 0; /* empty batch: nothing to do (pointers may be NULL) */
-    if (check_args(batch, n_p, d_pts_2d, d_pts_3d, n_l, d_line_2d, d_line_3d, d_K)) return -1;
-    if (!d_R || !d_t || !d_status) { snprintf(g_err, sizeof(g_err), "cvxpnpl: R, t and status outputs are required"); return -1; }
-    if (opts && (opts->max_iters < 1 || !(opts->rho > 0) || !(opts->eps > 0) || opts->check_every < 1 || opts->first_check < 1)) {
+    const int64_t batch = a.batch;
+    if (!a.R || !a.t || !a.status) { snprintf(g_err, sizeof(g_err), "cvxpnpl: R, t and status outputs are required"); return -1; }
+    if (opts && (opts->max_iters < 1 || !(opts->rho > 0) || !(opts->eps > 0) || opts->check_every < 1 || opts->first_check < 1 ||
+                 (opts->variant != CVXPNPL_VARIANT_FULL && opts->variant != CVXPNPL_VARIANT_RC))) {
         snprintf(g_err, sizeof(g_err), "cvxpnpl: bad options");
         return -1;
     }
-    if (batch == 0) return 0;
-    BatchArgs a;
-    a.batch = batch; a.n_p = n_p; a.n_l = n_l; a.K_per_problem = K_per_problem;
-    a.p2 = d_pts_2d; a.p3 = d_pts_3d; a.l2 = d_line_2d; a.l3 = d_line_3d; a.K = d_K;
-    a.R = d_R; a.t = d_t; a.cost = d_cost; a.Z = d_Z; a.status = d_status; a.iters = d_iters; a.work = d_work;
     cvx::Opts o = to_core(opts);
     hipStream_t s = (hipStream_t)stream;
     const int block = 64;
@@ -233,12 +235,16 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
     // The problems the quad phase leaves open are finished by the same wavefront, those of the lane phase
     // by a second kernel, one per wavefront in both cases.
     if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 3584 ? CVXPNPL_LAYOUT_WAVE : (batch < 38912 ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
+    // the 16-equality variant (benchmarks/toolkit/methods/rc.py) is built for the wave-per-problem layout only
+    if (o.variant == cvx::VAR_RC) layout = CVXPNPL_LAYOUT_WAVE;
     cvxw::WaveArgs w;
-    w.batch = batch; w.n_p = n_p; w.n_l = n_l; w.K_per_problem = K_per_problem;
-    w.p2 = d_pts_2d; w.p3 = d_pts_3d; w.l2 = d_line_2d; w.l3 = d_line_3d; w.K = d_K;
-    w.R = d_R; w.t = d_t; w.cost = d_cost; w.Z = d_Z; w.status = d_status; w.iters = d_iters; w.work = d_work;
+    w.batch = batch; w.n_p = a.n_p; w.n_l = a.n_l; w.K_per_problem = a.K_per_problem;
+    w.p2 = a.p2; w.p3 = a.p3; w.l2 = a.l2; w.l3 = a.l3; w.K = a.K;
+    w.R = a.R; w.t = a.t; w.cost = a.cost; w.Z = a.Z; w.status = a.status; w.iters = a.iters; w.work = a.work;
+    w.Q45 = a.Q45; w.B27 = a.B27;
     int quad_iters = opts ? opts->lane_iters : -1;
     if (quad_iters <= 0) quad_iters = 10; // measured optimum 8-12 at every launch size (tools/quad_tune.sh)
+    if (layout == 9 || layout == 8) layout = CVXPNPL_LAYOUT_QUAD; // experiment: quad iterations only (solve_quad_kernel<1>)
     if (layout == CVXPNPL_LAYOUT_QUAD && !(quad_iters >= 1 && o.max_iters > quad_iters)) layout = CVXPNPL_LAYOUT_WAVE;
     if (layout == CVXPNPL_LAYOUT_QUAD) {
         // four problems per wavefront for the first quad_iters iterations, survivors resumed one per wavefront
@@ -250,13 +256,15 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
         int32_t *count = wv.count, *entries = wv.entries;
         double *ws = wv.parked;
         const int64_t qgrid = (batch + 3) / 4;
-        hipLaunchKernelGGL(cvxq::solve_quad_kernel, dim3((unsigned)qgrid), dim3(64), 0, s, w, o, quad_iters, count, entries, ws);
+        if (opts && opts->layout == 9) hipLaunchKernelGGL((cvxq::solve_quad_kernel<1, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, w, o, quad_iters, count, entries, ws); // experiment
+        else if (opts && opts->layout == 8) hipLaunchKernelGGL((cvxq::solve_quad_kernel<1, 4>), dim3((unsigned)qgrid), dim3(64), 0, s, w, o, quad_iters, count, entries, ws); // experiment
+        else hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, w, o, quad_iters, count, entries, ws);
         const int64_t rgrid = batch < cvxw::RESUME_GRID_MAX ? batch : cvxw::RESUME_GRID_MAX;
         hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64 * cvxw::WPB), 0, s, w, o, count, entries, (const double *)ws);
     } else if (layout == CVXPNPL_LAYOUT_WAVE) {
         int64_t wgrid = (batch + cvxw::WPB - 1) / cvxw::WPB;
         if (wgrid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }
-        hipLaunchKernelGGL(cvxw::solve_wave_kernel, dim3((unsigned)wgrid), dim3(64 * cvxw::WPB), 0, s, w, o);
+        launch_wave(wgrid, s, w, o);
     } else {
         // hand-off point of the hybrid schedule (<= 0: default): right after the first certificate attempt, which
         // comes at iteration 5 (opts.first_check) -- 6 and 7 are slower: 110 / 105 / 100 M poses/s at 125 k.
@@ -278,12 +286,40 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
         } else {
             // fewer iterations allowed than the lane phase would run: the wave kernel does the whole solve
             int64_t wgrid = (batch + cvxw::WPB - 1) / cvxw::WPB;
-            hipLaunchKernelGGL(cvxw::solve_wave_kernel, dim3((unsigned)wgrid), dim3(64 * cvxw::WPB), 0, s, w, o);
+            launch_wave(wgrid, s, w, o);
         }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err("solve kernel launch", e);
     return 0;
+}
+
+int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, const double *d_pts_3d, int32_t n_l,
+                        const double *d_line_2d, const double *d_line_3d, const double *d_K, int32_t K_per_problem,
+                        const cvxpnpl_opts_t *opts, double *d_R, double *d_t, int32_t *d_status, int32_t *d_iters,
+                        double *d_cost, double *d_Z, int32_t *d_work, void *stream)
+{
+    if (batch == 0) return 0; /* empty batch: nothing to do (pointers may be NULL) */
+    if (check_args(batch, n_p, d_pts_2d, d_pts_3d, n_l, d_line_2d, d_line_3d, d_K)) return -1;
+    BatchArgs a;
+    a.batch = batch; a.n_p = n_p; a.n_l = n_l; a.K_per_problem = K_per_problem;
+    a.p2 = d_pts_2d; a.p3 = d_pts_3d; a.l2 = d_line_2d; a.l3 = d_line_3d; a.K = d_K;
+    a.R = d_R; a.t = d_t; a.cost = d_cost; a.Z = d_Z; a.status = d_status; a.iters = d_iters; a.work = d_work;
+    a.Q45 = nullptr; a.B27 = nullptr;
+    return launch_solve(a, opts, stream);
+}
+
+int cvxpnpl_solve_cost_batch(int64_t batch, const double *d_Q45, const double *d_B27, const cvxpnpl_opts_t *opts, double *d_R,
+                             double *d_t, int32_t *d_status, int32_t *d_iters, double *d_cost, double *d_Z, int32_t *d_work, void *stream)
+{
+    if (batch == 0) return 0;
+    if (batch < 0 || !d_Q45 || !d_B27) { snprintf(g_err, sizeof(g_err), "cvxpnpl_solve_cost_batch: bad arguments (batch=%lld)", (long long)batch); return -1; }
+    BatchArgs a;
+    memset(&a, 0, sizeof(a));
+    a.batch = batch;
+    a.R = d_R; a.t = d_t; a.cost = d_cost; a.Z = d_Z; a.status = d_status; a.iters = d_iters; a.work = d_work;
+    a.Q45 = d_Q45; a.B27 = d_B27;
+    return launch_solve(a, opts, stream);
 }
 
 int cvxpnpl_assemble_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, const double *d_pts_3d, int32_t n_l,

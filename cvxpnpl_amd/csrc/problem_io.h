@@ -12,6 +12,7 @@ namespace cvx {
 struct ProblemView {
     int n_p, n_l;
     const double *p2, *p3, *l2, *l3, *K;
+    const double *Q45, *B27; // cost entry (cvxpnpl_solve_cost_batch): A^T A packed and B given, nothing to assemble
 };
 
 CVX_HD ProblemView make_view(long b, int n_p, const double *pts_2d, const double *pts_3d, int n_l, const double *line_2d,
@@ -23,7 +24,8 @@ CVX_HD ProblemView make_view(long b, int n_p, const double *pts_2d, const double
     v.p3 = n_p ? pts_3d + b * n_p * 3 : nullptr;
     v.l2 = n_l ? line_2d + b * n_l * 4 : nullptr;
     v.l3 = n_l ? line_3d + b * n_l * 6 : nullptr;
-    v.K = K + (K_per_problem ? b * 9 : 0);
+    v.K = K ? K + (K_per_problem ? b * 9 : 0) : nullptr;
+    v.Q45 = nullptr; v.B27 = nullptr;
     return v;
 }
 
@@ -42,17 +44,23 @@ CVX_HD bool assemble(const ProblemView &v, double *B, double *Q9)
     return ok && (det == det) && det != 0.0;
 }
 
-template <bool TWIN = true, class ST = RegStore>
+template <bool TWIN = true, class ST = RegStore, int VAR = VAR_FULL>
 CVX_HD void solve_problem(const ProblemView &v, const Opts &o, Solution &sol, double *Zout, int handoff_at = 0,
                           double *handoff = nullptr, ST st = ST())
 {
     double B[27], Q9[45];
-    bool ok = assemble(v, B, Q9);
+    bool ok = true;
+    if (v.Q45) { // the seam of cvxpnpl.py:454-460: the caller brings A^T A and B
+        CVX_UNROLL for (int i = 0; i < 45; ++i) Q9[i] = v.Q45[i];
+        CVX_UNROLL for (int i = 0; i < 27; ++i) B[i] = v.B27[i];
+    } else {
+        ok = assemble(v, B, Q9);
+    }
     if (!ok) { // singular N^T N or K: the reference raises LinAlgError; report a NaN pose
         CVX_UNROLL for (int i = 0; i < 45; ++i) Q9[i] = NAN;
         CVX_UNROLL for (int i = 0; i < 27; ++i) B[i] = NAN;
     }
-    solve_sdp<TWIN, ST>(Q9, B, o, sol, Zout, handoff_at, handoff, st);
+    solve_sdp<TWIN, ST, VAR>(Q9, B, o, sol, Zout, handoff_at, handoff, st);
     if (!ok) { CVX_UNROLL for (int i = 0; i < 3; ++i) sol.t[i] = NAN; }
 }
 

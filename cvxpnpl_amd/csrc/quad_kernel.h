@@ -228,7 +228,11 @@ __device__ __noinline__ void finish_own(const WaveArgs &a, const cvx::Opts &o, u
     }
 }
 
-__global__ void __launch_bounds__(64, 2) solve_quad_kernel(WaveArgs a, cvx::Opts o, int handoff_at, int32_t *qcount, int32_t *qentries, double *ws)
+// MODE 0: the schedule described above.  MODE 1 (experiment, tools/phase_a_time.sh): the iterations only -- no
+// certificate code is compiled in, every problem is parked after handoff_at iterations -- to measure what the
+// iteration phase costs at the occupancy it gets without the certificate's registers.
+template <int MODE, int OCC = 2>
+__global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Opts o, int handoff_at, int32_t *qcount, int32_t *qentries, double *ws)
 {
     __shared__ __attribute__((aligned(16))) double lds_all[4 * QLDS];
     const int lane = threadIdx.x & 63, gl = lane & 15, grp = lane >> 4;
@@ -253,119 +257,127 @@ __global__ void __launch_bounds__(64, 2) solve_quad_kernel(WaveArgs a, cvx::Opts
     const int lane_base4 = (lane & 48) << 2;
 
     // ---------------------------------------------------------------- assembly (cvxpnpl.py:20-153, :545-549)
-    cvx::ProblemView pv = cvx::make_view(b, a.n_p, a.p2, a.p3, a.n_l, a.l2, a.l3, a.K, a.K_per_problem);
-    double Ki[9];
-    bool okK;
-    {
-        double Kc[9], det;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) Kc[i] = pv.K[i];
-        cvx::inv3(Kc, Ki, det);
-        okK = (det == det) && det != 0.0;
-    }
-    // Gram sums: role r = gl + 16 m < 60 is  sum rec[6 + qa] rec[6 + qb] rec[te]  with rec = (T[6], 1, P[3]):
-    // M0 (6): qa = qb = 0 | M1 (3 x 6): qa = 1 + a | M2 (6 x 6): qa = 1 + a, qb = 1 + b
-    int rqa[4], rqb[4], rte[4];
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int r = gl + 16 * m;
-        const int al = r < 60 ? r : 0;
-        int qa = 0, qb = 0, te = al;
-        if (al >= 6 && al < 24) { qa = 1 + (al - 6) / 6; te = (al - 6) % 6; }
-        if (al >= 24) {
-            const int ab = (al - 24) / 6;
-            te = (al - 24) % 6;
-            qa = 1 + (ab < 3 ? 0 : (ab < 5 ? 1 : 2));
-            qb = 1 + (ab < 3 ? ab : (ab < 5 ? ab - 2 : 2));
-        }
-        rqa[m] = 6 + qa; rqb[m] = 6 + qb; rte[m] = te;
-    }
-    const int nrec = pv.n_p + 2 * pv.n_l;
-    for (int base = 0; base < nrec; base += 16) {
-        const int cnt = nrec - base < 16 ? nrec - base : 16;
-        if (gl < cnt) {
-            const int r = base + gl;
-            double T[6], P[3];
-            if (r < pv.n_p) {
-                double p[3];
-                cvx::bearing(Ki, pv.p2[2 * r], pv.p2[2 * r + 1], p);
-                const double n2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
-                T[0] = n2 - p[0] * p[0]; T[1] = -p[0] * p[1]; T[2] = -p[0] * p[2];
-                T[3] = n2 - p[1] * p[1]; T[4] = -p[1] * p[2]; T[5] = n2 - p[2] * p[2];
-                P[0] = pv.p3[3 * r]; P[1] = pv.p3[3 * r + 1]; P[2] = pv.p3[3 * r + 2];
-            } else {
-                const int li = (r - pv.n_p) >> 1, en = (r - pv.n_p) & 1;
-                const double *l2 = pv.l2 + 4 * li, *l3 = pv.l3 + 6 * li + 3 * en;
-                double u[3], v[3];
-                cvx::bearing(Ki, l2[0], l2[1], u);
-                cvx::bearing(Ki, l2[2], l2[3], v);
-                double n[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
-                const double inv = cvx::rsqrt_(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-                n[0] *= inv; n[1] *= inv; n[2] *= inv;
-                T[0] = n[0] * n[0]; T[1] = n[0] * n[1]; T[2] = n[0] * n[2]; T[3] = n[1] * n[1]; T[4] = n[1] * n[2]; T[5] = n[2] * n[2];
-                P[0] = l3[0]; P[1] = l3[1]; P[2] = l3[2];
-            }
-            double *rec = L + Q_WF + gl * 10;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) rec[i] = T[i];
-            rec[6] = 1.0; rec[7] = P[0]; rec[8] = P[1]; rec[9] = P[2];
-        }
-        CVXW_SYNC();
-        for (int c = 0; c < cnt; ++c) {
-            const double *rec = L + Q_WF + c * 10;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] += rec[rqa[m]] * rec[rqb[m]] * rec[rte[m]];
-        }
-        CVXW_SYNC();
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-        if (gl + 16 * m < 60) L[Q_WF + gl + 16 * m] = acc[m];
-    CVXW_SYNC();
-    // B = M0^-1 [M1_0 M1_1 M1_2], Q = M2 - M1^T B
-    bool okG;
-    {
-        const double *mm = L + Q_WF;
-        double M0[9] = {mm[0], mm[1], mm[2], mm[1], mm[3], mm[4], mm[2], mm[4], mm[5]}, Mi[9], det;
-        cvx::inv3(M0, Mi, det);
-        const double sc = mm[0] + mm[3] + mm[5];
-        okG = det > 1e-12 * (sc * sc * sc) * (1.0 / 27.0);
-        if (gl < 9) {
-            double sel = Mi[0];
-#pragma unroll
-            for (int i = 1; i < 9; ++i) sel = gl == i ? Mi[i] : sel;
-            L[Q_X + gl] = sel;
-        }
-    }
-    CVXW_SYNC();
-    // packed index of (i, j) in a symmetric 3x3 (00 01 02 11 12 22)
-    auto psym = [](int i, int j) { const int lo = i < j ? i : j, hi = i < j ? j : i; return lo * 3 - (lo == 2 ? 1 : 0) + (hi - lo); };
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int idx = gl + 16 * m;
-        if (idx < 27) {
-            const int bb = idx / 9, i = (idx % 9) / 3, j = idx % 3;
-            const double *m1 = L + Q_WF + 6 + 6 * bb;
-            double v = 0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) v += L[Q_X + i * 3 + k] * m1[psym(k, j)];
-            L[Q_B + i * 9 + 3 * bb + j] = v; // B[i][3 bb + j]
-        }
-    }
-    CVXW_SYNC();
+    bool okK = true, okG = true;
     double Qs[4];
+    if (a.Q45) {
+        // cost entry (the seam of cvxpnpl.py:454-460): A^T A (packed 9x9) and B come from the caller
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        double v = 0.0;
-        if (w.ok[m] && w.ej[m] < 9) {
-            const int qa = w.ei[m] / 3, qi = w.ei[m] % 3, qb = w.ej[m] / 3, qj = w.ej[m] % 3;
-            const double *m1 = L + Q_WF + 6 + 6 * qa, *m2 = L + Q_WF + 24 + 6 * psym(qa, qb);
-            v = m2[psym(qi, qj)];
+        for (int m = 0; m < 4; ++m) Qs[m] = (w.ok[m] && w.ej[m] < 9) ? a.Q45[b * 45 + cvx::qidx(w.ei[m], w.ej[m])] : 0.0;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) v -= m1[psym(qi, k)] * L[Q_B + k * 9 + 3 * qb + qj];
+        for (int m = 0; m < 2; ++m)
+            if (gl + 16 * m < 27) L[Q_B + gl + 16 * m] = a.B27[b * 27 + gl + 16 * m];
+    } else {
+        cvx::ProblemView pv = cvx::make_view(b, a.n_p, a.p2, a.p3, a.n_l, a.l2, a.l3, a.K, a.K_per_problem);
+        double Ki[9];
+        {
+            double Kc[9], det;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Kc[i] = pv.K[i];
+            cvx::inv3(Kc, Ki, det);
+            okK = (det == det) && det != 0.0;
         }
-        Qs[m] = v;
+        // Gram sums: role r = gl + 16 m < 60 is  sum rec[6 + qa] rec[6 + qb] rec[te]  with rec = (T[6], 1, P[3]):
+        // M0 (6): qa = qb = 0 | M1 (3 x 6): qa = 1 + a | M2 (6 x 6): qa = 1 + a, qb = 1 + b
+        int rqa[4], rqb[4], rte[4];
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int r = gl + 16 * m;
+            const int al = r < 60 ? r : 0;
+            int qa = 0, qb = 0, te = al;
+            if (al >= 6 && al < 24) { qa = 1 + (al - 6) / 6; te = (al - 6) % 6; }
+            if (al >= 24) {
+                const int ab = (al - 24) / 6;
+                te = (al - 24) % 6;
+                qa = 1 + (ab < 3 ? 0 : (ab < 5 ? 1 : 2));
+                qb = 1 + (ab < 3 ? ab : (ab < 5 ? ab - 2 : 2));
+            }
+            rqa[m] = 6 + qa; rqb[m] = 6 + qb; rte[m] = te;
+        }
+        const int nrec = pv.n_p + 2 * pv.n_l;
+        for (int base = 0; base < nrec; base += 16) {
+            const int cnt = nrec - base < 16 ? nrec - base : 16;
+            if (gl < cnt) {
+                const int r = base + gl;
+                double T[6], P[3];
+                if (r < pv.n_p) {
+                    double p[3];
+                    cvx::bearing(Ki, pv.p2[2 * r], pv.p2[2 * r + 1], p);
+                    const double n2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+                    T[0] = n2 - p[0] * p[0]; T[1] = -p[0] * p[1]; T[2] = -p[0] * p[2];
+                    T[3] = n2 - p[1] * p[1]; T[4] = -p[1] * p[2]; T[5] = n2 - p[2] * p[2];
+                    P[0] = pv.p3[3 * r]; P[1] = pv.p3[3 * r + 1]; P[2] = pv.p3[3 * r + 2];
+                } else {
+                    const int li = (r - pv.n_p) >> 1, en = (r - pv.n_p) & 1;
+                    const double *l2 = pv.l2 + 4 * li, *l3 = pv.l3 + 6 * li + 3 * en;
+                    double u[3], v[3];
+                    cvx::bearing(Ki, l2[0], l2[1], u);
+                    cvx::bearing(Ki, l2[2], l2[3], v);
+                    double n[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+                    const double inv = cvx::rsqrt_(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                    n[0] *= inv; n[1] *= inv; n[2] *= inv;
+                    T[0] = n[0] * n[0]; T[1] = n[0] * n[1]; T[2] = n[0] * n[2]; T[3] = n[1] * n[1]; T[4] = n[1] * n[2]; T[5] = n[2] * n[2];
+                    P[0] = l3[0]; P[1] = l3[1]; P[2] = l3[2];
+                }
+                double *rec = L + Q_WF + gl * 10;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) rec[i] = T[i];
+                rec[6] = 1.0; rec[7] = P[0]; rec[8] = P[1]; rec[9] = P[2];
+            }
+            CVXW_SYNC();
+            for (int c = 0; c < cnt; ++c) {
+                const double *rec = L + Q_WF + c * 10;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] += rec[rqa[m]] * rec[rqb[m]] * rec[rte[m]];
+            }
+            CVXW_SYNC();
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (gl + 16 * m < 60) L[Q_WF + gl + 16 * m] = acc[m];
+        CVXW_SYNC();
+        // B = M0^-1 [M1_0 M1_1 M1_2], Q = M2 - M1^T B
+        {
+            const double *mm = L + Q_WF;
+            double M0[9] = {mm[0], mm[1], mm[2], mm[1], mm[3], mm[4], mm[2], mm[4], mm[5]}, Mi[9], det;
+            cvx::inv3(M0, Mi, det);
+            const double sc = mm[0] + mm[3] + mm[5];
+            okG = det > 1e-12 * (sc * sc * sc) * (1.0 / 27.0);
+            if (gl < 9) {
+                double sel = Mi[0];
+#pragma unroll
+                for (int i = 1; i < 9; ++i) sel = gl == i ? Mi[i] : sel;
+                L[Q_X + gl] = sel;
+            }
+        }
+        CVXW_SYNC();
+        // packed index of (i, j) in a symmetric 3x3 (00 01 02 11 12 22)
+        auto psym = [](int i, int j) { const int lo = i < j ? i : j, hi = i < j ? j : i; return lo * 3 - (lo == 2 ? 1 : 0) + (hi - lo); };
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int idx = gl + 16 * m;
+            if (idx < 27) {
+                const int bb = idx / 9, i = (idx % 9) / 3, j = idx % 3;
+                const double *m1 = L + Q_WF + 6 + 6 * bb;
+                double v = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) v += L[Q_X + i * 3 + k] * m1[psym(k, j)];
+                L[Q_B + i * 9 + 3 * bb + j] = v; // B[i][3 bb + j]
+            }
+        }
+        CVXW_SYNC();
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            double v = 0.0;
+            if (w.ok[m] && w.ej[m] < 9) {
+                const int qa = w.ei[m] / 3, qi = w.ei[m] % 3, qb = w.ej[m] / 3, qj = w.ej[m] % 3;
+                const double *m1 = L + Q_WF + 6 + 6 * qa, *m2 = L + Q_WF + 24 + 6 * psym(qa, qb);
+                v = m2[psym(qi, qj)];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) v -= m1[psym(qi, k)] * L[Q_B + k * 9 + 3 * qb + qj];
+            }
+            Qs[m] = v;
+        }
     }
     CVXW_SYNC();
 #pragma unroll
@@ -542,7 +554,7 @@ __global__ void __launch_bounds__(64, 2) solve_quad_kernel(WaveArgs a, cvx::Opts
             }
         }
         ++it;
-        const bool check = it >= next_check;
+        const bool check = MODE == 0 && it >= next_check;
         if (check) {
             // ---- certificate attempt (cvx::solve_sdp, non-twin branch): top eigenvector of Wp
             const double best = row_max(gl < 10 ? al : -1.0);
@@ -830,6 +842,7 @@ __global__ void __launch_bounds__(64, 2) solve_quad_kernel(WaveArgs a, cvx::Opts
     // ---------------------------------------------------------------- second phase (wave per problem)
     const unsigned long long pm = __ballot(parked);
     const unsigned pmask = (unsigned)((pm & 1ull) | ((pm >> 15) & 2ull) | ((pm >> 30) & 4ull) | ((pm >> 45) & 8ull));
+    if (MODE == 1) { if (gvalid && gl == 0) a.status[b] = cvx::ST_UNCERTIFIED; return; }
     if (pmask) { // wave-uniform
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // every park() acknowledged before the iterate is read back
         CVXW_SYNC();

@@ -64,13 +64,21 @@ struct Opts {
     int warm_start;    // 1: start each eigen-solve from the previous iteration's eigenvectors
     double rho_tail;   // penalty used from iteration tail_from on (the dual is rescaled at the switch)
     int tail_from;     // <= 0: never switch
+    int variant;       // VAR_FULL: the 22 equalities of cvxpnpl.py:387-451; VAR_RC: the 16 of benchmarks/toolkit/methods/rc.py:9-64
 };
+
+// Constraint sets.  VAR_RC is the reference's ablation "rc" (benchmarks/toolkit/methods/rc.py:16-35): the six row
+// orthonormality rows (kron(I3, E_ij), cvxpnpl.py:404-418) are left out -- in the closed forms below that means the
+// three triples 0..2 (Z01+Z34+Z67, Z02+Z35+Z68, Z12+Z45+Z78) are unconstrained and the diagonal block only has its
+// column sums fixed.
+enum Variant : int { VAR_FULL = 0, VAR_RC = 1 };
+CVX_HD constexpr bool tri_dropped(int t, int var) { return var == VAR_RC && t < 3; }
 
 CVX_HD Opts default_opts()
 {
     Opts o;
     o.eps = 1e-9; o.max_iters = 2500; o.rho = 0.1; o.alpha = 1.4;
-    o.first_check = 5; o.check_every = 2; o.res_tol = 1e-5; o.jacobi_sweeps = 12; o.jacobi_tol = 6e-2; o.warm_start = 1; o.rho_tail = 0.05; o.tail_from = 3;
+    o.first_check = 5; o.check_every = 2; o.res_tol = 1e-5; o.jacobi_sweeps = 12; o.jacobi_tol = 6e-2; o.warm_start = 1; o.rho_tail = 0.05; o.tail_from = 3; o.variant = VAR_FULL;
     return o;
 }
 
@@ -304,14 +312,16 @@ CVX_HD bool gram_finish(const Gram &g, double *B, double *Q9)
 
 // E <- E - P_range(E) shifted:  project the symmetric matrix E (55 packed) onto
 // { <A_i, Z> = b_i } (homog = false) or onto its direction space { <A_i, Z> = 0 }.
+template <int VAR = VAR_FULL>
 CVX_HD void proj_affine(double *E, bool homog)
 {
     CVX_UNROLL for (int t = 0; t < 15; ++t) {
+        if (tri_dropped(t, VAR)) continue;
         double m = (tri_s(t, 0) * E[sidx(tri_i(t, 0), tri_j(t, 0))] + tri_s(t, 1) * E[sidx(tri_i(t, 1), tri_j(t, 1))] +
                     tri_s(t, 2) * E[sidx(tri_i(t, 2), tri_j(t, 2))]) * (1.0 / 3.0);
         CVX_UNROLL for (int k = 0; k < 3; ++k) E[sidx(tri_i(t, k), tri_j(t, k))] -= tri_s(t, k) * m;
     }
-    // diagonal block D[i][j] = Z[3j+i, 3j+i]: rows and columns sum to Z99 = 1
+    // diagonal block D[i][j] = Z[3j+i, 3j+i]: rows (VAR_FULL only) and columns sum to Z99 = 1
     const double tgt = homog ? 0.0 : 1.0;
     double rs[3], cs[3], tot = 0;
     CVX_UNROLL for (int i = 0; i < 3; ++i) {
@@ -320,7 +330,8 @@ CVX_HD void proj_affine(double *E, bool homog)
         tot += rs[i];
     }
     CVX_UNROLL for (int i = 0; i < 3; ++i)
-        CVX_UNROLL for (int j = 0; j < 3; ++j) E[sidx(3 * j + i, 3 * j + i)] -= (rs[i] + cs[j]) * (1.0 / 3.0) - tot * (1.0 / 9.0);
+        CVX_UNROLL for (int j = 0; j < 3; ++j)
+            E[sidx(3 * j + i, 3 * j + i)] -= (VAR == VAR_RC) ? cs[j] * (1.0 / 3.0) : (rs[i] + cs[j]) * (1.0 / 3.0) - tot * (1.0 / 9.0);
     E[sidx(9, 9)] = tgt;
 }
 
@@ -641,12 +652,12 @@ CVX_HD double ldl_min_pivot(double *S)
 // a pivot-skipping generalised inverse there (any solution of the consistent system gives the same
 // projected correction).
 struct DualC { double c[100]; };
-constexpr DualC make_dual_c(bool symm)
+constexpr DualC make_dual_c(bool symm, int var = VAR_FULL)
 {
     const double z[10] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 1};
     double M[100] = {};
     for (int t = 0; t < 15; ++t) {
-        if (symm && odd_tri(t)) continue;
+        if ((symm && odd_tri(t)) || tri_dropped(t, var)) continue;
         double g[10] = {};
         for (int k = 0; k < 3; ++k) {
             g[tri_i(t, k)] += 0.5 * tri_s(t, k) * z[tri_j(t, k)];
@@ -657,7 +668,8 @@ constexpr DualC make_dual_c(bool symm)
     }
     for (int k = 0; k < 9; ++k)
         for (int l = 0; l < 9; ++l) {
-            const double p = ((k % 3) == (l % 3) ? 1.0 / 3.0 : 0.0) + ((k / 3) == (l / 3) ? 1.0 / 3.0 : 0.0) - 1.0 / 9.0;
+            const double p = var == VAR_RC ? ((k / 3) == (l / 3) ? 1.0 / 3.0 : 0.0)
+                                           : ((k % 3) == (l % 3) ? 1.0 / 3.0 : 0.0) + ((k / 3) == (l / 3) ? 1.0 / 3.0 : 0.0) - 1.0 / 9.0;
             M[k * 10 + l] += z[k] * p * z[l];
         }
     M[99] += 1.0;
@@ -701,8 +713,10 @@ constexpr DualC make_dual_c(bool symm)
     return out;
 }
 constexpr DualC kDualC = make_dual_c(false), kDualCs = make_dual_c(true);
+constexpr DualC kDualCrc = make_dual_c(false, VAR_RC), kDualCrcs = make_dual_c(true, VAR_RC);
 
 // lam = P(R) C P(R)^T rhs,  (P x)[3 j + i] = sum_k R[i][k] x[3 j + k],  R row-major
+template <int VAR = VAR_FULL>
 CVX_HD void dual_lambda(const double *R, const double *rhs, bool symm, double *lam)
 {
     double yp[10], lp[10];
@@ -712,8 +726,10 @@ CVX_HD void dual_lambda(const double *R, const double *rhs, bool symm, double *l
     CVX_UNROLL for (int a = 0; a < 10; ++a) {
         double u = 0, v = 0;
         CVX_UNROLL for (int b = 0; b < 10; ++b) {
-            if (kDualC.c[a * 10 + b] != 0.0) u += kDualC.c[a * 10 + b] * yp[b];
-            if (kDualCs.c[a * 10 + b] != 0.0) v += kDualCs.c[a * 10 + b] * yp[b];
+            const double cn = VAR == VAR_RC ? kDualCrc.c[a * 10 + b] : kDualC.c[a * 10 + b];
+            const double cs = VAR == VAR_RC ? kDualCrcs.c[a * 10 + b] : kDualCs.c[a * 10 + b];
+            if (cn != 0.0) u += cn * yp[b];
+            if (cs != 0.0) v += cs * yp[b];
         }
         lp[a] = symm ? v : u;
     }
@@ -724,6 +740,7 @@ CVX_HD void dual_lambda(const double *R, const double *rhs, bool symm, double *l
 
 // E <- P_range(E) = E - P_null(E), for E = sym(lam z^T) given implicitly; subtracts the
 // result from S:  S <- S - P_range(sym(lam z^T))
+template <int VAR = VAR_FULL>
 CVX_HD void sub_range_of_rank2(double *S, const double *lam, const double *z, bool symm = false)
 {
     double E[55];
@@ -731,7 +748,7 @@ CVX_HD void sub_range_of_rank2(double *S, const double *lam, const double *z, bo
         CVX_UNROLL for (int j = i; j < 10; ++j) E[sidx(i, j)] = (symm && odd_entry(i, j)) ? 0.0 : 0.5 * (lam[i] * z[j] + z[i] * lam[j]);
     double N[55];
     CVX_UNROLL for (int i = 0; i < 55; ++i) N[i] = E[i];
-    proj_affine(N, true); // N = P_null(E)
+    proj_affine<VAR>(N, true); // N = P_null(E)
     CVX_UNROLL for (int i = 0; i < 55; ++i) S[i] -= E[i] - N[i];
 }
 
@@ -834,7 +851,7 @@ CVX_HD void twin_candidates(const double *v1, const double *v2, double *zp, doub
 // SYMM: recognise planar scenes (Qs blind to the third column of R), whose relaxation is invariant
 // under D = diag(-I6, I4), and build the correction in the D-even subspace so that it annihilates
 // both twins z and D z at once.
-template <bool SYMM = true, class QV = const double *>
+template <bool SYMM = true, class QV = const double *, int VAR = VAR_FULL>
 CVX_HD void dual_certificate(QV Qs, const double *W, const double *Wp, double rho, double delta, double d0, Cert &c)
 {
     c.ok = false;
@@ -847,15 +864,15 @@ CVX_HD void dual_certificate(QV Qs, const double *W, const double *Wp, double rh
     double S[55], T[55];
     CVX_UNROLL for (int i = 0; i < 55; ++i) { S[i] = rho * (Wp[i] - W[i]); T[i] = S[i]; }
     CVX_UNROLL for (int i = 0; i < 9; ++i) CVX_UNROLL for (int j = i; j < 9; ++j) T[sidx(i, j)] -= Qs[qidx(i, j)];
-    proj_affine(T, true);
+    proj_affine<VAR>(T, true);
     CVX_UNROLL for (int i = 0; i < 55; ++i) S[i] -= T[i];
     if (symm) { CVX_UNROLL for (int i = 0; i < 10; ++i) CVX_UNROLL for (int j = i; j < 10; ++j) if (odd_entry(i, j)) S[sidx(i, j)] = 0.0; }
     // correction: min-norm dS in span A_i with (S - dS) z = 0
     // (closed form: the system matrix is a constant in the frame of R, see dual_lambda)
     double rhs[10], lam[10];
     sym_mul10(S, z, rhs);
-    dual_lambda(c.R, rhs, symm, lam);
-    sub_range_of_rank2(S, lam, z, symm);
+    dual_lambda<VAR>(c.R, rhs, symm, lam);
+    sub_range_of_rank2<VAR>(S, lam, z, symm);
     // checks
     double Sz[10];
     sym_mul10(S, z, Sz);
@@ -1067,7 +1084,7 @@ CVX_HD void fallback_pose(QV Qs, double tr, const double *v, const double *v2, i
 // schedule: the wave-per-problem kernel resumes it).
 // TWIN = false compiles the two-fold-ambiguity branch out (the lane phase of the hybrid schedule hands
 // off before iteration 6, where that branch starts, and the extra live state costs it registers).
-template <bool TWIN = true, class ST = RegStore>
+template <bool TWIN = true, class ST = RegStore, int VAR = VAR_FULL>
 CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution &sol, double *Zout, int handoff_at = 0,
                       double *handoff = nullptr, ST st = ST())
 {
@@ -1201,7 +1218,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                     polish_rotation(Qs, c.R, c.pobj);
                     if (TWIN) reused = 0;
                 }
-                dual_certificate<TWIN>(Qs, W, Wp, rho, delta, d0, c);
+                dual_certificate<TWIN, decltype(Qs), VAR>(Qs, W, Wp, rho, delta, d0, c);
                 have_prev = d0 > 0 && (c.pobj == c.pobj);
                 CVX_UNROLL for (int i = 0; i < 9; ++i) Rprev[i] = c.R[i];
                 fprev = c.pobj;
@@ -1227,7 +1244,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                 // the dual test (it is then a global optimum, and so is z- with the same cost).
                 if (ambiguous) {
                     c.pobj = fp;
-                    dual_certificate<TWIN>(Qs, W, Wp, rho, delta, dp, c);
+                    dual_certificate<TWIN, decltype(Qs), VAR>(Qs, W, Wp, rho, delta, dp, c);
                     ambiguous = c.ok && (tr * (fabs(c.zSz) + 4.0 * delta) <= (o.eps > 8e-13 * tr ? o.eps : 8e-13 * tr));
                     twin_tested = true;
                 }
@@ -1235,7 +1252,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                     const bool take_m = dm > 0 && (fm == fm) && (!(dp > 0) || !(fp == fp) || fm < fp);
                     if (take_m) { CVX_UNROLL for (int i = 0; i < 9; ++i) c.R[i] = Rm[i]; }
                     c.pobj = take_m ? fm : fp;
-                    dual_certificate<TWIN>(Qs, W, Wp, rho, delta, take_m ? dm : dp, c);
+                    dual_certificate<TWIN, decltype(Qs), VAR>(Qs, W, Wp, rho, delta, take_m ? dm : dp, c);
                 } else if (!ambiguous) {
                     c.ok = false; // equal-cost twins whose certificate is not there yet: keep iterating
                 }
@@ -1291,7 +1308,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
             double X[55];
             CVX_UNROLL for (int i = 0; i < 55; ++i) X[i] = 2.0 * Wp[i] - W[i];
             CVX_UNROLL for (int i = 0; i < 9; ++i) CVX_UNROLL for (int j = i; j < 9; ++j) X[sidx(i, j)] -= irho * Qs[qidx(i, j)];
-            proj_affine(X, false);
+            proj_affine<VAR>(X, false);
             double r2 = 0;
             CVX_UNROLL for (int i = 0; i < 10; ++i)
                 CVX_UNROLL for (int j = i; j < 10; ++j) {

@@ -211,6 +211,9 @@ struct Roles {
 
 // projection of the symmetric matrix held one entry per lane onto { <A_i, Z> = b_i }
 // (tgt = 1) or its direction space (tgt = 0); same closed form as cvx::proj_affine.
+// VAR_RC (the reference's "rc" ablation): the row-orthonormality rows are absent -- entries (i, j) inside one
+// diagonal 3x3 block (i / 3 == j / 3, i != j: triples 0..2) are free, diagonal entries only see their column sum.
+template <int VAR = cvx::VAR_FULL>
 __device__ __forceinline__ double coop_proj(double *L, const Roles &r, double X, double tgt)
 {
     L[L_X + r.el] = X;
@@ -223,10 +226,12 @@ __device__ __forceinline__ double coop_proj(double *L, const Roles &r, double X,
     const double tot = r0 + r1 + r2;
     const int ri = r.ei % 3, ci = r.ei / 3; // diagonal entry (ei, ei), ei < 9, is D[ri][ci]
     const double rr = ri == 0 ? r0 : (ri == 1 ? r1 : r2), cc = ci == 0 ? c0 : (ci == 1 ? c1 : c2);
-    const double xdiag = (r.ei == 9) ? tgt : X - (rr + cc) * (1.0 / 3.0) + tot * (1.0 / 9.0);
+    const double corr = VAR == cvx::VAR_RC ? cc * (1.0 / 3.0) : (rr + cc) * (1.0 / 3.0) - tot * (1.0 / 9.0);
+    const double xdiag = (r.ei == 9) ? tgt : X - corr;
     const double m = (r.s0 * X + r.s1 * L[L_X + r.p1] + r.s2 * L[L_X + r.p2]) * (1.0 / 3.0);
     CVXW_SYNC();
-    return r.is_diag ? xdiag : X - r.s0 * m;
+    const bool free_entry = VAR == cvx::VAR_RC && r.ei != r.ej && r.ej < 9 && (r.ei / 3 == r.ej / 3);
+    return r.is_diag ? xdiag : (free_entry ? X : X - r.s0 * m);
 }
 
 // LDS map of the certificate (regions that are dead while it runs)
@@ -394,6 +399,7 @@ __device__ __forceinline__ void coop_polish(double *L, const Roles &r, double Qs
 }
 
 // Dual half (cvx::dual_certificate, all lanes) for the rotation R: returns the verdict c.ok.
+template <int VAR = cvx::VAR_FULL>
 __device__ __forceinline__ bool coop_dual(double *L, const Roles &r, double Qs, double W, double Wp, const double *R, double d0,
                                           double pobj, double rho, double delta, double &zSz CVXW_PH_PARAM)
 {
@@ -415,7 +421,7 @@ __device__ __forceinline__ bool coop_dual(double *L, const Roles &r, double Qs, 
     CVXW_SYNC();
     // ---- dual hint S_h = rho (Wp - W); S1 = S_h - P_null(S_h - Qs)
     const double Sh = rho * (Wp - W);
-    double S = Sh - coop_proj(L, r, Sh - (r.ej < 9 ? Qs : 0.0), 0.0);
+    double S = Sh - coop_proj<VAR>(L, r, Sh - (r.ej < 9 ? Qs : 0.0), 0.0);
     if (odd) S = 0.0;
     if (lane < 55) { L[C_SF + r.ei * 10 + r.ej] = S; L[C_SF + r.ej * 10 + r.ei] = S; }
     CVXW_SYNC();
@@ -435,7 +441,7 @@ __device__ __forceinline__ bool coop_dual(double *L, const Roles &r, double Qs, 
         double rhs[10], lam[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) rhs[i] = L[C_ROW + i];
-        cvx::dual_lambda(R, rhs, symm, lam);
+        cvx::dual_lambda<VAR>(R, rhs, symm, lam);
         CVXW_SYNC();
         if (lane == 0) {
 #pragma unroll
@@ -447,7 +453,7 @@ __device__ __forceinline__ bool coop_dual(double *L, const Roles &r, double Qs, 
     // ---- S2 = S1 - P_range(sym(lam z^T))
     {
         const double E = odd ? 0.0 : 0.5 * (L[C_LAM + r.ei] * L[C_XV + r.ej] + L[C_XV + r.ei] * L[C_LAM + r.ej]);
-        const double Nn = coop_proj(L, r, E, 0.0);
+        const double Nn = coop_proj<VAR>(L, r, E, 0.0);
         S -= E - Nn;
     }
     if (lane < 55) { L[C_SF + r.ei * 10 + r.ej] = S; L[C_SF + r.ej * 10 + r.ei] = S; }
@@ -475,11 +481,13 @@ struct WaveArgs {
     const double *p2, *p3, *l2, *l3, *K;
     double *R, *t, *cost, *Z;
     int32_t *status, *iters, *work;
+    const double *Q45, *B27; // cost entry (cvxpnpl_solve_cost_batch): [batch][45] packed A^T A and [batch][27] B instead of correspondences
 };
 
 // Solve problem b with the wavefront that calls this.  resume (optional): 56 doubles written by
 // the lane-layout kernel for a problem it handed off -- W (55, vech order) and the iteration
 // count -- the solve then continues from that iterate instead of starting at e9 e9^T.
+template <int VAR = cvx::VAR_FULL>
 __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opts &o, const int64_t b, double *L, const double *resume)
 {
     const int lane = threadIdx.x & 63;
@@ -503,125 +511,131 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
     const int ji = jl % 10, jk = jl / 10;
 
     // ---------------------------------------------------------------- assembly
-    cvx::ProblemView pv = cvx::make_view(b, a.n_p, a.p2, a.p3, a.n_l, a.l2, a.l3, a.K, a.K_per_problem);
-    const int nrec = pv.n_p + 2 * pv.n_l;
-    constexpr int CHUNK = 32; // records (T[6], P[3]) staged per pass in L_EX.. (32 * 10 doubles)
-    // raw inputs of record r: a point (u, v, X, Y, Z) or one endpoint of a line (2D segment + its 3D point).
-    // The first chunk is requested BEFORE K is inverted, so that all global loads of the problem are in
-    // flight together (one memory round trip instead of three).
-    // (separate registers for the point and the line case: loads into the same registers from both sides of
-    // the branch would force a wait between them)
-    auto load_point = [&](int r, double *q) {
-        q[0] = pv.p2[2 * r]; q[1] = pv.p2[2 * r + 1];
-        q[2] = pv.p3[3 * r]; q[3] = pv.p3[3 * r + 1]; q[4] = pv.p3[3 * r + 2];
-    };
-    auto load_line = [&](int r, double *q) {
-        const int li = (r - pv.n_p) >> 1, en = (r - pv.n_p) & 1;
-        const double *l2 = pv.l2 + 4 * li, *l3 = pv.l3 + 6 * li + 3 * en;
-        q[0] = l2[0]; q[1] = l2[1]; q[2] = l2[2]; q[3] = l2[3];
-        q[4] = l3[0]; q[5] = l3[1]; q[6] = l3[2];
-    };
-    double rawp[5] = {0, 0, 0, 0, 0}, rawl[7] = {0, 0, 0, 0, 0, 0, 0};
-    {
-        const int cnt0 = nrec < CHUNK ? nrec : CHUNK;
-        if (lane < cnt0 && lane < pv.n_p) load_point(lane, rawp);
-        if (lane < cnt0 && lane >= pv.n_p) load_line(lane, rawl);
-    }
-    double Ki[9];
-    bool okK;
-    {
-        double Kc[9], det;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) Kc[i] = pv.K[i];
-        cvx::inv3(Kc, Ki, det);
-        okK = (det == det) && det != 0.0;
-    }
-    // accumulator role of this lane: sum rec[6 + qa] rec[6 + qb] rec[te] with rec = (T[6], 1, P[3]):
-    // M0 (6): qa = qb = 0 | M1 (3 x 6): qa = 1 + a | M2 (6 x 6): qa = 1 + a, qb = 1 + b
-    int acc_qa = 6, acc_qb = 6, acc_te = 0;
-    {
-        const int al = lane < 60 ? lane : 0;
-        acc_te = al;
-        if (al >= 6 && al < 24) { acc_qa = 7 + (al - 6) / 6; acc_te = (al - 6) % 6; }
-        if (al >= 24) {
-            const int ab = (al - 24) / 6;
-            acc_te = (al - 24) % 6;
-            acc_qa = 7 + (ab < 3 ? 0 : (ab < 5 ? 1 : 2));
-            acc_qb = 7 + (ab < 3 ? ab : (ab < 5 ? ab - 2 : 2));
-        }
-    }
-    double acc = 0.0;
-    for (int base = 0; base < nrec; base += CHUNK) {
-        const int cnt = nrec - base < CHUNK ? nrec - base : CHUNK;
-        if (lane < cnt) {
-            const int r = base + lane;
-            double T[6], P[3];
-            if (r < pv.n_p) {
-                if (base > 0) load_point(r, rawp);
-                double p[3];
-                cvx::bearing(Ki, rawp[0], rawp[1], p);
-                double n2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
-                T[0] = n2 - p[0] * p[0]; T[1] = -p[0] * p[1]; T[2] = -p[0] * p[2];
-                T[3] = n2 - p[1] * p[1]; T[4] = -p[1] * p[2]; T[5] = n2 - p[2] * p[2];
-                P[0] = rawp[2]; P[1] = rawp[3]; P[2] = rawp[4];
-            } else {
-                if (base > 0) load_line(r, rawl);
-                double u[3], v[3];
-                cvx::bearing(Ki, rawl[0], rawl[1], u);
-                cvx::bearing(Ki, rawl[2], rawl[3], v);
-                double n[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
-                double inv = cvx::rsqrt_(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-                n[0] *= inv; n[1] *= inv; n[2] *= inv;
-                T[0] = n[0] * n[0]; T[1] = n[0] * n[1]; T[2] = n[0] * n[2]; T[3] = n[1] * n[1]; T[4] = n[1] * n[2]; T[5] = n[2] * n[2];
-                P[0] = rawl[4]; P[1] = rawl[5]; P[2] = rawl[6];
-            }
-            double *rec = L + L_EX + lane * 10;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) rec[i] = T[i];
-            rec[6] = 1.0; rec[7] = P[0]; rec[8] = P[1]; rec[9] = P[2];
-        }
-        CVXW_SYNC();
-        for (int c = 0; c < cnt; ++c) {
-            const double *rec = L + L_EX + c * 10;
-            acc += rec[acc_qa] * rec[acc_qb] * rec[acc_te];
-        }
-        CVXW_SYNC();
-    }
-    L[L_P + lane] = acc; // ACC[0..59]
-    CVXW_SYNC();
-    // B = M0^-1 [M1_0 M1_1 M1_2], Q = M2 - M1^T B; every lane inverts M0 redundantly
-    bool okG;
-    {
-        const double *m = L + L_P;
-        double M0[9] = {m[0], m[1], m[2], m[1], m[3], m[4], m[2], m[4], m[5]}, Mi[9], det;
-        cvx::inv3(M0, Mi, det);
-        double sc = m[0] + m[3] + m[5];
-        okG = det > 1e-12 * (sc * sc * sc) * (1.0 / 27.0);
-        double sel = Mi[0]; // element `lane` of the inverse, without dynamic register indexing
-#pragma unroll
-        for (int i = 1; i < 9; ++i) sel = lane == i ? Mi[i] : sel;
-        if (lane < 9) L[L_X + lane] = sel;
-    }
-    CVXW_SYNC();
-    // packed index of (i, j) in a symmetric 3x3 (00 01 02 11 12 22)
-    auto psym = [](int i, int j) { const int lo = i < j ? i : j, hi = i < j ? j : i; return lo * 3 - (lo == 2 ? 1 : 0) + (hi - lo); };
-    if (lane < 27) {
-        const int bb = lane / 9, i = (lane % 9) / 3, j = lane % 3;
-        const double *m1 = L + L_P + 6 + 6 * bb;
-        double v = 0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) v += L[L_X + i * 3 + k] * m1[psym(k, j)];
-        L[L_B + i * 9 + 3 * bb + j] = v; // B[i][3 bb + j]
-    }
-    CVXW_SYNC();
+    bool okK = true, okG = true;
     double Qe = 0.0; // Q9 entry of this entry-lane (0 outside the 9x9 block)
-    if (ej < 9) {
-        const int qa = ei / 3, qi = ei % 3, qb = ej / 3, qj = ej % 3;
-        const double *m1 = L + L_P + 6 + 6 * qa, *m2 = L + L_P + 24 + 6 * psym(qa, qb);
-        double v = m2[psym(qi, qj)];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) v -= m1[psym(qi, k)] * L[L_B + k * 9 + 3 * qb + qj];
-        Qe = v;
+    if (a.Q45) {
+        // cost entry (the seam of cvxpnpl.py:454-460): A^T A (packed 9x9, cvx::qidx order) and B come from the caller
+        if (ej < 9) Qe = a.Q45[b * 45 + cvx::qidx(ei, ej)];
+        if (lane < 27) L[L_B + lane] = a.B27[b * 27 + lane];
+        okG = !__any(lane < 27 && !(L[L_B + lane] == L[L_B + lane]));
+    } else {
+        cvx::ProblemView pv = cvx::make_view(b, a.n_p, a.p2, a.p3, a.n_l, a.l2, a.l3, a.K, a.K_per_problem);
+        const int nrec = pv.n_p + 2 * pv.n_l;
+        constexpr int CHUNK = 32; // records (T[6], P[3]) staged per pass in L_EX.. (32 * 10 doubles)
+        // raw inputs of record r: a point (u, v, X, Y, Z) or one endpoint of a line (2D segment + its 3D point).
+        // The first chunk is requested BEFORE K is inverted, so that all global loads of the problem are in
+        // flight together (one memory round trip instead of three).
+        // (separate registers for the point and the line case: loads into the same registers from both sides of
+        // the branch would force a wait between them)
+        auto load_point = [&](int r, double *q) {
+            q[0] = pv.p2[2 * r]; q[1] = pv.p2[2 * r + 1];
+            q[2] = pv.p3[3 * r]; q[3] = pv.p3[3 * r + 1]; q[4] = pv.p3[3 * r + 2];
+        };
+        auto load_line = [&](int r, double *q) {
+            const int li = (r - pv.n_p) >> 1, en = (r - pv.n_p) & 1;
+            const double *l2 = pv.l2 + 4 * li, *l3 = pv.l3 + 6 * li + 3 * en;
+            q[0] = l2[0]; q[1] = l2[1]; q[2] = l2[2]; q[3] = l2[3];
+            q[4] = l3[0]; q[5] = l3[1]; q[6] = l3[2];
+        };
+        double rawp[5] = {0, 0, 0, 0, 0}, rawl[7] = {0, 0, 0, 0, 0, 0, 0};
+        {
+            const int cnt0 = nrec < CHUNK ? nrec : CHUNK;
+            if (lane < cnt0 && lane < pv.n_p) load_point(lane, rawp);
+            if (lane < cnt0 && lane >= pv.n_p) load_line(lane, rawl);
+        }
+        double Ki[9];
+        {
+            double Kc[9], det;
+    #pragma unroll
+            for (int i = 0; i < 9; ++i) Kc[i] = pv.K[i];
+            cvx::inv3(Kc, Ki, det);
+            okK = (det == det) && det != 0.0;
+        }
+        // accumulator role of this lane: sum rec[6 + qa] rec[6 + qb] rec[te] with rec = (T[6], 1, P[3]):
+        // M0 (6): qa = qb = 0 | M1 (3 x 6): qa = 1 + a | M2 (6 x 6): qa = 1 + a, qb = 1 + b
+        int acc_qa = 6, acc_qb = 6, acc_te = 0;
+        {
+            const int al = lane < 60 ? lane : 0;
+            acc_te = al;
+            if (al >= 6 && al < 24) { acc_qa = 7 + (al - 6) / 6; acc_te = (al - 6) % 6; }
+            if (al >= 24) {
+                const int ab = (al - 24) / 6;
+                acc_te = (al - 24) % 6;
+                acc_qa = 7 + (ab < 3 ? 0 : (ab < 5 ? 1 : 2));
+                acc_qb = 7 + (ab < 3 ? ab : (ab < 5 ? ab - 2 : 2));
+            }
+        }
+        double acc = 0.0;
+        for (int base = 0; base < nrec; base += CHUNK) {
+            const int cnt = nrec - base < CHUNK ? nrec - base : CHUNK;
+            if (lane < cnt) {
+                const int r = base + lane;
+                double T[6], P[3];
+                if (r < pv.n_p) {
+                    if (base > 0) load_point(r, rawp);
+                    double p[3];
+                    cvx::bearing(Ki, rawp[0], rawp[1], p);
+                    double n2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+                    T[0] = n2 - p[0] * p[0]; T[1] = -p[0] * p[1]; T[2] = -p[0] * p[2];
+                    T[3] = n2 - p[1] * p[1]; T[4] = -p[1] * p[2]; T[5] = n2 - p[2] * p[2];
+                    P[0] = rawp[2]; P[1] = rawp[3]; P[2] = rawp[4];
+                } else {
+                    if (base > 0) load_line(r, rawl);
+                    double u[3], v[3];
+                    cvx::bearing(Ki, rawl[0], rawl[1], u);
+                    cvx::bearing(Ki, rawl[2], rawl[3], v);
+                    double n[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+                    double inv = cvx::rsqrt_(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                    n[0] *= inv; n[1] *= inv; n[2] *= inv;
+                    T[0] = n[0] * n[0]; T[1] = n[0] * n[1]; T[2] = n[0] * n[2]; T[3] = n[1] * n[1]; T[4] = n[1] * n[2]; T[5] = n[2] * n[2];
+                    P[0] = rawl[4]; P[1] = rawl[5]; P[2] = rawl[6];
+                }
+                double *rec = L + L_EX + lane * 10;
+    #pragma unroll
+                for (int i = 0; i < 6; ++i) rec[i] = T[i];
+                rec[6] = 1.0; rec[7] = P[0]; rec[8] = P[1]; rec[9] = P[2];
+            }
+            CVXW_SYNC();
+            for (int c = 0; c < cnt; ++c) {
+                const double *rec = L + L_EX + c * 10;
+                acc += rec[acc_qa] * rec[acc_qb] * rec[acc_te];
+            }
+            CVXW_SYNC();
+        }
+        L[L_P + lane] = acc; // ACC[0..59]
+        CVXW_SYNC();
+        // B = M0^-1 [M1_0 M1_1 M1_2], Q = M2 - M1^T B; every lane inverts M0 redundantly
+        {
+            const double *m = L + L_P;
+            double M0[9] = {m[0], m[1], m[2], m[1], m[3], m[4], m[2], m[4], m[5]}, Mi[9], det;
+            cvx::inv3(M0, Mi, det);
+            double sc = m[0] + m[3] + m[5];
+            okG = det > 1e-12 * (sc * sc * sc) * (1.0 / 27.0);
+            double sel = Mi[0]; // element `lane` of the inverse, without dynamic register indexing
+    #pragma unroll
+            for (int i = 1; i < 9; ++i) sel = lane == i ? Mi[i] : sel;
+            if (lane < 9) L[L_X + lane] = sel;
+        }
+        CVXW_SYNC();
+        // packed index of (i, j) in a symmetric 3x3 (00 01 02 11 12 22)
+        auto psym = [](int i, int j) { const int lo = i < j ? i : j, hi = i < j ? j : i; return lo * 3 - (lo == 2 ? 1 : 0) + (hi - lo); };
+        if (lane < 27) {
+            const int bb = lane / 9, i = (lane % 9) / 3, j = lane % 3;
+            const double *m1 = L + L_P + 6 + 6 * bb;
+            double v = 0;
+    #pragma unroll
+            for (int k = 0; k < 3; ++k) v += L[L_X + i * 3 + k] * m1[psym(k, j)];
+            L[L_B + i * 9 + 3 * bb + j] = v; // B[i][3 bb + j]
+        }
+        CVXW_SYNC();
+        if (ej < 9) {
+            const int qa = ei / 3, qi = ei % 3, qb = ej / 3, qj = ej % 3;
+            const double *m1 = L + L_P + 6 + 6 * qa, *m2 = L + L_P + 24 + 6 * psym(qa, qb);
+            double v = m2[psym(qi, qj)];
+    #pragma unroll
+            for (int k = 0; k < 3; ++k) v -= m1[psym(qi, k)] * L[L_B + k * 9 + 3 * qb + qj];
+            Qe = v;
+        }
     }
     L[L_X + el] = Qe;
     CVXW_SYNC();
@@ -880,7 +894,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
                     coop_polish(L, roles, Qs, Rc, pobj CVXW_PH_ARG);
                 }
                 CVXW_PH(PH_POLISH);
-                const bool cok = coop_dual(L, roles, Qs, W, Wp, Rc, d0, pobj, rho, delta, zSz CVXW_PH_ARG);
+                const bool cok = coop_dual<VAR>(L, roles, Qs, W, Wp, Rc, d0, pobj, rho, delta, zSz CVXW_PH_ARG);
                 CVXW_PH(PH_DUAL);
                 gap_ok = cok && (tr * (fabs(zSz) + 4.0 * delta) <= gap_tol);
                 have_prev = d0 > 0 && (pobj == pobj);
@@ -956,7 +970,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
                     for (int i = 0; i < 9; ++i) Rc[i] = L[L_M + 30 + i];
                 }
                 pobj = take_m ? fm : fp;
-                const bool cok = coop_dual(L, roles, Qs, W, Wp, Rc, take_m ? dm : dp, pobj, rho, delta, zSz CVXW_PH_ARG);
+                const bool cok = coop_dual<VAR>(L, roles, Qs, W, Wp, Rc, take_m ? dm : dp, pobj, rho, delta, zSz CVXW_PH_ARG);
                 const bool ok = cok && (tr * (fabs(zSz) + 4.0 * delta) <= gap_tol);
                 ambiguous = twins && ok;
                 gap_ok = !twins && ok;
@@ -1054,7 +1068,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
         }
         if (!done) {
             // X = Pi_aff(2 Wp - W - Qs / rho);  W <- W + alpha (X - Wp)
-            const double Xn = coop_proj(L, roles, 2.0 * Wp - W - irho * Qs, 1.0);
+            const double Xn = coop_proj<VAR>(L, roles, 2.0 * Wp - W - irho * Qs, 1.0);
             const double dd = Xn - Wp;
             W += o.alpha * dd;
             fp_res = cvx::sqrt_fast(wave_sum(wgt * dd * dd));
@@ -1126,13 +1140,14 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
     CVXW_PH_FLUSH();
 }
 
+template <int VAR>
 __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx::Opts o)
 {
     __shared__ __attribute__((aligned(16))) double lds_all[WPB][LDSW];
     const int wib = threadIdx.x >> 6;
     const int64_t b = (int64_t)blockIdx.x * WPB + wib;
     if (b >= a.batch) return; // wave-uniform
-    solve_one_wave(a, o, b, lds_all[wib], nullptr);
+    solve_one_wave<VAR>(a, o, b, lds_all[wib], nullptr);
 }
 
 // Second phase of the hybrid schedules: the problems the first kernel parked, one wavefront each.  The queue is

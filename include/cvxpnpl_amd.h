@@ -48,6 +48,13 @@ enum {
                                 iterations; the wavefront then finishes its unfinished ones itself, one at a time */
 };
 
+/* constraint sets of the relaxation */
+enum {
+    CVXPNPL_VARIANT_FULL = 0, /* the 22 equalities of cvxpnpl.py:387-451 (pnp / pnl / pnpl) */
+    CVXPNPL_VARIANT_RC = 1    /* the 16 equalities of benchmarks/toolkit/methods/rc.py:9-64 (the reference's ablation "rc":
+                                 the six row-orthonormality rows are left out); wave-per-problem layout */
+};
+
 typedef struct {
     double eps;        /* absolute duality-gap tolerance; reference `eps` (cvxpnpl.py:527), default 1e-9 */
     int32_t max_iters; /* iteration cap; reference `max_iters` (cvxpnpl.py:528), default 2500 */
@@ -65,6 +72,7 @@ typedef struct {
                            wavefront each (hybrid schedule).  <= 0: default (lane: 5;
                            quad: 10).  The lane phase is capped at 5 iterations. */
     int32_t layout;    /* CVXPNPL_LAYOUT_* */
+    int32_t variant;   /* CVXPNPL_VARIANT_*, default FULL */
 } cvxpnpl_opts_t;
 
 void cvxpnpl_default_opts(cvxpnpl_opts_t *opts);
@@ -96,6 +104,19 @@ int cvxpnpl_solve_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, cons
                         const double *d_line_2d, const double *d_line_3d, const double *d_K, int32_t K_per_problem,
                         const cvxpnpl_opts_t *opts, double *d_R, double *d_t, int32_t *d_status, int32_t *d_iters,
                         double *d_cost, double *d_Z, int32_t *d_work, void *stream);
+
+/*
+ * The same solve at the seam of the reference's private _solve_relaxation(A, B, eps, max_iters, verbose)
+ * (cvxpnpl.py:454-460; callers: benchmarks/toolkit/methods/pnp.py:4 and rc.py:3): the caller brings the cost and the
+ * translation map instead of correspondences.
+ *   d_Q45 [batch][45]  A^T A (cvxpnpl.py:475), upper triangle row by row: entry (i <= j) at i*9 - i*(i-1)/2 + (j-i)
+ *                      -- what cvxpnpl_assemble_batch / cvxpnpl_assemble_large_batch write
+ *   d_B27 [batch][27]  B (3x9, row-major), t = -B r (cvxpnpl.py:513)
+ * Outputs, options, return codes: as cvxpnpl_solve_batch.  opts->variant selects the constraint set
+ * (CVXPNPL_VARIANT_RC: _solve_relaxation_rc, rc.py:67-131).
+ */
+int cvxpnpl_solve_cost_batch(int64_t batch, const double *d_Q45, const double *d_B27, const cvxpnpl_opts_t *opts, double *d_R,
+                             double *d_t, int32_t *d_status, int32_t *d_iters, double *d_cost, double *d_Z, int32_t *d_work, void *stream);
 
 /*
  * Host side of the cold path: all poses of a rank > 1 solution (cvxpnpl.py:507 ->

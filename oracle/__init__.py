@@ -116,6 +116,13 @@ def sdp_constraints():
     return Ad, b
 
 
+def sdp_constraints_rc():
+    """dense _A_rc (71 x 55), _b_rc of benchmarks/toolkit/methods/rc.py:9-64"""
+    Ad, b = np.zeros((71, 55)), np.zeros(71)
+    lib().orc_sdp_constraints_rc(_p(Ad), _p(b))
+    return Ad, b
+
+
 def eigh(A):
     A = _c(A).copy()
     n = len(A)
@@ -172,6 +179,27 @@ def solve_relaxation(A, B, eps=1e-9, max_iters=2500):
     info = OrcInfo()
     n = lib().orc_solve_relaxation(len(A), _p(A), _p(B), eps, max_iters, _p(R), _p(t), C.byref(info))
     return [(R[i].copy(), t[i].copy()) for i in range(n)], info
+
+
+def solve_relaxation_rc(A, B, eps=1e-9, max_iters=2500):
+    """_solve_relaxation_rc (benchmarks/toolkit/methods/rc.py:67-131) restated"""
+    A, B = _c(A), _c(B)
+    R, t = np.zeros((4, 3, 3)), np.zeros((4, 3))
+    info = OrcInfo()
+    lib().orc_solve_relaxation_rc.argtypes = [C.c_int, _dp, _dp, C.c_double, C.c_int, _dp, _dp, C.POINTER(OrcInfo)]
+    n = lib().orc_solve_relaxation_rc(len(A), _p(A), _p(B), eps, max_iters, _p(R), _p(t), C.byref(info))
+    return [(R[i].copy(), t[i].copy()) for i in range(n)], info
+
+
+def scs_solve_rc(c, eps=1e-9, max_iters=2500, cscale=1.0):
+    """the restated SCS on the rc constraint set (16 zero-cone rows)"""
+    c = _c(c)
+    x, y, res = np.zeros(55), np.zeros(71), np.zeros(3)
+    dobj, pobj, iters = C.c_double(), C.c_double(), C.c_int()
+    lib().orc_scs_solve_var.argtypes = [C.c_int, _dp, C.c_double, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _ip, _dp]
+    st = lib().orc_scs_solve_var(1, _p(c), eps, max_iters, cscale, _p(x), _p(y), C.byref(dobj), C.byref(pobj), C.byref(iters), _p(res))
+    return {"x": x, "y": y, "info": {"dobj": dobj.value, "pobj": pobj.value, "iter": iters.value,
+                                      "status": "solved" if st == 0 else "max_iters", "res": res}}
 
 
 def pnpl(pts_2d, line_2d, pts_3d, line_3d, K, eps=1e-9, max_iters=2500):

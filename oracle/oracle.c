@@ -372,12 +372,34 @@ static void chol_solve(int n, const double *L, double *x)
 typedef struct {
     double A[NM * NV], b[NM];
     double L[NV * NV];   /* chol(I + A^T A) */
+    int nm, nz;          /* rows in use, rows of the zero cone (77 / 22, or 71 / 16 for the rc variant) */
     int ready;
 } scs_static_t;
-static scs_static_t g_scs;
+static scs_static_t g_scs_var[2];
+#define g_scs g_scs_var[0]
 
-static void scs_static_init(void)
+/* benchmarks/toolkit/methods/rc.py:9-64: the same construction as cvxpnpl.py:387-451 without the six rows
+ * kron(I3, E_ij^T) (row orthonormality): Z99 = 1, the six column rows kron(E_ij, I3), the nine determinant rows,
+ * then the cone block -- 71 x 55 (row-major), b (71). */
+void orc_sdp_constraints_rc(double *Ad, double *b)
 {
+    static double full[NM * NV], fb[NM];
+    orc_sdp_constraints(full, fb);
+    memset(Ad, 0, sizeof(double) * 71 * NV);
+    memset(b, 0, sizeof(double) * 71);
+    memcpy(Ad, full, sizeof(double) * NV);                                        /* rc.py:24   Ad[0, -1] = 1        */
+    for (int i = 0; i < 6; ++i) memcpy(Ad + (size_t)(1 + i) * NV, full + (size_t)(7 + i) * NV, sizeof(double) * NV);  /* rc.py:27-36 */
+    for (int i = 0; i < 9; ++i) memcpy(Ad + (size_t)(7 + i) * NV, full + (size_t)(13 + i) * NV, sizeof(double) * NV); /* rc.py:39-53 */
+    for (int k = 0; k < NV; ++k) Ad[(size_t)(16 + k) * NV + k] = full[(size_t)(22 + k) * NV + k];                       /* rc.py:56-57 */
+    b[0] = 1.0;                                                                                                       /* rc.py:63    */
+}
+
+static void scs_static_init_var(int variant);
+static void scs_static_init(void) { scs_static_init_var(0); }
+static void scs_static_init_var(int variant)
+{
+#undef g_scs
+#define g_scs g_scs_var[variant]
     if (g_scs.ready) return;
 #ifdef _OPENMP
 #pragma omp critical(orc_scs_init)
@@ -385,36 +407,42 @@ static void scs_static_init(void)
     {
         if (!g_scs.ready) {
             static scs_static_t tmp;
-            orc_sdp_constraints(tmp.A, tmp.b);
+            memset(&tmp, 0, sizeof(tmp));
+            if (variant) { orc_sdp_constraints_rc(tmp.A, tmp.b); tmp.nm = 71; tmp.nz = 16; }
+            else { orc_sdp_constraints(tmp.A, tmp.b); tmp.nm = NM; tmp.nz = 22; }
             for (int i = 0; i < NV; ++i)
                 for (int j = 0; j < NV; ++j) {
                     double s = (i == j);
-                    for (int r = 0; r < NM; ++r) s += tmp.A[r * NV + i] * tmp.A[r * NV + j];
+                    for (int r = 0; r < tmp.nm; ++r) s += tmp.A[r * NV + i] * tmp.A[r * NV + j];
                     tmp.L[i * NV + j] = s;
                 }
             chol(NV, tmp.L);
             memcpy(g_scs.A, tmp.A, sizeof(tmp.A));
             memcpy(g_scs.b, tmp.b, sizeof(tmp.b));
             memcpy(g_scs.L, tmp.L, sizeof(tmp.L));
+            g_scs.nm = tmp.nm; g_scs.nz = tmp.nz;
 #ifdef _OPENMP
 #pragma omp flush
 #endif
             g_scs.ready = 1;
         }
     }
+#undef g_scs
+#define g_scs g_scs_var[0]
 }
 
 /* [x;y] = M^-1 [wx; wy],  M = [[I, A^T], [-A, I]]:  x = (I + A^T A)^-1 (wx - A^T wy), y = wy + A x */
-static void solve_M(const double *wx, const double *wy, double *x, double *y)
+static void solve_M(const scs_static_t *G, const double *wx, const double *wy, double *x, double *y)
 {
-    const double *A = g_scs.A;
+    const double *A = G->A;
+    const int NMv = G->nm;
     for (int j = 0; j < NV; ++j) {
         double s = wx[j];
-        for (int r = 0; r < NM; ++r) s -= A[r * NV + j] * wy[r];
+        for (int r = 0; r < NMv; ++r) s -= A[r * NV + j] * wy[r];
         x[j] = s;
     }
-    chol_solve(NV, g_scs.L, x);
-    for (int r = 0; r < NM; ++r) {
+    chol_solve(NV, G->L, x);
+    for (int r = 0; r < NMv; ++r) {
         double s = wy[r];
         for (int j = 0; j < NV; ++j) s += A[r * NV + j] * x[j];
         y[r] = s;
@@ -428,22 +456,24 @@ static void solve_M(const double *wx, const double *wy, double *x, double *y)
  * apply SCS's primal/dual balance by solving the problem with c' = c * cscale, which
  * leaves x unchanged and multiplies y, dobj by cscale (undone on return).
  */
-int orc_scs_solve(const double *c_in, double eps, int max_iters, double cscale, double *x_out, double *y_out,
-                  double *dobj, double *pobj, int *iters_out, double *res_out)
+int orc_scs_solve_var(int variant, const double *c_in, double eps, int max_iters, double cscale, double *x_out, double *y_out,
+                      double *dobj, double *pobj, int *iters_out, double *res_out)
 {
-    scs_static_init();
-    const double *A = g_scs.A, *b = g_scs.b;
+    scs_static_init_var(variant);
+    const scs_static_t *G = &g_scs_var[variant];
+    const double *A = G->A, *b = G->b;
+    const int NMv = G->nm, NZv = G->nz; /* rows, zero-cone rows: 77 / 22 (cvxpnpl.py:448) or 71 / 16 (rc.py:91) */
     const double alpha = 1.5;
     double c[NV];
     for (int j = 0; j < NV; ++j) c[j] = c_in[j] * cscale;
     /* M^-1 h, h = [c; b] */
     double ghx[NV], ghy[NM];
-    solve_M(c, b, ghx, ghy);
+    solve_M(G, c, b, ghx, ghy);
     double hgh = 0;
     for (int j = 0; j < NV; ++j) hgh += c[j] * ghx[j];
-    for (int r = 0; r < NM; ++r) hgh += b[r] * ghy[r];
+    for (int r = 0; r < NMv; ++r) hgh += b[r] * ghy[r];
     double nb = 0, nc = 0;
-    for (int r = 0; r < NM; ++r) nb += b[r] * b[r];
+    for (int r = 0; r < NMv; ++r) nb += b[r] * b[r];
     for (int j = 0; j < NV; ++j) nc += c[j] * c[j];
     nb = sqrt(nb); nc = sqrt(nc);
 
@@ -455,29 +485,29 @@ int orc_scs_solve(const double *c_in, double eps, int max_iters, double cscale, 
     for (it = 1; it <= max_iters; ++it) {
         /* u~ = (I+Q)^-1 (u + v) */
         for (int j = 0; j < NV; ++j) wx[j] = ux[j];
-        for (int r = 0; r < NM; ++r) wy[r] = uy[r] + vs[r];
+        for (int r = 0; r < NMv; ++r) wy[r] = uy[r] + vs[r];
         wt = ut + vk;
-        solve_M(wx, wy, tx, ty);
+        solve_M(G, wx, wy, tx, ty);
         double hmw = 0;
         for (int j = 0; j < NV; ++j) hmw += c[j] * tx[j];
-        for (int r = 0; r < NM; ++r) hmw += b[r] * ty[r];
+        for (int r = 0; r < NMv; ++r) hmw += b[r] * ty[r];
         tt = (wt + hmw) / (1.0 + hgh);
         for (int j = 0; j < NV; ++j) tx[j] -= ghx[j] * tt;
-        for (int r = 0; r < NM; ++r) ty[r] -= ghy[r] * tt;
+        for (int r = 0; r < NMv; ++r) ty[r] -= ghy[r] * tt;
         /* u = Pi_C(alpha u~ + (1-alpha) u - v), v += u - alpha u~ - (1-alpha) u_old */
         for (int j = 0; j < NV; ++j) ux[j] = alpha * tx[j] + (1 - alpha) * ux[j]; /* free cone, v_x = 0 */
         double ry[NM], un[NM];
-        for (int r = 0; r < NM; ++r) { ry[r] = alpha * ty[r] + (1 - alpha) * uy[r]; un[r] = ry[r] - vs[r]; }
-        proj_psd_svec(un + 22); /* dual cone: free (22) x PSD */
-        for (int r = 0; r < NM; ++r) { vs[r] = vs[r] - ry[r] + un[r]; uy[r] = un[r]; }
-        for (int r = 0; r < 22; ++r) vs[r] = 0.0; /* s in the zero cone */
+        for (int r = 0; r < NMv; ++r) { ry[r] = alpha * ty[r] + (1 - alpha) * uy[r]; un[r] = ry[r] - vs[r]; }
+        proj_psd_svec(un + NZv); /* dual cone: free (22 / 16) x PSD */
+        for (int r = 0; r < NMv; ++r) { vs[r] = vs[r] - ry[r] + un[r]; uy[r] = un[r]; }
+        for (int r = 0; r < NZv; ++r) vs[r] = 0.0; /* s in the zero cone */
         double rt = alpha * tt + (1 - alpha) * ut, utn = rt - vk;
         if (utn < 0) utn = 0;
         vk = vk - rt + utn; ut = utn;
 
         if (ut > 1e-12) {
             double px = 0, py = 0, rp = 0, rd = 0;
-            for (int r = 0; r < NM; ++r) {
+            for (int r = 0; r < NMv; ++r) {
                 double s = vs[r] / ut - b[r];
                 for (int j = 0; j < NV; ++j) s += A[r * NV + j] * ux[j] / ut;
                 rp += s * s;
@@ -485,7 +515,7 @@ int orc_scs_solve(const double *c_in, double eps, int max_iters, double cscale, 
             }
             for (int j = 0; j < NV; ++j) {
                 double s = c[j];
-                for (int r = 0; r < NM; ++r) s += A[r * NV + j] * uy[r] / ut;
+                for (int r = 0; r < NMv; ++r) s += A[r * NV + j] * uy[r] / ut;
                 rd += s * s;
                 px += c[j] * ux[j] / ut;
             }
@@ -497,12 +527,18 @@ int orc_scs_solve(const double *c_in, double eps, int max_iters, double cscale, 
     if (it > max_iters) it = max_iters;
     double px = 0, py = 0;
     for (int j = 0; j < NV; ++j) { x_out[j] = ut > 0 ? ux[j] / ut : NAN; px += c_in[j] * x_out[j]; }
-    for (int r = 0; r < NM; ++r) { double y = ut > 0 ? uy[r] / ut / cscale : NAN; if (y_out) y_out[r] = y; py += b[r] * y; }
+    for (int r = 0; r < NMv; ++r) { double y = ut > 0 ? uy[r] / ut / cscale : NAN; if (y_out) y_out[r] = y; py += b[r] * y; }
     if (dobj) *dobj = -py;
     if (pobj) *pobj = px;
     if (iters_out) *iters_out = it;
     if (res_out) { res_out[0] = pres; res_out[1] = dres; res_out[2] = gap; }
     return status;
+}
+
+int orc_scs_solve(const double *c_in, double eps, int max_iters, double cscale, double *x_out, double *y_out,
+                  double *dobj, double *pobj, int *iters_out, double *res_out)
+{
+    return orc_scs_solve_var(0, c_in, eps, max_iters, cscale, x_out, y_out, dobj, pobj, iters_out, res_out);
 }
 
 /* ------------------------------------------------------------------ rank > 1 recovery */
@@ -922,6 +958,36 @@ int orc_solve_relaxation(int m, const double *A, const double *B, double eps, in
     int status, rank;
     double eigs[10];
     int np = orc_recover(x, dobj, A, m, B, eps, R_out, t_out, &status, &rank, eigs);
+    if (info) {
+        info->n_poses = np; info->status = status; info->rank = rank; info->iters = iters;
+        info->scs_status = st; info->dobj = dobj; info->pobj = pobj;
+        memcpy(info->x, x, sizeof(x)); memcpy(info->eigs, eigs, sizeof(eigs));
+        info->res[0] = res[0]; info->res[1] = res[1]; info->res[2] = res[2];
+    }
+    return np;
+}
+
+/* benchmarks/toolkit/methods/rc.py:67-131 (_solve_relaxation_rc): the same driver on the 16-equality constraint set;
+ * the recovery (:104-131) is that of cvxpnpl.py:492-513 without the certificate check. */
+int orc_solve_relaxation_rc(int m, const double *A, const double *B, double eps, int max_iters,
+                            double *R_out, double *t_out, orc_info_t *info)
+{
+    double Q[100] = {0}, c[NV], x[NV], dobj, pobj, res[3];
+    for (int i = 0; i < 9; ++i)
+        for (int j = 0; j < 9; ++j) {
+            double s = 0;
+            for (int q = 0; q < m; ++q) s += A[q * 9 + i] * A[q * 9 + j];
+            Q[i * 10 + j] = s;
+        }
+    orc_vech10(Q, 2.0, c);
+    double tr = 0;
+    for (int i = 0; i < 9; ++i) tr += Q[i * 10 + i];
+    double cscale = tr > 0 ? 10.0 / tr : 1.0;
+    int iters, st = orc_scs_solve_var(1, c, eps, max_iters, cscale, x, NULL, &dobj, &pobj, &iters, res);
+    int status, rank;
+    double eigs[10];
+    int np = orc_recover(x, dobj, A, m, B, eps, R_out, t_out, &status, &rank, eigs);
+    status &= ~4; /* rc.py has no certificate check */
     if (info) {
         info->n_poses = np; info->status = status; info->rank = rank; info->iters = iters;
         info->scs_status = st; info->dobj = dobj; info->pobj = pobj;

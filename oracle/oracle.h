@@ -26,8 +26,13 @@ int orc_eliminate(int m, const double *C, const double *N, double *B, double *A)
 void orc_vech10(const double *A, double scale, double *v);
 void orc_vech10_inv(const double *v, double *A);
 void orc_sdp_constraints(double *Ad, double *b);
+void orc_sdp_constraints_rc(double *Ad71x55, double *b71); /* benchmarks/toolkit/methods/rc.py:9-64 */
 int orc_scs_solve(const double *c, double eps, int max_iters, double cscale, double *x, double *y,
                   double *dobj, double *pobj, int *iters, double *res);
+int orc_scs_solve_var(int variant, const double *c, double eps, int max_iters, double cscale, double *x, double *y,
+                      double *dobj, double *pobj, int *iters, double *res); /* variant 1: the rc constraint set */
+int orc_solve_relaxation_rc(int m, const double *A, const double *B, double eps, int max_iters,
+                            double *R_out, double *t_out, orc_info_t *info); /* rc.py:67-131 */
 int orc_poly_roots_real(int deg, const double *p, double *re);
 int orc_re6q3(int nrows, const double *A, double *a, double *b, double *c);
 int orc_constraint_ortho_det(const double *vecs, int rank, double *rc_out);

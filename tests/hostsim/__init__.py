@@ -16,7 +16,7 @@ _ip = C.POINTER(C.c_int)
 class Opts(C.Structure):
     _fields_ = [("eps", C.c_double), ("max_iters", C.c_int), ("rho", C.c_double), ("alpha", C.c_double),
                 ("first_check", C.c_int), ("check_every", C.c_int), ("res_tol", C.c_double), ("jacobi_sweeps", C.c_int),
-                ("jacobi_tol", C.c_double), ("warm_start", C.c_int), ("rho_tail", C.c_double), ("tail_from", C.c_int)]
+                ("jacobi_tol", C.c_double), ("warm_start", C.c_int), ("rho_tail", C.c_double), ("tail_from", C.c_int), ("variant", C.c_int)]
 
 
 def build(force=False):
@@ -107,3 +107,25 @@ def rounds_to(v, Rp, tol=0.1):
     lib().hs_rounds_to.argtypes = [_dp, _dp, C.c_double, C.POINTER(C.c_double)]
     ok = lib().hs_rounds_to(_p(v), _p(Rp), float(tol), C.byref(d0))
     return bool(ok), d0.value
+
+
+def solve_cost_batch(Q45, B27, opts=None, variant=0, want_Z=False):
+    """host build of the device algorithm at the cost seam (cvxpnpl_solve_cost_batch); variant 0 full / 1 rc"""
+    Q45 = np.ascontiguousarray(Q45, dtype=np.float64).reshape(-1, 45)
+    B27 = np.ascontiguousarray(B27, dtype=np.float64).reshape(-1, 27)
+    Bn = len(Q45)
+    o = opts or default_opts()
+    o.variant = int(variant)
+    R, t = np.zeros((Bn, 3, 3)), np.zeros((Bn, 3))
+    st, it, rk = (np.zeros(Bn, np.int32) for _ in range(3))
+    cost = np.zeros((Bn, 2))
+    Z = np.zeros((Bn, 55)) if want_Z else None
+    lib().hs_solve_cost_batch(Bn, _p(Q45), _p(B27), C.byref(o), _p(R), _p(t), st.ctypes.data_as(_ip), it.ctypes.data_as(_ip), _p(cost),
+                              rk.ctypes.data_as(_ip), _p(Z))
+    return {"R": R, "t": t, "status": st, "iters": it, "cost": cost, "rank": rk, "Z": Z}
+
+
+def proj_affine_rc(E55, homog):
+    E = np.ascontiguousarray(E55, dtype=np.float64).copy()
+    lib().hs_proj_affine_rc(_p(E), int(homog))
+    return E

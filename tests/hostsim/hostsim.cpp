@@ -60,3 +60,26 @@ int hs_pospart(const double *W, double *Wp, double *lam)
 
 void hs_polar3(const double *M, double *R, int iters) { cvx::polar3(M, R, iters); }
 }
+
+// the solve at the cost seam (cvxpnpl_solve_cost_batch), host pointers; variant: cvx::VAR_FULL / cvx::VAR_RC
+extern "C" int hs_solve_cost_batch(int batch, const double *Q45, const double *B27, const cvx::Opts *opts, double *R_out, double *t_out,
+                                   int *status, int *iters, double *cost, int *rank, double *Z_out)
+{
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int b = 0; b < batch; ++b) {
+        cvx::Solution sol;
+        double Z[55];
+        if (opts->variant == cvx::VAR_RC) cvx::solve_sdp<true, cvx::RegStore, cvx::VAR_RC>(Q45 + (size_t)b * 45, B27 + (size_t)b * 27, *opts, sol, Z_out ? Z : nullptr);
+        else cvx::solve_sdp<true, cvx::RegStore, cvx::VAR_FULL>(Q45 + (size_t)b * 45, B27 + (size_t)b * 27, *opts, sol, Z_out ? Z : nullptr);
+        for (int i = 0; i < 9; ++i) R_out[(size_t)b * 9 + i] = sol.R[i];
+        for (int i = 0; i < 3; ++i) t_out[(size_t)b * 3 + i] = sol.t[i];
+        if (status) status[b] = sol.status;
+        if (iters) iters[b] = sol.iters;
+        if (cost) { cost[2 * (size_t)b] = sol.cost; cost[2 * (size_t)b + 1] = sol.dobj; }
+        if (rank) rank[b] = sol.rank;
+        if (Z_out) for (int i = 0; i < 55; ++i) Z_out[(size_t)b * 55 + i] = Z[i];
+    }
+    return 0;
+}
+
+extern "C" void hs_proj_affine_rc(double *E, int homog) { cvx::proj_affine<cvx::VAR_RC>(E, homog != 0); }
