@@ -43,7 +43,8 @@ def _kernel_name(layout, batch):
     """kernels of one step (AUTO policy of cvxpnpl_solve_batch)"""
     if layout == 0:
         layout = 2 if batch < 3584 else (3 if batch < 38912 else 1)
-    return {1: "solve_lane_kernel + resume_wave_kernel", 2: "solve_wave_kernel", 3: "solve_quad_kernel (+ resume_wave_kernel: planar scenes only, empty here)"}[layout]
+    return {1: "solve_lane_kernel + resume_wave_kernel", 2: "solve_wave_kernel",
+            3: "solve_quad_kernel (+ resume_wave_kernel: planar scenes only, empty here)"}.get(layout, f"experimental layout {layout}")
 
 
 def main():

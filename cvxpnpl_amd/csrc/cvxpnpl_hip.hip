@@ -107,9 +107,8 @@ size_t hybrid_queue_bytes(int64_t cap) { return 256 + (((size_t)(cap + cvxw::RES
 size_t hybrid_ws_bytes(int64_t cap) { return hybrid_queue_bytes(cap) + (size_t)cap * 56 * sizeof(double); }
 int64_t hybrid_capacity(size_t bytes) // largest capacity whose layout fits
 {
-    const size_t fixed = 256 + 256 + (size_t)cvxw::RESUME_GRID_MAX * sizeof(int32_t);
-    if (bytes <= fixed) return 0;
-    int64_t cap = (int64_t)((bytes - fixed) / (sizeof(int32_t) + 56 * sizeof(double)));
+    if (bytes < hybrid_ws_bytes(1)) return 0;
+    int64_t cap = (int64_t)(bytes / (sizeof(int32_t) + 56 * sizeof(double))) + 1; // an upper bound, then down to the first fit
     while (cap > 0 && hybrid_ws_bytes(cap) > bytes) --cap;
     return cap;
 }

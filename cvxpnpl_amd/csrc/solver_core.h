@@ -1038,7 +1038,7 @@ struct Solution {
 // rank-1 ratio of the top eigenvector is meaningless there (for an exact two-fold ambiguity it is z1 - z2
 // with last entry 0), so the pose is the better of the two rank-2 candidates of the top-2 eigenspace
 // (twin_candidates: what the reference's rank-2 branch, cvxpnpl.py:303-315, computes for a rank-2 Z) --
-// proper rotations before reflections, then the lower cost.
+// proper rotations before reflections, then the lower cost; a proper rotation is Newton-polished on SO(3).
 template <class QV>
 CVX_HD double rounded_cost(QV Qs, const double *z, double *R, bool &fin)
 {
@@ -1071,6 +1071,16 @@ CVX_HD void fallback_pose(QV Qs, double tr, const double *v, const double *v2, i
         if (okp || okm) {
             CVX_UNROLL for (int i = 0; i < 9; ++i) sol.R[i] = take_m ? Rm[i] : Rp[i];
             c = take_m ? fm : fp;
+            // a proper rotation is Newton-polished on SO(3): the pose returned is then a stationary point of the cost,
+            // the same one cvxpnpl_recover_multi (with Q45) reports for this candidate
+            if (take_m ? pm : pp) {
+                double Rq[9], fq;
+                CVX_UNROLL for (int i = 0; i < 9; ++i) Rq[i] = sol.R[i];
+                polish_rotation(Qs, Rq, fq);
+                bool fin = (fq == fq);
+                CVX_UNROLL for (int i = 0; i < 9; ++i) fin &= (Rq[i] == Rq[i]);
+                if (fin) { CVX_UNROLL for (int i = 0; i < 9; ++i) sol.R[i] = Rq[i]; c = fq; }
+            }
         }
     }
     sol.cost = tr * c;

@@ -1039,6 +1039,21 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
 #pragma unroll
                         for (int i = 0; i < 9; ++i) Rf[i] = take_m ? Rm[i] : Rp[i];
                         fc = take_m ? fm : fp;
+                        if (take_m ? pm : pp) { // wave-uniform: polish a proper rotation (cvx::fallback_pose)
+                            double Rq[9], fq;
+#pragma unroll
+                            for (int i = 0; i < 9; ++i) Rq[i] = Rf[i];
+                            CVXW_SYNC();
+                            coop_polish(L, roles, Qs, Rq, fq CVXW_PH_ARG);
+                            bool fin = (fq == fq);
+#pragma unroll
+                            for (int i = 0; i < 9; ++i) fin = fin && (Rq[i] == Rq[i]);
+                            if (fin) {
+#pragma unroll
+                                for (int i = 0; i < 9; ++i) Rf[i] = Rq[i];
+                                fc = fq;
+                            }
+                        }
                     }
                 }
                 const int fst = rank > 1 ? cvx::ST_RANK_GT1

