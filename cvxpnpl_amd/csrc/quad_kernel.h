@@ -241,6 +241,11 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Op
     const int64_t b_raw = (int64_t)blockIdx.x * 4 + grp;
     const bool gvalid = b_raw < a.batch;
     const int64_t b = gvalid ? b_raw : a.batch - 1; // surplus rows redo the last problem, outputs suppressed
+#ifdef CVXQ_TIMELINE // diagnostics build (tools/timeline.py): shader-clock stamps of this wavefront, written over cost[] at the end
+    unsigned long long tl_[4];
+    auto tl_now = []() { unsigned long long t; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory"); return t; };
+    tl_[0] = tl_now();
+#endif
 
     // ---------------------------------------------------------------- roles
     Own w;
@@ -423,6 +428,9 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Op
 #pragma unroll
     for (int m = 0; m < 4; ++m) odd[m] = symm && ((w.ei[m] < 6) != (w.ej[m] < 6));
 
+#ifdef CVXQ_TIMELINE
+    tl_[1] = tl_now();
+#endif
     // ---------------------------------------------------------------- ADMM
     double delta = o.eps / (8.0 * tr);
     delta = delta < 1e-13 ? 1e-13 : delta;
@@ -839,6 +847,9 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Op
         }
     }
 
+#ifdef CVXQ_TIMELINE
+    tl_[2] = tl_now();
+#endif
     // ---------------------------------------------------------------- second phase (wave per problem)
     const unsigned long long pm = __ballot(parked);
     const unsigned pmask = (unsigned)((pm & 1ull) | ((pm >> 15) & 2ull) | ((pm >> 30) & 4ull) | ((pm >> 45) & 8ull));
@@ -852,6 +863,18 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Op
         const cvx::Opts o2 = o;
         finish_own(a2, o2, pmask, ws, lds_all);
     }
+#ifdef CVXQ_TIMELINE
+    tl_[3] = tl_now();
+    if (lane == 0 && a.cost && (int64_t)blockIdx.x * 4 + 1 < a.batch) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        double *c = a.cost + 2 * ((int64_t)blockIdx.x * 4);
+        c[0] = (double)tl_[0]; c[1] = (double)tl_[1]; c[2] = (double)tl_[2]; c[3] = (double)tl_[3];
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (a.work) { int32_t *wk = a.work + 2 * ((int64_t)blockIdx.x * 4); wk[0] = (int)hw; wk[1] = it; wk[2] = (int)(xcc & 15); }
+    }
+#endif
 }
 
 } // namespace cvxq
