@@ -165,6 +165,8 @@ cvx::Opts to_core(const cvxpnpl_opts_t *opts)
         o.first_check = opts->first_check; o.check_every = opts->check_every; o.res_tol = opts->res_tol;
         o.jacobi_sweeps = opts->jacobi_sweeps; o.jacobi_tol = opts->jacobi_tol; o.warm_start = opts->warm_start; o.rho_tail = opts->rho_tail; o.tail_from = opts->tail_from;
         o.variant = opts->variant;
+        o.adapt_every = opts->adapt_every; o.adapt_from = opts->adapt_from; o.adapt_mu = opts->adapt_mu; o.adapt_tau = opts->adapt_tau;
+        o.stall_from = opts->stall_from; o.stall_lam = opts->stall_lam; o.stall_res = opts->stall_res; o.stall_drop = opts->stall_drop;
     }
     return o;
 }
@@ -194,6 +196,8 @@ void cvxpnpl_default_opts(cvxpnpl_opts_t *opts)
     opts->eps = o.eps; opts->max_iters = o.max_iters; opts->rho = o.rho; opts->alpha = o.alpha;
     opts->first_check = o.first_check; opts->check_every = o.check_every; opts->res_tol = o.res_tol;
     opts->jacobi_sweeps = o.jacobi_sweeps; opts->jacobi_tol = o.jacobi_tol; opts->warm_start = o.warm_start; opts->rho_tail = o.rho_tail; opts->tail_from = o.tail_from; opts->lane_iters = -1; opts->layout = CVXPNPL_LAYOUT_AUTO; opts->variant = CVXPNPL_VARIANT_FULL;
+    opts->adapt_every = o.adapt_every; opts->adapt_from = o.adapt_from; opts->adapt_mu = o.adapt_mu; opts->adapt_tau = o.adapt_tau;
+    opts->stall_from = o.stall_from; opts->stall_lam = o.stall_lam; opts->stall_res = o.stall_res; opts->stall_drop = o.stall_drop;
 }
 
 static int check_args(int64_t batch, int32_t n_p, const double *p2, const double *p3, int32_t n_l, const double *l2,
@@ -212,7 +216,8 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     const int64_t batch = a.batch;
     if (!a.R || !a.t || !a.status) { snprintf(g_err, sizeof(g_err), "cvxpnpl: R, t and status outputs are required"); return -1; }
     if (opts && (opts->max_iters < 1 || !(opts->rho > 0) || !(opts->eps > 0) || opts->check_every < 1 || opts->first_check < 1 ||
-                 (opts->variant != CVXPNPL_VARIANT_FULL && opts->variant != CVXPNPL_VARIANT_RC))) {
+                 (opts->variant != CVXPNPL_VARIANT_FULL && opts->variant != CVXPNPL_VARIANT_RC) || opts->adapt_every < 0 ||
+                 (opts->adapt_every > 0 && !(opts->adapt_mu >= 1.0 && opts->adapt_tau > 1.0)))) {
         snprintf(g_err, sizeof(g_err), "cvxpnpl: bad options");
         return -1;
     }

@@ -64,6 +64,14 @@ struct Opts {
     int warm_start;    // 1: start each eigen-solve from the previous iteration's eigenvectors
     double rho_tail;   // penalty used from iteration tail_from on (the dual is rescaled at the switch)
     int tail_from;     // <= 0: never switch
+    int adapt_every;   // residual balancing of the penalty every this many iterations (0: never) ...
+    int adapt_from;    // ... from this iteration on
+    double adapt_mu;   // a residual larger than the other by this factor moves the penalty ...
+    double adapt_tau;  // ... by this factor (kept within [1e-3, 10])
+    int stall_from;    // from this iteration on a solve whose Z has settled at rank > 1 stops as RANK_GT1 (0: never): ...
+    double stall_lam;  // ... second eigenvalue above this and no longer shrinking since the previous attempt, ...
+    double stall_res;  // ... fixed-point residual below this
+    double stall_drop; // ... (relative decrease of the second eigenvalue between two attempts that still counts as settled)
     int variant;       // VAR_FULL: the 22 equalities of cvxpnpl.py:387-451; VAR_RC: the 16 of benchmarks/toolkit/methods/rc.py:9-64
 };
 
@@ -79,6 +87,7 @@ CVX_HD Opts default_opts()
     Opts o;
     o.eps = 1e-9; o.max_iters = 2500; o.rho = 0.1; o.alpha = 1.4;
     o.first_check = 5; o.check_every = 2; o.res_tol = 1e-5; o.jacobi_sweeps = 12; o.jacobi_tol = 6e-2; o.warm_start = 1; o.rho_tail = 0.05; o.tail_from = 3; o.variant = VAR_FULL;
+    o.adapt_every = 10; o.adapt_from = 20; o.adapt_mu = 2.0; o.adapt_tau = 2.0; o.stall_from = 300; o.stall_lam = 0.05; o.stall_res = 1e-3; o.stall_drop = 0.003;
     return o;
 }
 
@@ -1013,6 +1022,25 @@ CVX_HD void canon_congruence(const Canon &cn, double *Z, bool to_canon)
 // tail, which sets the end of every launch, gains most from the sparser attempts.
 constexpr int REUSE_MAX = 3; // consecutive certificate attempts that may take over the previous attempt's polished pose
 
+// residual balancing: rp2, rd2 = squared primal / dual residuals
+CVX_HD double adapted_rho(double rho, double rp2, double rd2, const Opts &o)
+{
+    const double m2 = o.adapt_mu * o.adapt_mu;
+    double rn = rho;
+    if (rp2 > m2 * rd2) rn = rho * o.adapt_tau;
+    else if (rd2 > m2 * rp2) rn = rho / o.adapt_tau;
+    return rn > 10.0 ? 10.0 : (rn < 1e-3 ? 1e-3 : rn);
+}
+
+// rank > 1 stall test (Opts::stall_*): lam1 >= lam2 the two largest eigenvalues of Z at this attempt, lam2_prev the
+// second one at the previous attempt
+CVX_HD bool rank_stalled(int it, double lam2, double lam2_prev, double fp_res, const Opts &o)
+{
+    // (a second eigenvalue that still shrinks -- by more than stall_drop of itself between two attempts -- is on its way to
+    // rank one: such a problem is left alone)
+    return o.stall_from > 0 && it >= o.stall_from && lam2 > o.stall_lam && fp_res < o.stall_res && (lam2_prev - lam2) <= o.stall_drop * lam2 && lam2_prev > 0;
+}
+
 CVX_HD int next_check_after(int it, const Opts &o)
 {
     int s = 1 + (it >= 10) + (it >= 16) + (it >= 24) + (it >= 36) + (it >= 54) + (it >= 80) + (it >= 104) + (it >= 128);
@@ -1150,7 +1178,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
     double Rk[2][9], fk[2] = {0, 0}; // the twins polished by the previous check (cvx::polish_or_reuse)
     bool hk[2] = {false, false};
     int tw_reused = 0, reused = 0;
-    double fp_res = 1e300;
+    double fp_res = 1e300, lam2_prev = -1.0;
     while (!done) {
         if (handoff_at > 0 && it >= handoff_at) { // W is the iterate after `it` completed iterations
             CVX_UNROLL for (int i = 0; i < 55; ++i) handoff[i] = W[i];
@@ -1188,6 +1216,11 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                 j2 = b1 ? jm : (b2 ? j : j2);
                 best = b1 ? n2 : best;
                 jm = b1 ? j : jm;
+            }
+            if (TWIN && o.stall_from > 0 && it >= o.stall_from - 32) { // a Z that has settled at rank > 1: the relaxation is not tight
+                const double lam2 = sqrt_fast(second) - e.sigma;
+                last = last || rank_stalled(it, lam2, lam2_prev, fp_res, o);
+                lam2_prev = lam2;
             }
             // Two-fold ambiguous problems (two poses with equal or nearly equal cost -- every planar scene is
             // one: R diag(-1,-1,1) has exactly the same algebraic cost) make Z converge to a rank-2 mixture
@@ -1312,6 +1345,31 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
             CVX_UNROLL for (int i = 0; i < 55; ++i) W[i] = Wp[i] + (W[i] - Wp[i]) * sc;
             rho = o.rho_tail;
             irho = 1.0 / rho;
+        }
+        if (TWIN && !done && o.adapt_every > 0 && it >= o.adapt_from && (it - o.adapt_from) % o.adapt_every == 0) { // (TWIN = false: the lane phase ends at iteration 5)
+            // Residual balancing for the slow tail (from iteration adapt_from on, every adapt_every): primal residual =
+            // distance of the PSD iterate from the affine set, dual residual = the part of S - Qs outside span A_i (S =
+            // rho (Wp - W)).  The larger one by more than adapt_mu gets the penalty moved its way by adapt_tau; the dual is
+            // kept (Wm rescaled), like at the tail_from switch.  Measured on 12 k minimal (N = 4) hypotheses: problems
+            // beyond 300 iterations 145 -> 59, uncertified exits 35 -> 8; planar scenes p99 968 -> 147 iterations.
+            double P[55], T[55];
+            CVX_UNROLL for (int i = 0; i < 55; ++i) { P[i] = Wp[i]; T[i] = rho * (Wp[i] - W[i]); }
+            CVX_UNROLL for (int i = 0; i < 9; ++i) CVX_UNROLL for (int j = i; j < 9; ++j) T[sidx(i, j)] -= Qs[qidx(i, j)];
+            proj_affine<VAR>(P, false);
+            proj_affine<VAR>(T, true);
+            double rp = 0, rd = 0;
+            CVX_UNROLL for (int i = 0; i < 10; ++i)
+                CVX_UNROLL for (int j = i; j < 10; ++j) {
+                    const double w_ = (i == j ? 1.0 : 2.0), dp_ = P[sidx(i, j)] - Wp[sidx(i, j)];
+                    rp += w_ * dp_ * dp_;
+                    rd += w_ * T[sidx(i, j)] * T[sidx(i, j)];
+                }
+            const double rn = adapted_rho(rho, rp, rd, o);
+            if (rn != rho) {
+                const double sc = rho / rn;
+                CVX_UNROLL for (int i = 0; i < 55; ++i) W[i] = Wp[i] + (W[i] - Wp[i]) * sc;
+                rho = rn; irho = 1.0 / rho;
+            }
         }
         if (!done) {
             // X = Pi_aff(2 Wp - W - Qs / rho);  W <- W + alpha (X - Wp)

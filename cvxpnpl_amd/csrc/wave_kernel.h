@@ -720,7 +720,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
         cold = true;
         if (o.tail_from > 0 && it >= o.tail_from) { rho = o.rho_tail; irho = 1.0 / rho; }
     }
-    double fp_res = 1e300;
+    double fp_res = 1e300, lam2_prev = -1.0;
     int status = cvx::ST_NONFINITE, rank_out = 0;
     bool done = !finite;
     bool certified = false;
@@ -841,7 +841,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
         ++it;
         CVXW_PH(PH_WP);
         const bool check = it >= next_check;
-        const bool last = (it >= o.max_iters) || (fp_res < o.res_tol);
+        bool last = (it >= o.max_iters) || (fp_res < o.res_tol);
         if (check || last) {
             // top eigenvector slot and the runner-up (wave-uniform)
             int smax = 0, s2nd = 0;
@@ -854,6 +854,11 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
                 s2nd = b1 ? smax : (b2 ? s : s2nd);
                 best = b1 ? n2 : best;
                 smax = b1 ? s : smax;
+            }
+            if (o.stall_from > 0 && it >= o.stall_from - 32) { // a Z that has settled at rank > 1 (cvx::rank_stalled): not tight, stop
+                const double lam2 = cvx::sqrt_fast(second) - sigma;
+                last = last || cvx::rank_stalled(it, lam2, lam2_prev, fp_res, o);
+                lam2_prev = lam2;
             }
             int rank = 0;
 #pragma unroll
@@ -1080,6 +1085,18 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
             W = Wp + (W - Wp) * (rho / o.rho_tail);
             rho = o.rho_tail;
             irho = 1.0 / rho;
+        }
+        if (!done && o.adapt_every > 0 && it >= o.adapt_from && (it - o.adapt_from) % o.adapt_every == 0) { // wave-uniform
+            // residual balancing of the penalty for the slow tail (cvx::solve_sdp has the rationale and the numbers)
+            const double Pa = coop_proj<VAR>(L, roles, Wp, 1.0);
+            const double Td = coop_proj<VAR>(L, roles, rho * (Wp - W) - (ej < 9 ? Qs : 0.0), 0.0);
+            const double rp2 = wave_sum(wgt * (Pa - Wp) * (Pa - Wp)), rd2 = wave_sum(wgt * Td * Td);
+            const double rn = cvx::adapted_rho(rho, rp2, rd2, o);
+            if (rn != rho) {
+                W = Wp + (W - Wp) * (rho / rn);
+                rho = rn;
+                irho = 1.0 / rho;
+            }
         }
         if (!done) {
             // X = Pi_aff(2 Wp - W - Qs / rho);  W <- W + alpha (X - Wp)

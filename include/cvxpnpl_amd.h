@@ -73,6 +73,15 @@ typedef struct {
                            quad: 10).  The lane phase is capped at 5 iterations. */
     int32_t layout;    /* CVXPNPL_LAYOUT_* */
     int32_t variant;   /* CVXPNPL_VARIANT_*, default FULL */
+    int32_t adapt_every; /* residual balancing of the penalty for long solves: every this many iterations (default 10; 0 never) */
+    int32_t adapt_from;  /* ... from this iteration on (default 20) */
+    double adapt_mu;     /* a primal / dual residual larger than the other by this factor (default 2) moves the penalty ... */
+    double adapt_tau;    /* ... by this factor (default 2), within [1e-3, 10] */
+    int32_t stall_from;  /* from this iteration on (default 300; 0 never) a solve whose Z has settled at rank > 1 -- second eigenvalue
+                            above stall_lam (0.05), no longer shrinking (by less than stall_drop = 0.3 % between two certificate
+                            attempts), fixed-point residual below stall_res (1e-3) -- stops as CVXPNPL_RANK_GT1: the relaxation
+                            is not tight and the first-order iteration would crawl to max_iters (the reference's solve does) */
+    double stall_lam, stall_res, stall_drop;
 } cvxpnpl_opts_t;
 
 void cvxpnpl_default_opts(cvxpnpl_opts_t *opts);
