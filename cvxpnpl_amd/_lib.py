@@ -17,6 +17,7 @@ _ip = C.POINTER(C.c_int32)
 # every symbol include/cvxpnpl_amd.h declares
 EXPORTS = (
     "cvxpnpl_default_opts", "cvxpnpl_solve_batch", "cvxpnpl_solve_cost_batch", "cvxpnpl_recover_multi", "cvxpnpl_recover_multi_batch", "cvxpnpl_assemble_batch",
+    "cvxpnpl_assemble_large_batch", "cvxpnpl_assemble_large_scratch_bytes",
     "cvxpnpl_score_hypotheses", "cvxpnpl_pack_results",
     "cvxpnpl_workspace_bytes", "cvxpnpl_set_workspace", "cvxpnpl_release_workspace", "cvxpnpl_calibration_copy",
     "cvxpnpl_event_create", "cvxpnpl_event_record", "cvxpnpl_event_elapsed_ms", "cvxpnpl_event_destroy",
@@ -68,6 +69,11 @@ def lib():
     L.cvxpnpl_assemble_batch.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cvxpnpl_assemble_batch.restype = C.c_int
+    L.cvxpnpl_assemble_large_scratch_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+    L.cvxpnpl_assemble_large_scratch_bytes.restype = C.c_size_t
+    L.cvxpnpl_assemble_large_batch.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.cvxpnpl_assemble_large_batch.restype = C.c_int
     L.cvxpnpl_recover_multi.argtypes = [_dp, _dp, _dp, _dp, _dp]
     L.cvxpnpl_recover_multi.restype = C.c_int
     L.cvxpnpl_recover_multi_batch.argtypes = [C.c_int64, _ip, _dp, _dp, _dp, _dp, _dp, _ip, C.c_int32]

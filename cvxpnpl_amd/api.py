@@ -95,6 +95,11 @@ def pnpl_batch(pts_2d, line_2d, pts_3d, line_3d, K, eps: float = 1e-9, max_iters
     n_l = l3.shape[-3] if l3 is not None and l3.dim() >= 4 else 0
     if n_p == 0 and n_l == 0:
         raise ValueError("need at least one point or line correspondence ([B,n,3] points / [B,n,2,3] lines)")
+    if n_p + 2 * n_l >= LARGE_N and (p3 if n_p else l3).shape[0] > 0:
+        # the scalability regime (benchmarks/scalability/pnp.py:37-40: up to 10^4 points per problem): bandwidth-shaped
+        # blocked assembly, then the solve at the cost seam -- instead of one wavefront streaming the problem
+        Bt, Qt = assemble_batch(pts_2d, line_2d, p3 if n_p else None, l3 if n_l else None, K, device=device, blocked=True)
+        return solve_cost_batch(Qt, Bt, eps=eps, max_iters=max_iters, want_Z=want_Z, device=device, **solver_opts)
     batch = (p3 if n_p else l3).shape[0]
     p2, l2 = _pair_2d(pts_2d, line_2d, device, batch, n_p, n_l)
     p3 = p3.reshape(batch, n_p, 3) if n_p else None
@@ -285,7 +290,10 @@ def solve_relaxation_rc(A: np.ndarray, B: np.ndarray, eps: float = 1e-9, max_ite
     return solve_relaxation(A, B, eps=eps, max_iters=max_iters, verbose=verbose, variant=_lib.VARIANT_RC)
 
 
-def assemble_batch(pts_2d, line_2d, pts_3d, line_3d, K, device=None):
+LARGE_N = 192  # correspondence records (points + 2 x lines) from which pnpl_batch assembles with the blocked kernel
+
+
+def assemble_batch(pts_2d, line_2d, pts_3d, line_3d, K, device=None, blocked=None):
     """Device-side constraint assembly only (cvxpnpl.py:432-452): returns (B [batch,27], Q [batch,45]),
     the translation map t = -B r and the packed 9x9 cost r^T Q r, as float64 device tensors.  What
     the rank > 1 recovery (recover_multi) needs next to Z."""
@@ -302,11 +310,29 @@ def assemble_batch(pts_2d, line_2d, pts_3d, line_3d, K, device=None):
     p2, l2 = _pair_2d(pts_2d, line_2d, dev, batch, n_p, n_l)
     Kd = _as_dev(K, dev, (3, 3))
     per = int(Kd.dim() == 3)
+    if blocked is None:
+        blocked = n_p + 2 * n_l >= LARGE_N
+    p3 = p3.reshape(batch, n_p, 3) if n_p else None
+    l3 = l3.reshape(batch, n_l, 2, 3) if n_l else None
     with torch.cuda.device(dev):
         Bt = torch.empty((batch, 27), dtype=torch.float64, device=dev)
         Qt = torch.empty((batch, 45), dtype=torch.float64, device=dev)
+        sh = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        if blocked:
+            # many correspondences per problem: several workgroups per problem at HBM rate (cvxpnpl_assemble_large_batch)
+            for lo in range(0, batch, 65535):
+                hi = min(batch, lo + 65535)
+                nb = L.cvxpnpl_assemble_large_scratch_bytes(hi - lo, n_p, n_l)
+                scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
+                sl = lambda x: None if x is None else x[lo:hi]  # noqa: E731
+                rc = L.cvxpnpl_assemble_large_batch(hi - lo, n_p, _ptr(sl(p2)), _ptr(sl(p3)), n_l, _ptr(sl(l2)), _ptr(sl(l3)),
+                                                    _ptr(Kd[lo:hi] if per else Kd), per, _ptr(Bt[lo:hi]), _ptr(Qt[lo:hi]),
+                                                    _ptr(scratch), nb, sh)
+                if rc != 0:
+                    raise RuntimeError(f"cvxpnpl_assemble_large_batch failed ({rc}): {_lib.last_error()}")
+            return Bt, Qt
         rc = L.cvxpnpl_assemble_batch(batch, n_p, _ptr(p2), _ptr(p3 if n_p else None), n_l, _ptr(l2), _ptr(l3 if n_l else None),
-                                      _ptr(Kd), per, _ptr(Bt), _ptr(Qt), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+                                      _ptr(Kd), per, _ptr(Bt), _ptr(Qt), sh)
     if rc != 0:
         raise RuntimeError(f"cvxpnpl_assemble_batch failed ({rc}): {_lib.last_error()}")
     return Bt, Qt

@@ -14,6 +14,7 @@
 #include "wave_kernel.h"
 #include "quad_kernel.h"
 #include "score_kernel.h"
+#include "assemble_kernel.h"
 
 namespace {
 
@@ -340,6 +341,36 @@ int cvxpnpl_assemble_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, c
     hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((batch + block - 1) / block)), dim3(block), 0, (hipStream_t)stream, a, d_B, d_Q45);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err("assemble_kernel launch", e);
+    return 0;
+}
+
+size_t cvxpnpl_assemble_large_scratch_bytes(int64_t batch, int32_t n_p, int32_t n_l)
+{
+    if (batch <= 0 || n_p < 0 || n_l < 0) return 0;
+    return (size_t)batch * cvxa::asm_blocks((int64_t)n_p + 2 * (int64_t)n_l, batch) * 60 * sizeof(double);
+}
+
+int cvxpnpl_assemble_large_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, const double *d_pts_3d, int32_t n_l,
+                                 const double *d_line_2d, const double *d_line_3d, const double *d_K, int32_t K_per_problem,
+                                 double *d_B, double *d_Q45, void *d_scratch, size_t scratch_bytes, void *stream)
+{
+    if (check_args(batch, n_p, d_pts_2d, d_pts_3d, n_l, d_line_2d, d_line_3d, d_K) || !d_B) return -1;
+    if (batch == 0) return 0;
+    if (batch > 65535) { snprintf(g_err, sizeof(g_err), "cvxpnpl_assemble_large_batch: at most 65535 problems per call (got %lld)", (long long)batch); return -1; }
+    const size_t need = cvxpnpl_assemble_large_scratch_bytes(batch, n_p, n_l);
+    if (!d_scratch || scratch_bytes < need) {
+        snprintf(g_err, sizeof(g_err), "cvxpnpl_assemble_large_batch: scratch of %zu bytes needed (cvxpnpl_assemble_large_scratch_bytes), got %zu", need, scratch_bytes);
+        return -1;
+    }
+    cvxa::AsmArgs a;
+    a.batch = batch; a.n_p = n_p; a.n_l = n_l; a.K_per_problem = K_per_problem;
+    a.nblk = cvxa::asm_blocks((int64_t)n_p + 2 * (int64_t)n_l, batch);
+    a.p2 = d_pts_2d; a.p3 = d_pts_3d; a.l2 = d_line_2d; a.l3 = d_line_3d; a.K = d_K;
+    a.partial = (double *)d_scratch;
+    hipLaunchKernelGGL(cvxa::assemble_large_kernel, dim3((unsigned)a.nblk, (unsigned)batch), dim3(cvxa::ASM_TPB), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(cvxa::assemble_finish_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a, d_B, d_Q45);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err("assemble_large_kernel launch", e);
     return 0;
 }
 

@@ -153,6 +153,19 @@ int cvxpnpl_assemble_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, c
                            const double *d_line_2d, const double *d_line_3d, const double *d_K, int32_t K_per_problem,
                            double *d_B, double *d_Q45, void *stream);
 
+/*
+ * The same outputs for problems with MANY correspondences (the reference's scalability benchmark goes to 10^4 points per
+ * problem, benchmarks/scalability/pnp.py:37-40): several workgroups per problem stream the correspondences at HBM rate and
+ * reduce the 60 Gram sums; sums are taken about the problem's first 3D point (exact, better conditioned far from the
+ * origin).  Feed d_B / d_Q45 to cvxpnpl_solve_cost_batch.  d_scratch: DEVICE memory of at least
+ * cvxpnpl_assemble_large_scratch_bytes(batch, n_p, n_l) bytes (partial sums; no initialisation needed).  batch <= 65535.
+ * Deterministic: partial sums are added in a fixed order.
+ */
+size_t cvxpnpl_assemble_large_scratch_bytes(int64_t batch, int32_t n_p, int32_t n_l);
+int cvxpnpl_assemble_large_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, const double *d_pts_3d, int32_t n_l,
+                                 const double *d_line_2d, const double *d_line_3d, const double *d_K, int32_t K_per_problem,
+                                 double *d_B, double *d_Q45, void *d_scratch, size_t scratch_bytes, void *stream);
+
 /* Results of one shard as the [batch][13] float64 records the multi-GPU gather exchanges (north-star config 4):
  * R (9, row-major), t (3), status.  DEVICE pointers; one launch on `stream`.  Returns 0, -1 for bad arguments. */
 int cvxpnpl_pack_results(int64_t batch, const double *d_R, const double *d_t, const int32_t *d_status, double *d_packed, void *stream);
