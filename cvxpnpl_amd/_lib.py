@@ -18,7 +18,7 @@ _ip = C.POINTER(C.c_int32)
 EXPORTS = (
     "cvxpnpl_default_opts", "cvxpnpl_solve_batch", "cvxpnpl_solve_cost_batch", "cvxpnpl_recover_multi", "cvxpnpl_recover_multi_batch", "cvxpnpl_assemble_batch",
     "cvxpnpl_assemble_large_batch", "cvxpnpl_assemble_large_scratch_bytes",
-    "cvxpnpl_score_hypotheses", "cvxpnpl_pack_results",
+    "cvxpnpl_score_hypotheses", "cvxpnpl_pack_results", "cvxpnpl_synth_batch", "cvxpnpl_pose_errors", "cvxpnpl_disambiguate",
     "cvxpnpl_workspace_bytes", "cvxpnpl_set_workspace", "cvxpnpl_release_workspace", "cvxpnpl_calibration_copy",
     "cvxpnpl_event_create", "cvxpnpl_event_record", "cvxpnpl_event_elapsed_ms", "cvxpnpl_event_destroy",
     "cvxpnpl_last_error", "cvxpnpl_version", "cvxpnpl_device_count",
@@ -83,6 +83,14 @@ def lib():
     L.cvxpnpl_score_hypotheses.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int32,
                                            C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cvxpnpl_score_hypotheses.restype = C.c_int
+    L.cvxpnpl_synth_batch.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cvxpnpl_synth_batch.restype = C.c_int
+    L.cvxpnpl_pose_errors.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cvxpnpl_pose_errors.restype = C.c_int
+    L.cvxpnpl_disambiguate.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cvxpnpl_disambiguate.restype = C.c_int
     L.cvxpnpl_workspace_bytes.argtypes = [C.c_int64]
     L.cvxpnpl_workspace_bytes.restype = C.c_size_t
     L.cvxpnpl_set_workspace.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]

@@ -15,6 +15,7 @@
 #include "quad_kernel.h"
 #include "score_kernel.h"
 #include "assemble_kernel.h"
+#include "synth_kernel.h"
 
 namespace {
 
@@ -372,6 +373,50 @@ int cvxpnpl_assemble_large_batch(int64_t batch, int32_t n_p, const double *d_pts
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err("assemble_large_kernel launch", e);
     return 0;
+}
+
+int cvxpnpl_synth_batch(int64_t batch, int32_t n_p, int32_t n_l, double sigma, uint64_t seed, const double *d_K, double *d_pts_2d,
+                        double *d_pts_3d, double *d_line_2d, double *d_line_3d, double *d_R_gt, double *d_t_gt, void *stream)
+{
+    if (batch < 0 || n_p < 0 || n_l < 0 || !d_K || !(sigma >= 0.0) || (n_p > 0 && (!d_pts_2d || !d_pts_3d)) || (n_l > 0 && (!d_line_2d || !d_line_3d))) {
+        snprintf(g_err, sizeof(g_err), "cvxpnpl_synth_batch: bad arguments");
+        return -1;
+    }
+    if (batch == 0) return 0;
+    cvxg::SynthArgs a;
+    a.batch = batch; a.n_p = n_p; a.n_l = n_l; a.sigma = sigma; a.length = 0.6 /* synth.py:55 */; a.seed = seed; a.K = d_K;
+    a.p2 = d_pts_2d; a.p3 = d_pts_3d; a.l2 = d_line_2d; a.l3 = d_line_3d; a.R_gt = d_R_gt; a.t_gt = d_t_gt;
+    const int64_t nrec = (int64_t)n_p + 2 * (int64_t)n_l, n = batch * (nrec > 0 ? nrec : 1), grid = (n + 255) / 256;
+    if (grid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl_synth_batch: too many records for one launch"); return -1; }
+    hipLaunchKernelGGL(cvxg::synth_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : set_err("synth_kernel launch", e);
+}
+
+int cvxpnpl_pose_errors(int64_t batch, const double *d_R_gt, const double *d_t_gt, const double *d_R, const double *d_t, double *d_ang_deg,
+                        double *d_trans, void *stream)
+{
+    if (batch < 0 || !d_R_gt || !d_t_gt || !d_R || !d_t || !d_ang_deg || !d_trans) { snprintf(g_err, sizeof(g_err), "cvxpnpl_pose_errors: bad arguments"); return -1; }
+    if (batch == 0) return 0;
+    hipLaunchKernelGGL(cvxg::pose_error_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, batch, d_R_gt, d_t_gt, d_R, d_t,
+                       d_ang_deg, d_trans);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : set_err("pose_error_kernel launch", e);
+}
+
+int cvxpnpl_disambiguate(int64_t batch, const double *d_R_all, const double *d_t_all, const int32_t *d_n_poses, const double *d_K,
+                         const double *d_R_gt, const double *d_t_gt, const double *d_support, int32_t n_support, double *d_R, double *d_t,
+                         int32_t *d_index, void *stream)
+{
+    if (batch < 0 || !d_R_all || !d_t_all || !d_n_poses || !d_K || !d_R_gt || !d_t_gt || (n_support > 0 && !d_support) || n_support < 0 || !d_R || !d_t || !d_index) {
+        snprintf(g_err, sizeof(g_err), "cvxpnpl_disambiguate: bad arguments");
+        return -1;
+    }
+    if (batch == 0) return 0;
+    hipLaunchKernelGGL(cvxg::disambiguate_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, batch, d_R_all, d_t_all,
+                       d_n_poses, d_K, d_R_gt, d_t_gt, d_support, n_support, d_R, d_t, d_index);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : set_err("disambiguate_kernel launch", e);
 }
 
 int cvxpnpl_pack_results(int64_t batch, const double *d_R, const double *d_t, const int32_t *d_status, double *d_packed, void *stream)

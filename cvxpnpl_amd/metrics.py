@@ -64,3 +64,60 @@ def disambiguate(R_all: np.ndarray, t_all: np.ndarray, n_poses: np.ndarray, K: n
     t = t_all[np.arange(B), idx].copy()
     R[none], t[none] = np.nan, np.nan
     return R, t, np.where(none, -1, idx)
+
+
+# ----------------------------------------------------------------------------------------------------- on the device
+def _dev_f64(x, device):
+    import torch
+
+    if not isinstance(x, torch.Tensor):
+        x = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64))
+    return x.to(device=device, dtype=torch.float64).contiguous()
+
+
+def pose_errors_device(R_gt, t_gt, R, t):
+    """pose_errors on the device (cvxpnpl_pose_errors, one HIP launch): (angular error [deg], relative translation error)
+    as float64 device tensors [B].  Inputs: device tensors (or anything torch.as_tensor takes)."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+
+    dev = R.device if isinstance(R, torch.Tensor) and R.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    Rg, tg, Rd, td = (_dev_f64(x, dev) for x in (R_gt, t_gt, R, t))
+    B = Rd.shape[0]
+    ang = torch.empty((B,), dtype=torch.float64, device=dev)
+    trans = torch.empty((B,), dtype=torch.float64, device=dev)
+    p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+    with torch.cuda.device(dev):
+        rc = _lib.lib().cvxpnpl_pose_errors(B, p(Rg), p(tg), p(Rd), p(td), p(ang), p(trans), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"cvxpnpl_pose_errors failed ({rc}): {_lib.last_error()}")
+    return ang, trans
+
+
+def disambiguate_device(R_all, t_all, n_poses, K, R_gt, t_gt, n_support: int = 20, seed: int = 0):
+    """disambiguate on the device (cvxpnpl_disambiguate): the same support points as the numpy version (same seed), the
+    same choice.  Returns device tensors (R [B,3,3], t [B,3], index [B] int32)."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+
+    dev = R_gt.device if isinstance(R_gt, torch.Tensor) and R_gt.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    Ra, ta, Kd, Rg, tg = (_dev_f64(x, dev) for x in (R_all, t_all, K, R_gt, t_gt))
+    npz = torch.as_tensor(np.asarray(n_poses) if not isinstance(n_poses, torch.Tensor) else n_poses).to(device=dev, dtype=torch.int32).contiguous()
+    S = torch.as_tensor(np.random.RandomState(seed).random_sample((n_support, 3)) - 0.5, device=dev)
+    B = Ra.shape[0]
+    R = torch.empty((B, 3, 3), dtype=torch.float64, device=dev)
+    t = torch.empty((B, 3), dtype=torch.float64, device=dev)
+    idx = torch.empty((B,), dtype=torch.int32, device=dev)
+    p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+    with torch.cuda.device(dev):
+        rc = _lib.lib().cvxpnpl_disambiguate(B, p(Ra), p(ta), p(npz), p(Kd), p(Rg), p(tg), p(S), n_support, p(R), p(t), p(idx),
+                                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"cvxpnpl_disambiguate failed ({rc}): {_lib.last_error()}")
+    return R, t, idx

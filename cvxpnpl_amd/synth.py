@@ -97,3 +97,87 @@ def make_planar_pnp(batch, n_p, sigma=0.0, seed=42, general=True, K=K_KINECT):
     if sigma > 0:
         d["pts_2d"] = d["pts_2d"] + rs.normal(scale=sigma, size=d["pts_2d"].shape)
     return d
+
+
+# ----------------------------------------------------------------------------------------------------- on the device
+def device_pnpl(batch, n_p, n_l, sigma=0.0, seed=42, K=K_KINECT, device=None):
+    """The same problems generated ON THE DEVICE (cvxpnpl_synth_batch: one HIP launch, counter-based Philox4x32-10):
+    no host generation, no H2D copy -- what accuracy sweeps over millions of problems use.  Returns a dict of float64
+    device tensors with the keys of make_pnpl (pts_2d, pts_3d, line_2d, line_3d, R_gt, t_gt, K).  The distributions
+    are the reference's (see the module docstring); the stream is Philox, restated in numpy by philox_pnpl below."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("device_pnpl needs a ROCm GPU")
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    Kd = torch.as_tensor(np.ascontiguousarray(K, dtype=np.float64), device=dev)
+    mk = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)  # noqa: E731
+    out = {"pts_2d": mk(batch, n_p, 2), "pts_3d": mk(batch, n_p, 3), "line_2d": mk(batch, n_l, 2, 2), "line_3d": mk(batch, n_l, 2, 3),
+           "R_gt": mk(batch, 3, 3), "t_gt": mk(batch, 3), "K": Kd}
+    p = lambda t: C.c_void_p(t.data_ptr()) if t.numel() else C.c_void_p(0)  # noqa: E731
+    with torch.cuda.device(dev):
+        rc = _lib.lib().cvxpnpl_synth_batch(batch, n_p, n_l, float(sigma), int(seed) & 0xFFFFFFFFFFFFFFFF, p(Kd), p(out["pts_2d"]), p(out["pts_3d"]),
+                                            p(out["line_2d"]), p(out["line_3d"]), p(out["R_gt"]), p(out["t_gt"]),
+                                            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"cvxpnpl_synth_batch failed ({rc}): {_lib.last_error()}")
+    return out
+
+
+def _philox4x32(c, k0, k1):
+    """Philox4x32-10 on uint32 arrays c [..., 4]; keys scalars.  numpy restatement of synth_kernel.h's generator."""
+    c = [np.asarray(c[..., i], dtype=np.uint64) for i in range(4)]
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    M = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]
+        p1 = np.uint64(0xCD9E8D57) * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & M, p1 & M, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & M, p0 & M]
+        k0 = (k0 + np.uint64(0x9E3779B9)) & M
+        k1 = (k1 + np.uint64(0xBB67AE85)) & M
+    return c
+
+
+def _u53(a, b):
+    return ((a >> np.uint64(5)).astype(np.float64) * 67108864.0 + (b >> np.uint64(6)).astype(np.float64)) / 9007199254740992.0
+
+
+def philox_pnpl(batch, n_p, n_l, sigma=0.0, seed=42, K=K_KINECT):
+    """numpy restatement of cvxpnpl_synth_batch (same counters, same arithmetic up to libm rounding): the checker of
+    the device generator."""
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    b = np.arange(batch, dtype=np.uint64)
+
+    def draw(rec, j, shape):
+        c = np.zeros(shape + (4,), dtype=np.uint64)
+        c[..., 0] = (b & np.uint64(0xFFFFFFFF)).reshape((-1,) + (1,) * (len(shape) - 1))
+        c[..., 1] = (b >> np.uint64(32)).reshape((-1,) + (1,) * (len(shape) - 1))
+        c[..., 2] = rec
+        c[..., 3] = j
+        return _philox4x32(c, k0, k1)
+
+    w = [draw(0xFFFFFFFF, j, (batch,)) for j in range(4)]
+    axis = np.stack([_u53(w[0][0], w[0][1]) - 0.5, _u53(w[0][2], w[0][3]) - 0.5, _u53(w[1][0], w[1][1]) - 0.5], 1)
+    axis = axis * (1.0 / np.sqrt((axis * axis).sum(1)))[:, None]
+    ang = 2.0 * np.pi * _u53(w[1][2], w[1][3])
+    kx, ky, kz = axis.T
+    zero = np.zeros(batch)
+    Kx = np.stack([np.stack([zero, -kz, ky], 1), np.stack([kz, zero, -kx], 1), np.stack([-ky, kx, zero], 1)], 1)
+    R = np.eye(3)[None] + np.sin(ang)[:, None, None] * Kx + (1.0 - np.cos(ang))[:, None, None] * (Kx @ Kx)
+    t = np.stack([_u53(w[2][0], w[2][1]) - 0.5, _u53(w[2][2], w[2][3]) - 0.5, 1.6 * _u53(w[3][0], w[3][1]) + 0.6], 1)
+    nrec = n_p + 2 * n_l
+    rec = np.arange(nrec, dtype=np.uint64)[None, :].repeat(batch, 0)
+    v = [draw(rec, j, (batch, nrec)) for j in range(3)]
+    P = LENGTH * np.stack([_u53(v[0][0], v[0][1]) - 0.5, _u53(v[0][2], v[0][3]) - 0.5, _u53(v[1][0], v[1][1]) - 0.5], -1)
+    x = project(P, np.asarray(K, dtype=np.float64), R, t)
+    if sigma > 0:
+        rad = np.sqrt(-2.0 * np.log(1.0 - _u53(v[1][2], v[1][3])))
+        th = 2.0 * np.pi * _u53(v[2][0], v[2][1])
+        x = x + sigma * np.stack([rad * np.cos(th), rad * np.sin(th)], -1)
+    return {"pts_2d": np.ascontiguousarray(x[:, :n_p]), "pts_3d": np.ascontiguousarray(P[:, :n_p]),
+            "line_2d": np.ascontiguousarray(x[:, n_p:].reshape(batch, n_l, 2, 2)),
+            "line_3d": np.ascontiguousarray(P[:, n_p:].reshape(batch, n_l, 2, 3)), "R_gt": R, "t_gt": t, "K": np.array(K, dtype=np.float64)}

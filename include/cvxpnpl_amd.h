@@ -166,6 +166,28 @@ int cvxpnpl_assemble_large_batch(int64_t batch, int32_t n_p, const double *d_pts
                                  const double *d_line_2d, const double *d_line_3d, const double *d_K, int32_t K_per_problem,
                                  double *d_B, double *d_Q45, void *d_scratch, size_t scratch_bytes, void *stream);
 
+/*
+ * The reference's benchmark toolkit on the device.  DEVICE pointers, one launch each.
+ *
+ * cvxpnpl_synth_batch: `batch` synthetic problems with n_p points and n_l lines each, the distributions of
+ *   benchmarks/toolkit/suites/synth.py:27-42 (pose), :276-346 (3D points 0.6 (U - .5), pixels K (R X + t) + N(0, sigma^2),
+ *   lines = consecutive point pairs); counter-based generator (Philox4x32-10 keyed by `seed`, counter = problem, record,
+ *   draw): reproducible, independent of the launch geometry.  Outputs in the layout of cvxpnpl_solve_batch's inputs;
+ *   d_R_gt [batch][9], d_t_gt [batch][3] (optional).
+ * cvxpnpl_pose_errors: angular error [degrees] of R_gt^-1 R after projection onto O(3), and |t - t_gt| / |t_gt|
+ *   (suite.py:8-14, :22-33); a NaN estimate gives NaN.
+ * cvxpnpl_disambiguate: for every problem the candidate (of d_n_poses[b] <= 4 in d_R_all [batch][4][9], d_t_all [batch][4][3],
+ *   e.g. the outputs of cvxpnpl_recover_multi_batch copied to the device) whose reprojection of the n_support support
+ *   points d_support [n_support][3] is closest to the ground truth's (suite.py:96-108); d_index = -1 and NaN when none.
+ */
+int cvxpnpl_synth_batch(int64_t batch, int32_t n_p, int32_t n_l, double sigma, uint64_t seed, const double *d_K, double *d_pts_2d,
+                        double *d_pts_3d, double *d_line_2d, double *d_line_3d, double *d_R_gt, double *d_t_gt, void *stream);
+int cvxpnpl_pose_errors(int64_t batch, const double *d_R_gt, const double *d_t_gt, const double *d_R, const double *d_t, double *d_ang_deg,
+                        double *d_trans, void *stream);
+int cvxpnpl_disambiguate(int64_t batch, const double *d_R_all, const double *d_t_all, const int32_t *d_n_poses, const double *d_K,
+                         const double *d_R_gt, const double *d_t_gt, const double *d_support, int32_t n_support, double *d_R, double *d_t,
+                         int32_t *d_index, void *stream);
+
 /* Results of one shard as the [batch][13] float64 records the multi-GPU gather exchanges (north-star config 4):
  * R (9, row-major), t (3), status.  DEVICE pointers; one launch on `stream`.  Returns 0, -1 for bad arguments. */
 int cvxpnpl_pack_results(int64_t batch, const double *d_R, const double *d_t, const int32_t *d_status, double *d_packed, void *stream);

@@ -1,0 +1,129 @@
+"""The reference's benchmark toolkit on the device: synthetic problem generator, error
+metrics and pose disambiguation as HIP kernels, against their numpy counterparts (cvxpnpl_amd/synth.py, metrics.py --
+themselves following benchmarks/toolkit/suites/synth.py:27-42, :276-346 and suite.py:8-33, :96-108).
+
+CPU: the numpy restatement of the counter-based generator has the reference's distributions.  GPU: device == numpy."""
+import numpy as np
+import pytest
+
+
+def test_philox_known_answer():
+    """Philox4x32-10 known-answer vectors (Random123 kat_vectors): counter / key all zero, and all ones."""
+    from cvxpnpl_amd.synth import _philox4x32
+
+    out = _philox4x32(np.zeros((1, 4), dtype=np.uint64), 0, 0)
+    assert [int(x[0]) for x in out] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    out = _philox4x32(np.full((1, 4), 0xFFFFFFFF, dtype=np.uint64), 0xFFFFFFFF, 0xFFFFFFFF)
+    assert [int(x[0]) for x in out] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+
+
+def test_philox_generator_has_the_reference_distributions():
+    from cvxpnpl_amd import synth
+
+    d = synth.philox_pnpl(20000, 3, 2, sigma=1.5, seed=7)
+    R, t = d["R_gt"], d["t_gt"]
+    assert np.abs(R @ np.swapaxes(R, 1, 2) - np.eye(3)).max() < 1e-12 and np.abs(np.linalg.det(R) - 1).max() < 1e-12
+    ang = np.arccos(np.clip(0.5 * (np.trace(R, axis1=1, axis2=2) - 1), -1, 1))
+    # rotation angle 2 pi U folded onto [0, pi]: uniform; t: U-.5, U-.5, 1.6 U + .6 (synth.py:36, :41)
+    assert abs(ang.mean() - np.pi / 2) < 0.03 and abs(ang.std() - np.pi / np.sqrt(12)) < 0.03
+    assert abs(t[:, 0].mean()) < 0.01 and abs(t[:, 1].std() - 1 / np.sqrt(12)) < 0.01
+    assert t[:, 2].min() >= 0.6 and t[:, 2].max() < 2.2 and abs(t[:, 2].mean() - 1.4) < 0.01
+    P = np.concatenate([d["pts_3d"].reshape(-1, 3), d["line_3d"].reshape(-1, 3)])
+    assert P.min() >= -0.3 and P.max() < 0.3 and abs(P.std() - 0.6 / np.sqrt(12)) < 0.002  # 0.6 (U - .5), synth.py:279
+    clean = synth.philox_pnpl(20000, 3, 2, sigma=0.0, seed=7)
+    noise = np.concatenate([(d["pts_2d"] - clean["pts_2d"]).ravel(), (d["line_2d"] - clean["line_2d"]).ravel()])
+    assert abs(noise.mean()) < 0.02 and abs(noise.std() - 1.5) < 0.02
+    assert abs(np.mean(noise ** 4) / noise.std() ** 4 - 3.0) < 0.1  # Gaussian kurtosis
+    # noise-free pixels are the projections (suite.py:17-19)
+    assert np.abs(clean["pts_2d"] - synth.project(clean["pts_3d"], clean["K"], clean["R_gt"], clean["t_gt"])).max() < 1e-9
+    # different seeds / problems are different streams
+    e = synth.philox_pnpl(8, 3, 2, sigma=0.0, seed=8)
+    assert np.abs(e["pts_3d"] - clean["pts_3d"][:8]).min() > 1e-9
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+
+    from cvxpnpl_amd import _lib
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch,n_p,n_l,sigma", [(1, 6, 0, 0.0), (1000, 10, 0, 2.0), (257, 5, 5, 1.0), (64, 0, 7, 0.5), (3, 0, 0, 0.0)])
+def test_device_generator_matches_numpy_restatement(gpu, batch, n_p, n_l, sigma):
+    """cvxpnpl_synth_batch == its numpy restatement: identical uniform draws (exact integer arithmetic), poses / points /
+    pixels to libm rounding; and the solver recovers the generated ground truth on noise-free data."""
+    import cvxpnpl_amd as ca
+    from cvxpnpl_amd import synth
+
+    d = synth.device_pnpl(batch, n_p, n_l, sigma=sigma, seed=1234 + batch, device=gpu)
+    h = synth.philox_pnpl(batch, n_p, n_l, sigma=sigma, seed=1234 + batch)
+    for k in ("pts_3d", "line_3d", "R_gt", "t_gt"):
+        assert np.abs(d[k].cpu().numpy() - h[k]).max() < 1e-14 if h[k].size else True, k
+    for k in ("pts_2d", "line_2d"):  # pixels ~ 1e2, noise through log / sin / cos
+        assert np.abs(d[k].cpu().numpy() - h[k]).max() < 1e-9 if h[k].size else True, k
+    if n_p + n_l >= 6 and sigma == 0.0:
+        res = ca.pnpl_batch(d["pts_2d"] if n_p else None, d["line_2d"] if n_l else None, d["pts_3d"] if n_p else None,
+                            d["line_3d"] if n_l else None, d["K"])
+        assert (res.status.cpu().numpy() == 0).all()
+        assert synth.geodesic(res.R.cpu().numpy(), d["R_gt"].cpu().numpy()).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_device_metrics_and_disambiguation_match_numpy(gpu):
+    """cvxpnpl_pose_errors / cvxpnpl_disambiguate == cvxpnpl_amd.metrics (numpy): errors to 1e-9, identical choices;
+    NaN poses, missing candidates and reflections handled like the reference's harness."""
+    import torch
+
+    from cvxpnpl_amd import metrics, synth
+
+    rs = np.random.RandomState(5)
+    B = 700
+    Rg, tg = synth.random_poses(rs, B)
+    dR, _ = synth.random_poses(rs, B)
+    small = rs.uniform(0, 1, B) < 0.7
+    w = rs.normal(size=(B, 3)) * 1e-3
+    for i in np.where(small)[0]:  # mostly small errors, like a benchmark
+        th = np.linalg.norm(w[i])
+        k = w[i] / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        dR[i] = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    R = Rg @ dR + rs.normal(size=(B, 3, 3)) * 1e-6  # not exactly orthogonal: the SVD projection matters
+    t = tg * (1 + rs.normal(size=(B, 1)) * 0.01)
+    R[3] = np.nan
+    R[7] = -R[7]  # a reflection (cvxpnpl.py:510-511 can return one)
+    a0, e0 = metrics.pose_errors(Rg, tg, R, t)
+    a1, e1 = metrics.pose_errors_device(torch.as_tensor(Rg, device=gpu), tg, torch.as_tensor(R, device=gpu), t)
+    a1, e1 = a1.cpu().numpy(), e1.cpu().numpy()
+    assert np.isnan(a1[3]) and np.isnan(a0[3])
+    ok = ~np.isnan(a0)
+    # arccos near 0 amplifies rounding: 1e-9 rad differences in R appear as ~1e-5 deg for errors ~1e-4 deg; compare in cos
+    assert np.abs(np.cos(np.radians(a0[ok])) - np.cos(np.radians(a1[ok]))).max() < 1e-12
+    big = ok & (a0 > 1e-3)
+    assert np.abs(a0[big] - a1[big]).max() < 1e-7 * np.maximum(1.0, a0[big]).max()
+    assert np.abs(e0 - e1).max() < 1e-13
+    # disambiguation: candidates = the true pose hidden among distractors
+    K = synth.K_KINECT
+    R_all = np.zeros((B, 4, 3, 3))
+    t_all = np.zeros((B, 4, 3))
+    n_poses = rs.choice([0, 1, 2, 4, -1], B).astype(np.int32)
+    where = rs.randint(0, 4, B)
+    for c in range(4):
+        Rc, tc = synth.random_poses(rs, B)
+        R_all[:, c], t_all[:, c] = Rc, tc
+    for i in range(B):
+        if n_poses[i] > 0:
+            j = where[i] % n_poses[i]
+            R_all[i, j], t_all[i, j] = Rg[i], tg[i]
+    R_all[11, 0] = np.nan
+    R0, t0, i0 = metrics.disambiguate(R_all, t_all, n_poses, K, Rg, tg)
+    R1, t1, i1 = metrics.disambiguate_device(R_all, t_all, n_poses, K, torch.as_tensor(Rg, device=gpu), tg)
+    assert np.array_equal(i0, i1.cpu().numpy())
+    assert np.array_equal(R0, R1.cpu().numpy(), equal_nan=True) and np.array_equal(t0, t1.cpu().numpy(), equal_nan=True)
+    picked = n_poses > 0
+    picked[11] = picked[11] and (where[11] % max(n_poses[11], 1)) != 0
+    assert (i0[picked] == (where % np.maximum(n_poses, 1))[picked]).all()
