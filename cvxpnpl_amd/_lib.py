@@ -16,7 +16,7 @@ _ip = C.POINTER(C.c_int32)
 
 # every symbol include/cvxpnpl_amd.h declares
 EXPORTS = (
-    "cvxpnpl_default_opts", "cvxpnpl_solve_batch", "cvxpnpl_solve_cost_batch", "cvxpnpl_recover_multi", "cvxpnpl_recover_multi_batch", "cvxpnpl_assemble_batch",
+    "cvxpnpl_default_opts", "cvxpnpl_solve_batch", "cvxpnpl_solve_cost_batch", "cvxpnpl_recover_multi", "cvxpnpl_recover_multi_batch", "cvxpnpl_recover_multi_device", "cvxpnpl_assemble_batch",
     "cvxpnpl_assemble_large_batch", "cvxpnpl_assemble_large_scratch_bytes",
     "cvxpnpl_score_hypotheses", "cvxpnpl_pack_results", "cvxpnpl_synth_batch", "cvxpnpl_pose_errors", "cvxpnpl_disambiguate",
     "cvxpnpl_workspace_bytes", "cvxpnpl_set_workspace", "cvxpnpl_release_workspace", "cvxpnpl_calibration_copy",
@@ -78,6 +78,8 @@ def lib():
     L.cvxpnpl_recover_multi.restype = C.c_int
     L.cvxpnpl_recover_multi_batch.argtypes = [C.c_int64, _ip, _dp, _dp, _dp, _dp, _dp, _ip, C.c_int32]
     L.cvxpnpl_recover_multi_batch.restype = C.c_int
+    L.cvxpnpl_recover_multi_device.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cvxpnpl_recover_multi_device.restype = C.c_int
     L.cvxpnpl_pack_results.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cvxpnpl_pack_results.restype = C.c_int
     L.cvxpnpl_score_hypotheses.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int32,

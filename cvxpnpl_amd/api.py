@@ -176,6 +176,33 @@ def recover_multi_batch(res: "BatchResult", B, Q=None, n_threads: int = 0):
     return R, t, cnt
 
 
+def recover_multi_device(res: "BatchResult", B, Q=None):
+    """recover_multi_batch on the DEVICE (cvxpnpl_recover_multi_device): every rank > 1 problem of a batch result solved
+    with want_Z=True, one HIP launch, nothing leaves the GPU.  B, Q: outputs of assemble_batch (device tensors).  Returns
+    device tensors (R [batch,4,3,3], t [batch,4,3], n_poses [batch] int32)."""
+    _require_gpu()
+    L = _lib.lib()
+    if getattr(res, "Z", None) is None:
+        raise ValueError("recover_multi_device needs the SDP solutions: solve with want_Z=True")
+    dev = res.Z.device
+    Z = res.Z.contiguous()
+    st = res.status.to(torch.int32).contiguous()
+    Bd = torch.as_tensor(B).to(device=dev, dtype=torch.float64).contiguous().reshape(-1, 27)
+    Qd = torch.as_tensor(Q).to(device=dev, dtype=torch.float64).contiguous().reshape(-1, 45) if Q is not None else None
+    n = Z.shape[0]
+    if Bd.shape[0] != n or (Qd is not None and Qd.shape[0] != n) or st.shape[0] != n:
+        raise ValueError("recover_multi_device: Z, B, Q and status must describe the same batch")
+    with torch.cuda.device(dev):
+        R = torch.empty((n, 4, 3, 3), dtype=torch.float64, device=dev)
+        t = torch.empty((n, 4, 3), dtype=torch.float64, device=dev)
+        cnt = torch.empty((n,), dtype=torch.int32, device=dev)
+        rc = L.cvxpnpl_recover_multi_device(n, _ptr(st), _ptr(Z), _ptr(Bd), _ptr(Qd), _ptr(R), _ptr(t), _ptr(cnt),
+                                            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"cvxpnpl_recover_multi_device failed ({rc}): {_lib.last_error()}")
+    return R, t, cnt
+
+
 def _alloc_outputs(batch, device, want_Z):
     R = torch.empty((batch, 3, 3), dtype=torch.float64, device=device)
     t = torch.empty((batch, 3), dtype=torch.float64, device=device)

@@ -16,6 +16,7 @@
 #include "score_kernel.h"
 #include "assemble_kernel.h"
 #include "synth_kernel.h"
+#include "recover_kernel.h"
 
 namespace {
 
@@ -417,6 +418,17 @@ int cvxpnpl_disambiguate(int64_t batch, const double *d_R_all, const double *d_t
                        d_n_poses, d_K, d_R_gt, d_t_gt, d_support, n_support, d_R, d_t, d_index);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : set_err("disambiguate_kernel launch", e);
+}
+
+int cvxpnpl_recover_multi_device(int64_t batch, const int32_t *d_status, const double *d_Z55, const double *d_B27, const double *d_Q45,
+                                 double *d_R_out, double *d_t_out, int32_t *d_n_poses, void *stream)
+{
+    if (batch < 0 || !d_Z55 || !d_B27 || !d_R_out || !d_t_out || !d_n_poses) { snprintf(g_err, sizeof(g_err), "cvxpnpl_recover_multi_device: bad arguments"); return -1; }
+    if (batch == 0) return 0;
+    hipLaunchKernelGGL(cvxr::recover_multi_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, (hipStream_t)stream, batch, d_status, d_Z55, d_B27,
+                       d_Q45, d_R_out, d_t_out, d_n_poses);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : set_err("recover_multi_kernel launch", e);
 }
 
 int cvxpnpl_pack_results(int64_t batch, const double *d_R, const double *d_t, const int32_t *d_status, double *d_packed, void *stream)

@@ -147,6 +147,16 @@ int cvxpnpl_recover_multi(const double *Z55, const double *B27, const double *Q4
 int cvxpnpl_recover_multi_batch(int64_t batch, const int32_t *status, const double *Z55, const double *B27, const double *Q45,
                                 double *R_out, double *t_out, int32_t *n_poses, int32_t n_threads);
 
+/*
+ * The same on the DEVICE, one launch for the whole batch: no copy of Z to the host, no host thread per problem (a batch of
+ * minimal RANSAC hypotheses flags 0.2 - 24 % of its problems, a planar batch all of them).  DEVICE pointers, same shapes
+ * and meaning as cvxpnpl_recover_multi_batch: d_status [batch] or NULL, d_Z55 [batch][55] (cvxpnpl_solve_batch's d_Z),
+ * d_B27 / d_Q45 (cvxpnpl_assemble_batch; d_Q45 may be NULL: no polish), d_R_out [batch][4][9], d_t_out [batch][4][3],
+ * d_n_poses [batch] (0 = skipped, 2 / 4 / 1 / -1 as cvxpnpl_recover_multi).  Same source as the host path: bit-comparable.
+ */
+int cvxpnpl_recover_multi_device(int64_t batch, const int32_t *d_status, const double *d_Z55, const double *d_B27, const double *d_Q45,
+                                 double *d_R_out, double *d_t_out, int32_t *d_n_poses, void *stream);
+
 /* Translation maps B (3x9 per problem, t = -B r; cvxpnpl.py:548) for callers that need them
  * on the host (cvxpnpl_recover_multi).  d_B [batch][27]. */
 int cvxpnpl_assemble_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, const double *d_pts_3d, int32_t n_l,

@@ -648,3 +648,61 @@ def test_ransac_default_device_and_workspace_entry_points(gpu):
     assert L.cvxpnpl_release_workspace(stream, 1) == 0
     r2 = _solve(gpu, big, 6, 0, layout=LAYOUTS["quad"])
     assert np.array_equal(r["R"], r2["R"])
+
+
+def test_device_rank_gt1_recovery(gpu, golden, orc):
+    """cvxpnpl_recover_multi_device (cvxpnpl.py:221-343, :156-218 on the GPU): the reference's own outputs for injected
+    rank-2 / rank-4 / rank-1 solutions (golden G6, G7: _constraint_ortho_det + _re6q3 + the SVD projection), and the host
+    path on HIP-produced Z (minimal problems cut short: ranks 2..6; planar scenes: certified pairs)."""
+    import torch
+
+    import cvxpnpl_amd as ca
+    from cvxpnpl_amd import synth
+    from cvxpnpl_amd.api import BatchResult
+
+    # golden: x -> poses through the reference's _solve_relaxation (tests/golden/make_golden.py, G6)
+    tags = ("r1", "r1p", "r2", "r4")
+    Z = torch.as_tensor(np.stack([golden[f"g6_{t}_x"] for t in tags]), device=gpu)
+    B = torch.as_tensor(np.tile(golden["g3_pnp_B"].reshape(1, 27), (4, 1)), device=gpu)
+    res = BatchResult(Z=Z, status=torch.ones(4, dtype=torch.int32, device=gpu))
+    R, t, cnt = ca.recover_multi_device(res, B)
+    R, t, cnt = R.cpu().numpy(), t.cpu().numpy(), cnt.cpu().numpy()
+    for k, tag in enumerate(tags):
+        Rg, tg = golden[f"g6_{tag}_R"], golden[f"g6_{tag}_t"]
+        assert cnt[k] == len(Rg), (tag, cnt[k])
+        for i in range(cnt[k]):
+            assert min(geodesic_np(R[k, i], Rg[j]) + np.abs(t[k, i] - tg[j]).max() for j in range(len(Rg))) < 1e-8, tag
+    # NaN solution: -1 poses (reference: NaN sentinel)
+    res = BatchResult(Z=torch.full((1, 55), float("nan"), dtype=torch.float64, device=gpu), status=torch.ones(1, dtype=torch.int32, device=gpu))
+    assert int(ca.recover_multi_device(res, B[:1])[2][0]) == -1
+    # HIP-produced Z: device == host, with and without the Newton polish
+    for d, n_p, kw in ((synth.make_pnp(600, 4, 1.0, seed=9), 4, dict(max_iters=6, first_check=1000)),
+                       (synth.make_planar_pnp(400, 8, 0.5, seed=21, general=True), 8, {})):
+        tt = lambda x: torch.as_tensor(x, device=gpu)  # noqa: E731
+        r = ca.pnp_batch(tt(d["pts_2d"]), tt(d["pts_3d"]), tt(d["K"]), want_Z=True, **kw)
+        Bt, Qt = ca.assemble_batch(tt(d["pts_2d"]), None, tt(d["pts_3d"]), None, tt(d["K"]))
+        st = r.status.cpu().numpy()
+        assert (st == 1).sum() > 100
+        for Q in (None, Qt):
+            Rh, th, ch = ca.recover_multi_batch(r, Bt, Q)
+            Rd, td, cd_ = ca.recover_multi_device(r, Bt, Q)
+            Rd, td, cd_ = Rd.cpu().numpy(), td.cpu().numpy(), cd_.cpu().numpy()
+            assert np.array_equal(ch, cd_)
+            assert (cd_[st != 1] == 0).all() and np.isin(cd_[st == 1], (2, 4, -1)).all()
+            # same source, two compilers (fused multiply-adds differ): the pose SETS agree (the root finder may list the four
+            # poses of the rank-4 branch in another order); typical 1e-14.  Odd ranks pad the basis with an eigenvector from
+            # a degenerate null space (cvxpnpl.py:231-233) where any rounding difference changes the answer -- for the
+            # reference itself too (test_uncertified_exits_follow_reference_recovery) -- and are only counted.
+            Zn = r.Z.cpu().numpy()
+            n_ok = n_bad = 0
+            for i in np.where(st == 1)[0]:
+                if cd_[i] <= 0:
+                    continue
+                rank = int((np.linalg.eigvalsh(orc.vech10_inv(Zn[i])) > 1e-3).sum())
+                e = max(min(geodesic_np(Rd[i, k], Rh[i, j]) + np.abs(td[i, k] - th[i, j]).max() for j in range(ch[i])) for k in range(cd_[i]))
+                if rank in (2, 4):
+                    assert e < 1e-6, (i, rank, e)
+                    n_ok += 1
+                else:
+                    n_bad += e > 1e-6
+            assert n_ok > 50
