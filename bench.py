@@ -303,7 +303,7 @@ def main():
         if pmc:
             out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
             out["roofline"]["traffic_source"] = pmc["source"]
-            out["roofline"]["traffic_detail"] = {k: pmc[k] for k in ("fetch_bytes", "write_bytes", "calibration") if k in pmc}
+            out["roofline"]["traffic_detail"] = {k: pmc[k] for k in ("fetch_bytes", "write_bytes", "by_kernel", "calibration") if k in pmc}
             if pmc.get("valu_insts_per_launch"):
                 # what actually binds: VALU issue.  One wave64 VALU instruction occupies a SIMD for 4 cycles
                 # (fp64 FMA is full rate on gfx950); 256 CUs x 4 SIMDs at the 2.4 GHz peak engine clock.
@@ -470,9 +470,13 @@ def _measure_pmc(args):
     ff = ref.get("fetch_reported_over_true") or 1.0
     wf = ref.get("write_reported_over_true") or 1.0
     fetch, write = per_step("FETCH_SIZE") * 1024 / ff, per_step("WRITE_SIZE") * 1024 / wf
+    by_kernel = {k: {"fetch_bytes": (sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"])) * 1024 / ff if "FETCH_SIZE" in v else None,
+                     "write_bytes": (sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])) * 1024 / wf if "WRITE_SIZE" in v else None,
+                     "valu_insts": sum(v["SQ_INSTS_VALU"]) / len(v["SQ_INSTS_VALU"]) if "SQ_INSTS_VALU" in v else None,
+                     "waves": sum(v["SQ_WAVES"]) / len(v["SQ_WAVES"]) if "SQ_WAVES" in v else None} for k, v in solve.items()}
     return {"hbm_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
             "valu_insts_per_launch": per_step("SQ_INSTS_VALU"), "salu_insts_per_launch": per_step("SQ_INSTS_SALU"),
-            "lds_insts_per_launch": per_step("SQ_INSTS_LDS"), "waves_per_launch": per_step("SQ_WAVES"),
+            "lds_insts_per_launch": per_step("SQ_INSTS_LDS"), "waves_per_launch": per_step("SQ_WAVES"), "by_kernel": by_kernel,
             "calibration": {"bytes_per_lane": cal, "applied": "8 (the width of this path's global accesses): reported / true",
                             "fetch_factor": ff, "write_factor": wf},
             "lib_sha16": _lib_hash(),

@@ -106,6 +106,13 @@ void launch_wave(int64_t wgrid, hipStream_t s, const cvxw::WaveArgs &w, const cv
     else hipLaunchKernelGGL(cvxw::solve_wave_kernel<cvx::VAR_FULL>, dim3((unsigned)wgrid), dim3(64 * cvxw::WPB), 0, s, w, o);
 }
 
+void launch_resume(int64_t rgrid, hipStream_t s, const cvxw::WaveArgs &w, const cvx::Opts &o, int32_t *count, int32_t *entries, const double *ws)
+{
+    cvxw::ResumeArgs ra;
+    ra.a = w; ra.o = o; ra.count_p = count; ra.entries = entries; ra.ws = ws;
+    hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64), 0, s, ra);
+}
+
 size_t hybrid_queue_bytes(int64_t cap) { return 256 + (((size_t)(cap + cvxw::RESUME_GRID_MAX) * sizeof(int32_t) + 255) & ~(size_t)255); }
 size_t hybrid_ws_bytes(int64_t cap) { return hybrid_queue_bytes(cap) + (size_t)cap * 56 * sizeof(double); }
 int64_t hybrid_capacity(size_t bytes) // largest capacity whose layout fits
@@ -263,11 +270,13 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
         int32_t *count = wv.count, *entries = wv.entries;
         double *ws = wv.parked;
         const int64_t qgrid = (batch + 3) / 4;
-        if (opts && opts->layout == 9) hipLaunchKernelGGL((cvxq::solve_quad_kernel<1, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, w, o, quad_iters, count, entries, ws); // experiment
-        else if (opts && opts->layout == 8) hipLaunchKernelGGL((cvxq::solve_quad_kernel<1, 4>), dim3((unsigned)qgrid), dim3(64), 0, s, w, o, quad_iters, count, entries, ws); // experiment
-        else hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, w, o, quad_iters, count, entries, ws);
+        cvxq::QuadArgs qa;
+        qa.a = w; qa.o = o; qa.handoff_at = quad_iters; qa.qcount = count; qa.qentries = entries; qa.ws = ws;
+        if (opts && opts->layout == 9) hipLaunchKernelGGL((cvxq::solve_quad_kernel<1, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // experiment
+        else if (opts && opts->layout == 8) hipLaunchKernelGGL((cvxq::solve_quad_kernel<1, 4>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // experiment
+        else hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         const int64_t rgrid = batch < cvxw::RESUME_GRID_MAX ? batch : cvxw::RESUME_GRID_MAX;
-        hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64 * cvxw::WPB), 0, s, w, o, count, entries, (const double *)ws);
+        launch_resume(rgrid, s, w, o, count, entries, ws);
     } else if (layout == CVXPNPL_LAYOUT_WAVE) {
         int64_t wgrid = (batch + cvxw::WPB - 1) / cvxw::WPB;
         if (wgrid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }
@@ -289,7 +298,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
             double *ws = wv.parked;
             hipLaunchKernelGGL(solve_lane_kernel, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws);
             const int64_t rgrid = batch < cvxw::RESUME_GRID_MAX ? batch : cvxw::RESUME_GRID_MAX;
-            hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64 * cvxw::WPB), 0, s, w, o, count, entries, (const double *)ws);
+            launch_resume(rgrid, s, w, o, count, entries, ws);
         } else {
             // fewer iterations allowed than the lane phase would run: the wave kernel does the whole solve
             int64_t wgrid = (batch + cvxw::WPB - 1) / cvxw::WPB;

@@ -124,11 +124,18 @@ __device__ __forceinline__ double flip(double x, unsigned neg) // neg in {0, 1}
 __device__ __forceinline__ unsigned grp_bits(unsigned long long m, int grp) { return (unsigned)(m >> (16 * grp)) & 0xFFFFu; }
 
 // entries owned by a lane
+// Only the packed words are state; everything else is re-derived where it is used (a few bit-field extracts), and the
+// main loop hides the words behind an empty asm once per iteration so that the compiler cannot hoist the derived values
+// out of the loop and carry ~28 registers of them across every phase (they were the bulk of the kernel's spills).
 struct Own {
-    int e[4], ei[4], ej[4];
     unsigned pk[4];
-    bool ok[4];
-    double wgt[4];
+    int gl;
+    __device__ __forceinline__ int e(int m) const { return gl + 16 * m; }
+    __device__ __forceinline__ int ei(int m) const { return (int)(pk[m] & 15u); }
+    __device__ __forceinline__ int ej(int m) const { return (int)((pk[m] >> 4) & 15u); }
+    __device__ __forceinline__ bool ok(int m) const { return gl + 16 * m < 55; }
+    __device__ __forceinline__ double wgt(int m) const { return ok(m) ? (ei(m) == ej(m) ? 1.0 : 2.0) : 0.0; }
+    __device__ __forceinline__ void refresh() { asm volatile("" : "+v"(pk[0]), "+v"(pk[1]), "+v"(pk[2]), "+v"(pk[3])); }
 };
 
 // Projection of the symmetric matrix held 3-4 entries per lane onto { <A_i, Z> = b_i } (tgt = 1) or its
@@ -137,7 +144,7 @@ __device__ __forceinline__ void quad_proj(double *L, const Own &w, double *X, do
 {
 #pragma unroll
     for (int m = 0; m < 4; ++m)
-        if (w.ok[m]) L[Q_X + w.e[m]] = X[m];
+        if (w.ok(m)) L[Q_X + w.e(m)] = X[m];
     CVXW_SYNC();
     double d[9];
 #pragma unroll
@@ -148,9 +155,9 @@ __device__ __forceinline__ void quad_proj(double *L, const Own &w, double *X, do
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const unsigned pk = w.pk[m];
-        const int ri = w.ei[m] % 3, ci = w.ei[m] / 3; // diagonal entry (ei, ei), ei < 9, is D[ri][ci]
+        const int ri = w.ei(m) % 3, ci = w.ei(m) / 3; // diagonal entry (ei, ei), ei < 9, is D[ri][ci]
         const double rr = ri == 0 ? r0 : (ri == 1 ? r1 : r2), cc = ci == 0 ? c0 : (ci == 1 ? c1 : c2);
-        const double xdiag = (w.ei[m] == 9) ? tgt : X[m] - (rr + cc) * (1.0 / 3.0) + tot * (1.0 / 9.0);
+        const double xdiag = (w.ei(m) == 9) ? tgt : X[m] - (rr + cc) * (1.0 / 3.0) + tot * (1.0 / 9.0);
         const double x1 = L[Q_X + ((pk >> 8) & 63)], x2 = L[Q_X + ((pk >> 14) & 63)];
         const unsigned n0 = (pk >> 20) & 1;
         const double mm = (flip(X[m], n0) + flip(x1, (pk >> 21) & 1) + flip(x2, (pk >> 22) & 1)) * (1.0 / 3.0);
@@ -188,15 +195,15 @@ __device__ __forceinline__ double quad_ldl(double *L, const Own &w, double *Me)
     for (int k = 0; k < 10; ++k) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-            if (w.ok[m] && w.ei[m] == k) L[C_ROW + w.ej[m]] = Me[m];
+            if (w.ok(m) && w.ei(m) == k) L[C_ROW + w.ej(m)] = Me[m];
         CVXW_SYNC();
         const double d = L[C_ROW + k];
         minp = d < minp ? d : minp;
         const double id = cvxw::fast_rcp(d);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const double ra = L[C_ROW + w.ei[m]], rb = L[C_ROW + w.ej[m]];
-            if (w.ei[m] > k) Me[m] -= ra * id * rb;
+            const double ra = L[C_ROW + w.ei(m)], rb = L[C_ROW + w.ej(m)];
+            if (w.ei(m) > k) Me[m] -= ra * id * rb;
         }
         CVXW_SYNC();
     }
@@ -218,22 +225,48 @@ __device__ __forceinline__ double quad_ldl(double *L, const Own &w, double *Me)
 // segment inside the callee (the segment pointer is null there); handing that pointer down (scalar loads, but the
 // callee's frame grows from 136 to 588 B); through LDS, with or without readfirstlane (callee frame 492 / 552 B).)
 __device__ __forceinline__ void park(double *p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __noinline__ void finish_own(const WaveArgs &a, const cvx::Opts &o, unsigned parked, const double *ws, double *lds)
+
+// All kernel arguments as ONE struct, so that the kernarg segment IS this struct: the second phase reads what it needs
+// straight from there (scalar loads through the segment pointer the kernel hands down) instead of from copies on the
+// stack.  History: handing down references to the kernel's own by-value arguments made every wavefront of the grid
+// write them to its scratch frame at kernel entry (190 B per lane = 30 MB of HBM writes per 10 k launch in round 1;
+// copies made inside the calling branch fixed that until the option block grew and LLVM hoisted part of the copy back
+// to the entry: 68 B per lane again).
+struct QuadArgs {
+    WaveArgs a;
+    cvx::Opts o;
+    int handoff_at;
+    int32_t *qcount, *qentries;
+    double *ws;
+};
+typedef const __attribute__((address_space(4))) QuadArgs *QuadArgsPtr;
+
+__device__ __noinline__ void finish_own(QuadArgsPtr kp, unsigned parked, double *lds)
 {
+#if defined(__HIP_DEVICE_COMPILE__) // (the host pass cannot copy out of the constant address space; it never calls this)
+    const WaveArgs a = kp->a; // scalar loads from the kernarg segment, only in the wavefronts that get here
+    const cvx::Opts o = kp->o;
+    const double *ws = kp->ws;
     const int64_t b0 = (int64_t)blockIdx.x * 4;
     for (int g = 0; g < 4; ++g) { // wave-uniform
         if (!((parked >> g) & 1u)) continue;
         cvxw::solve_one_wave(a, o, b0 + g, lds, ws + (b0 + g) * 56);
         CVXW_SYNC();
     }
+#endif
 }
 
 // MODE 0: the schedule described above.  MODE 1 (experiment, tools/phase_a_time.sh): the iterations only -- no
 // certificate code is compiled in, every problem is parked after handoff_at iterations -- to measure what the
 // iteration phase costs at the occupancy it gets without the certificate's registers.
 template <int MODE, int OCC = 2>
-__global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Opts o, int handoff_at, int32_t *qcount, int32_t *qentries, double *ws)
+__global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
 {
+    const WaveArgs &a = k.a;
+    const cvx::Opts &o = k.o;
+    const int handoff_at = k.handoff_at;
+    int32_t *const qcount = k.qcount, *const qentries = k.qentries;
+    double *const ws = k.ws;
     __shared__ __attribute__((aligned(16))) double lds_all[4 * QLDS];
     const int lane = threadIdx.x & 63, gl = lane & 15, grp = lane >> 4;
     double *L = lds_all + grp * QLDS;
@@ -249,15 +282,9 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Op
 
     // ---------------------------------------------------------------- roles
     Own w;
+    w.gl = gl;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        w.e[m] = gl + 16 * m;
-        w.ok[m] = w.e[m] < 55;
-        w.pk[m] = kETab.w[w.e[m]];
-        w.ei[m] = (int)(w.pk[m] & 15);
-        w.ej[m] = (int)((w.pk[m] >> 4) & 15);
-        w.wgt[m] = w.ok[m] ? (w.ei[m] == w.ej[m] ? 1.0 : 2.0) : 0.0;
-    }
+    for (int m = 0; m < 4; ++m) w.pk[m] = kETab.w[gl + 16 * m];
     const unsigned long long ptab = kPTab.packed[gl];
     const int lane_base4 = (lane & 48) << 2;
 
@@ -267,7 +294,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Op
     if (a.Q45) {
         // cost entry (the seam of cvxpnpl.py:454-460): A^T A (packed 9x9) and B come from the caller
 #pragma unroll
-        for (int m = 0; m < 4; ++m) Qs[m] = (w.ok[m] && w.ej[m] < 9) ? a.Q45[b * 45 + cvx::qidx(w.ei[m], w.ej[m])] : 0.0;
+        for (int m = 0; m < 4; ++m) Qs[m] = (w.ok(m) && w.ej(m) < 9) ? a.Q45[b * 45 + cvx::qidx(w.ei(m), w.ej(m))] : 0.0;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
             if (gl + 16 * m < 27) L[Q_B + gl + 16 * m] = a.B27[b * 27 + gl + 16 * m];
@@ -374,8 +401,8 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Op
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             double v = 0.0;
-            if (w.ok[m] && w.ej[m] < 9) {
-                const int qa = w.ei[m] / 3, qi = w.ei[m] % 3, qb = w.ej[m] / 3, qj = w.ej[m] % 3;
+            if (w.ok(m) && w.ej(m) < 9) {
+                const int qa = w.ei(m) / 3, qi = w.ei(m) % 3, qb = w.ej(m) / 3, qj = w.ej(m) % 3;
                 const double *m1 = L + Q_WF + 6 + 6 * qa, *m2 = L + Q_WF + 24 + 6 * psym(qa, qb);
                 v = m2[psym(qi, qj)];
 #pragma unroll
@@ -387,7 +414,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Op
     CVXW_SYNC();
 #pragma unroll
     for (int m = 0; m < 4; ++m)
-        if (w.ok[m]) L[Q_X + w.e[m]] = Qs[m];
+        if (w.ok(m)) L[Q_X + w.e(m)] = Qs[m];
     CVXW_SYNC();
     double tr = 0;
 #pragma unroll
@@ -413,7 +440,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Op
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         Qs[m] *= itr;
-        if (w.ok[m] && w.ej[m] < 9) { L[Q_QF + w.ei[m] * 10 + w.ej[m]] = Qs[m]; L[Q_QF + w.ej[m] * 10 + w.ei[m]] = Qs[m]; }
+        if (w.ok(m) && w.ej(m) < 9) { L[Q_QF + w.ei(m) * 10 + w.ej(m)] = Qs[m]; L[Q_QF + w.ej(m) * 10 + w.ei(m)] = Qs[m]; }
     }
     if (gl < 9) L[Q_QF + gl * 10 + 9] = 0.0;
     // planar scene: the cost is blind to the third column of R (cvx::dual_certificate, SYMM)
@@ -421,12 +448,12 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Op
     {
         bool zero = true;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) zero = zero && !(w.ok[m] && w.ej[m] >= 6 && w.ej[m] < 9 && !(fabs(Qs[m]) < 1e-13));
+        for (int m = 0; m < 4; ++m) zero = zero && !(w.ok(m) && w.ej(m) >= 6 && w.ej(m) < 9 && !(fabs(Qs[m]) < 1e-13));
         symm = grp_bits(__ballot(!zero), grp) == 0;
     }
     bool odd[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) odd[m] = symm && ((w.ei[m] < 6) != (w.ej[m] < 6));
+    for (int m = 0; m < 4; ++m) odd[m] = symm && ((w.ei(m) < 6) != (w.ej(m) < 6));
 
 #ifdef CVXQ_TIMELINE
     tl_[1] = tl_now();
@@ -438,7 +465,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Op
     double rho = o.rho, irho = 1.0 / o.rho;
     double W[4], Wp[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) { W[m] = (w.e[m] == 54) ? 1.0 : 0.0; Wp[m] = W[m]; }
+    for (int m = 0; m < 4; ++m) { W[m] = (w.e(m) == 54) ? 1.0 : 0.0; Wp[m] = W[m]; }
     double v[10]; // unit eigenvector owned by this lane (warm start of the next eigen-solve)
 #pragma unroll
     for (int i = 0; i < 10; ++i) v[i] = (gl == i) ? 1.0 : 0.0;
@@ -457,7 +484,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Op
         // finishing them here, four in a row per wavefront, was 1.6x slower on a planar batch.
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-            if (w.ok[m]) ws[b * 56 + w.e[m]] = W[m];
+            if (w.ok(m)) ws[b * 56 + w.e(m)] = W[m];
         if (gl == 0) {
             ws[b * 56 + 55] = 0.0;
             const int q = atomicAdd(qcount, 1);
@@ -478,21 +505,22 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Op
         if (a.Z) {
 #pragma unroll
             for (int m = 0; m < 4; ++m)
-                if (w.ok[m]) a.Z[b * 55 + w.e[m]] = NAN;
+                if (w.ok(m)) a.Z[b * 55 + w.e(m)] = NAN;
         }
     }
 
     while (__any(!done)) {
+        w.refresh();
         double al = 0.0, sigma = 0.0;
         if (!(it == 0 && o.first_check > 1)) {
             // ---- eigendecomposition of W: one-sided Jacobi on G = (W + sigma I) V_prev, column gl in this lane
             double fro = 0.0;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) fro += w.wgt[m] * W[m] * W[m];
+            for (int m = 0; m < 4; ++m) fro += w.wgt(m) * W[m] * W[m];
             sigma = 1.5 * cvx::sqrt_fast(row_sum(fro)) + 1e-300;
 #pragma unroll
             for (int m = 0; m < 4; ++m)
-                if (w.ok[m]) { L[Q_WF + w.ei[m] * 10 + w.ej[m]] = W[m]; L[Q_WF + w.ej[m] * 10 + w.ei[m]] = W[m]; }
+                if (w.ok(m)) { L[Q_WF + w.ei(m) * 10 + w.ej(m)] = W[m]; L[Q_WF + w.ej(m) * 10 + w.ei(m)] = W[m]; }
             CVXW_SYNC();
             double g[10];
 #pragma unroll
@@ -557,7 +585,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Op
                 if ((anypos >> s) & 1u) { // wave-uniform; a column with no weight in THIS problem adds 0
                     const double ws_ = L[Q_Y + 100 + s];
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) Wp[m] += ws_ * L[Q_Y + s * 10 + w.ei[m]] * L[Q_Y + s * 10 + w.ej[m]];
+                    for (int m = 0; m < 4; ++m) Wp[m] += ws_ * L[Q_Y + s * 10 + w.ei(m)] * L[Q_Y + s * 10 + w.ej(m)];
                 }
             }
         }
@@ -714,12 +742,12 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Op
             {
                 double T[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) { S[m] = rho * (Wp[m] - W[m]); T[m] = S[m] - (w.ej[m] < 9 ? L[Q_QF + w.ei[m] * 10 + w.ej[m]] : 0.0); }
+                for (int m = 0; m < 4; ++m) { S[m] = rho * (Wp[m] - W[m]); T[m] = S[m] - (w.ej(m) < 9 ? L[Q_QF + w.ei(m) * 10 + w.ej(m)] : 0.0); }
                 quad_proj(L, w, T, 0.0);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     S[m] = odd[m] ? 0.0 : S[m] - T[m];
-                    if (w.ok[m]) { L[Q_WF + w.ei[m] * 10 + w.ej[m]] = S[m]; L[Q_WF + w.ej[m] * 10 + w.ei[m]] = S[m]; }
+                    if (w.ok(m)) { L[Q_WF + w.ei(m) * 10 + w.ej(m)] = S[m]; L[Q_WF + w.ej(m) * 10 + w.ei(m)] = S[m]; }
                 }
             }
             CVXW_SYNC();
@@ -740,14 +768,14 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Op
                 double E[4], Nn[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    E[m] = odd[m] ? 0.0 : 0.5 * (L[C_LAM + w.ei[m]] * L[C_XV + w.ej[m]] + L[C_XV + w.ei[m]] * L[C_LAM + w.ej[m]]);
+                    E[m] = odd[m] ? 0.0 : 0.5 * (L[C_LAM + w.ei(m)] * L[C_XV + w.ej(m)] + L[C_XV + w.ei(m)] * L[C_LAM + w.ej(m)]);
                     Nn[m] = E[m];
                 }
                 quad_proj(L, w, Nn, 0.0);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     S[m] -= E[m] - Nn[m];
-                    if (w.ok[m]) { L[Q_WF + w.ei[m] * 10 + w.ej[m]] = S[m]; L[Q_WF + w.ej[m] * 10 + w.ei[m]] = S[m]; }
+                    if (w.ok(m)) { L[Q_WF + w.ei(m) * 10 + w.ej(m)] = S[m]; L[Q_WF + w.ej(m) * 10 + w.ei(m)] = S[m]; }
                 }
             }
             CVXW_SYNC();
@@ -793,7 +821,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Op
                 if (a.Z) { // Z = z z^T with z = [vec_colmajor(R); 1]
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
-                        if (w.ok[m]) a.Z[b * 55 + w.e[m]] = L[C_XV + w.ei[m]] * L[C_XV + w.ej[m]];
+                        if (w.ok(m)) a.Z[b * 55 + w.e(m)] = L[C_XV + w.ei(m)] * L[C_XV + w.ej(m)];
                 }
                 done = true;
             }
@@ -807,14 +835,14 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Op
         {
             double X[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) X[m] = 2.0 * Wp[m] - W[m] - irho * (w.ej[m] < 9 ? L[Q_QF + w.ei[m] * 10 + w.ej[m]] : 0.0); // (the cost entries stay in LDS: 8 registers less to carry through the loop)
+            for (int m = 0; m < 4; ++m) X[m] = 2.0 * Wp[m] - W[m] - irho * (w.ej(m) < 9 ? L[Q_QF + w.ei(m) * 10 + w.ej(m)] : 0.0); // (the cost entries stay in LDS: 8 registers less to carry through the loop)
             quad_proj(L, w, X, 1.0);
             double r2 = 0.0;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const double dd = X[m] - Wp[m];
                 W[m] += o.alpha * dd;
-                r2 += w.wgt[m] * dd * dd;
+                r2 += w.wgt(m) * dd * dd;
             }
             const double fp_res = cvx::sqrt_fast(row_sum(r2));
             if (!done && !(fp_res == fp_res)) { // NaN guard
@@ -829,7 +857,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Op
                 if (a.Z) {
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
-                        if (w.ok[m]) a.Z[b * 55 + w.e[m]] = NAN;
+                        if (w.ok(m)) a.Z[b * 55 + w.e(m)] = NAN;
                 }
                 done = true;
             }
@@ -839,7 +867,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Op
             if (!done) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
-                    if (w.ok[m]) park(ws + b * 56 + w.e[m], W[m]);
+                    if (w.ok(m)) park(ws + b * 56 + w.e(m), W[m]);
                 if (gl == 0) park(ws + b * 56 + 55, (double)it);
                 parked = true;
             }
@@ -857,11 +885,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(WaveArgs a, cvx::Op
     if (pmask) { // wave-uniform
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // every park() acknowledged before the iterate is read back
         CVXW_SYNC();
-        // copies made HERE: taking the address of the kernel's own a / o would make every wavefront of the grid
-        // spill them to its scratch frame at kernel entry (190 B per lane, 30 MB per 10 k launch)
-        const WaveArgs a2 = a;
-        const cvx::Opts o2 = o;
-        finish_own(a2, o2, pmask, ws, lds_all);
+        finish_own((QuadArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), pmask, lds_all);
     }
 #ifdef CVXQ_TIMELINE
     tl_[3] = tl_now();

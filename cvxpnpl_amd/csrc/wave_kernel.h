@@ -1190,19 +1190,47 @@ __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx
 // that a failed launch or a hipGraph replay could desynchronise -- and every index is range checked, so a
 // corrupted workspace cannot turn into an out-of-bounds write.  entries[] has RESUME_GRID_MAX spare slots.
 constexpr int RESUME_GRID_MAX = 8192;
-__global__ void __launch_bounds__(64 * WPB, 2) resume_wave_kernel(WaveArgs a, cvx::Opts o, int32_t *count_p, int32_t *entries, const double *ws)
+// The kernel proper is a thin shell: a block whose first queue slot is empty (every block of most launches) leaves
+// after one load, before the solver's register allocation could cost it a single spill store -- the body is a separate,
+// non-inlined function (with the queue walk inlined into the shell the 8192 mostly idle wavefronts of a launch wrote
+// 126 MB of spilled registers at kernel entry).
+struct ResumeArgs {
+    WaveArgs a;
+    cvx::Opts o;
+    int32_t *count_p, *entries;
+    const double *ws;
+};
+typedef const __attribute__((address_space(4))) ResumeArgs *ResumeArgsPtr;
+
+__device__ __noinline__ void resume_body(ResumeArgsPtr kp, int32_t first, double *lds)
 {
-    __shared__ __attribute__((aligned(16))) double lds_all[WPB][LDSW];
-    const int wib = threadIdx.x >> 6;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *count_p = 0;
-    for (int64_t q = (int64_t)blockIdx.x * WPB + wib; q < a.batch + RESUME_GRID_MAX; q += (int64_t)gridDim.x * WPB) { // wave-uniform
-        const int32_t b = entries[q];
-        if (b < 0) break;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const WaveArgs a = kp->a;
+    const cvx::Opts o = kp->o;
+    int32_t *entries = kp->entries;
+    const double *ws = kp->ws;
+    int32_t b = first;
+    for (int64_t q = blockIdx.x;;) { // wave-uniform
         if ((threadIdx.x & 63) == 0) entries[q] = -1;
-        if (b >= a.batch) continue;
-        solve_one_wave(a, o, b, lds_all[wib], ws + (int64_t)b * 56);
-        CVXW_SYNC();
+        if (b < a.batch) {
+            solve_one_wave(a, o, b, lds, ws + (int64_t)b * 56);
+            CVXW_SYNC();
+        }
+        q += gridDim.x;
+        if (q >= a.batch + RESUME_GRID_MAX) break;
+        b = entries[q];
+        if (b < 0) break;
     }
+#endif
+}
+
+__global__ void __launch_bounds__(64, 2) resume_wave_kernel(ResumeArgs k)
+{
+    __shared__ __attribute__((aligned(16))) double lds_all[LDSW];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *k.count_p = 0;
+    const int32_t first = k.entries[blockIdx.x];
+    if (first < 0) return;
+    resume_body((ResumeArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), first, lds_all);
 }
 
 } // namespace cvxw
