@@ -1190,10 +1190,11 @@ __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx
 // that a failed launch or a hipGraph replay could desynchronise -- and every index is range checked, so a
 // corrupted workspace cannot turn into an out-of-bounds write.  entries[] has RESUME_GRID_MAX spare slots.
 constexpr int RESUME_GRID_MAX = 8192;
-// The kernel proper is a thin shell: a block whose first queue slot is empty (every block of most launches) leaves
-// after one load, before the solver's register allocation could cost it a single spill store -- the body is a separate,
-// non-inlined function (with the queue walk inlined into the shell the 8192 mostly idle wavefronts of a launch wrote
-// 126 MB of spilled registers at kernel entry).
+// A block whose first queue slot is empty (every block of most launches) leaves after one load: the arguments of the
+// solve are read from the kernarg segment only behind that test, so that nothing is live -- and nothing spilled -- before
+// it (with by-value arguments the 8192 mostly idle wavefronts of a launch wrote 126 MB of spilled registers at kernel
+// entry; as a separate non-inlined function the body paid the calling convention instead: ~185 register saves and
+// restores per call, 0.8 GB per 125 k launch).
 struct ResumeArgs {
     WaveArgs a;
     cvx::Opts o;
@@ -1202,7 +1203,7 @@ struct ResumeArgs {
 };
 typedef const __attribute__((address_space(4))) ResumeArgs *ResumeArgsPtr;
 
-__device__ __noinline__ void resume_body(ResumeArgsPtr kp, int32_t first, double *lds)
+__device__ __forceinline__ void resume_body(ResumeArgsPtr kp, int32_t first, double *lds)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     const WaveArgs a = kp->a;
