@@ -258,7 +258,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     w.Q45 = a.Q45; w.B27 = a.B27;
     int quad_iters = opts ? opts->lane_iters : -1;
     if (quad_iters <= 0) quad_iters = 10; // measured optimum 8-12 at every launch size (tools/quad_tune.sh)
-    if (layout == 9 || layout == 8) layout = CVXPNPL_LAYOUT_QUAD; // experiment: quad iterations only (solve_quad_kernel<1>)
+    if (layout == 9) layout = CVXPNPL_LAYOUT_QUAD; // experiment (tools/README.md): quad iterations only, 3 waves/SIMD: quad iterations only (solve_quad_kernel<1>)
     if (layout == CVXPNPL_LAYOUT_QUAD && !(quad_iters >= 1 && o.max_iters > quad_iters)) layout = CVXPNPL_LAYOUT_WAVE;
     if (layout == CVXPNPL_LAYOUT_QUAD) {
         // four problems per wavefront for the first quad_iters iterations, survivors resumed one per wavefront
@@ -273,7 +273,6 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
         cvxq::QuadArgs qa;
         qa.a = w; qa.o = o; qa.handoff_at = quad_iters; qa.qcount = count; qa.qentries = entries; qa.ws = ws;
         if (opts && opts->layout == 9) hipLaunchKernelGGL((cvxq::solve_quad_kernel<1, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // experiment
-        else if (opts && opts->layout == 8) hipLaunchKernelGGL((cvxq::solve_quad_kernel<1, 4>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // experiment
         else hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         const int64_t rgrid = batch < cvxw::RESUME_GRID_MAX ? batch : cvxw::RESUME_GRID_MAX;
         launch_resume(rgrid, s, w, o, count, entries, ws);

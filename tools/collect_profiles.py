@@ -13,7 +13,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
-WORKLOAD_KEY = {"default": "pnp_n10_10k:10000", "quad_24k": "pnp_n10_10k:24000", "hybrid_125k": "pnp_n10_125k:125000"}
+WORKLOAD_KEY = {"default": "pnp_n10_10k:10000", "quad_24k": "pnp_n10_10k:24000", "hybrid_125k": "pnp_n10_125k:125000", "large_n": "pnp_n10000_1k:1000"}
 
 
 def counters(run):
@@ -39,7 +39,7 @@ def counters(run):
 
 
 traffic = {}
-for run in ("default", "quad_24k", "hybrid_125k"):
+for run in ("default", "quad_24k", "hybrid_125k", "large_n"):
     if not os.path.isdir(os.path.join(src, run)):
         continue
     os.makedirs(os.path.join(dst, run), exist_ok=True)

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for one round on the GPU box (run from the repo root):
-#   tools/profile_round.sh r01
+#   tools/profile_round.sh r02
 # Writes gpurun_out/<tag>/ ; `python tools/collect_profiles.py <tag>` (container) then condenses it into
 # profiles/<tag>/ and profiles/pmc_traffic.json.  Counter passes are separate runs with no tracing
 # (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950, MI355X guide).
-tag=${1:-r01}
+tag=${1:-r02}
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/$tag
 rm -rf $out; mkdir -p $out
@@ -12,27 +12,29 @@ export TMPDIR=/tmp
 cd /tmp
 prof() { # name, bench args...
   name=$1; shift
-  CMD="python $root/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-overlap $@"
+  CMD="python $root/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-overlap --pmc off $@"
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name/trace -o trace -- $CMD > $out/$name.trace.log 2>&1
-  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/$name/pmc_fetch -o fetch -- $CMD > $out/$name.fetch.log 2>&1
-  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/$name/pmc_write -o write -- $CMD > $out/$name.write.log 2>&1
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/$name/pmc_fetch -o fetch -- $CMD --pmc-child > $out/$name.fetch.log 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/$name/pmc_write -o write -- $CMD --pmc-child > $out/$name.write.log 2>&1
   timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $out/$name/pmc_sq -o sq -- $CMD > $out/$name.sq.log 2>&1
   timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --output-format csv -d $out/$name/pmc_sq2 -o sq2 -- $CMD > $out/$name.sq2.log 2>&1
 }
 prof default
 prof quad_24k --batch 24000
 prof hybrid_125k --workload pnp_n10_125k
+prof large_n --workload pnp_n10000_1k
 cd $root
-# condense the counter passes first, so that the bench lines below quote this build's traffic (profiles/pmc_traffic.json)
-python tools/collect_profiles.py $tag > /dev/null 2>&1
-# bench lines of the same build (full default run incl. cpu_baseline; the other configurations without)
+# bench lines of the same build (full default run incl. both CPU baselines and the in-run PMC passes)
 python bench.py > $out/bench_default.json 2> $out/bench_default.err
 python bench.py --batch 24000 --no-cpu-baseline > $out/bench_quad_24k.json 2>/dev/null
 python bench.py --workload pnp_n10_125k --no-cpu-baseline > $out/bench_125k.json 2>/dev/null
 python bench.py --workload pnpl_5p5l_100k --no-cpu-baseline > $out/bench_pnpl_100k.json 2>/dev/null
-python bench.py --workload pnp_n10_125k --batch 1000000 --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_1m.json 2>/dev/null
+python bench.py --workload pnp_n10000_1k --steps 20 > $out/bench_n10000_1k.json 2>/dev/null
+python bench.py --workload pnp_n10_125k --batch 1000000 --steps 10 --warmup 2 --no-cpu-baseline --pmc off > $out/bench_1m.json 2>/dev/null
+python bench.py --gpus 2 --steps 20 --warmup 3 > $out/bench_2ranks_one_device.json 2>/dev/null
 python tools/config5_sweep.py > $out/config5_sweep.jsonl 2>/dev/null
 python tools/planar_timing.py > $out/planar_timing.jsonl 2>/dev/null
-python tools/planar_general.py > $out/planar_general.txt 2>/dev/null
+python tools/iters_hist.py config5 2500 > $out/iters_config5.json 2>/dev/null
 tools/layout_sweep.sh > $out/layout_sweep.txt 2>/dev/null
+CVXPNPL_AMD_LIB=$root/cvxpnpl_amd/libcvxpnpl_timeline.so python tools/timeline.py 10000 > $out/timeline_10k.json 2>/dev/null
 ls $out
