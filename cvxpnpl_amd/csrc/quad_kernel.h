@@ -276,7 +276,8 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
     const int64_t b = gvalid ? b_raw : a.batch - 1; // surplus rows redo the last problem, outputs suppressed
 #ifdef CVXQ_TIMELINE // diagnostics build (tools/timeline.py): shader-clock stamps of this wavefront, written over cost[] at the end
     unsigned long long tl_[4];
-    auto tl_now = []() { unsigned long long t; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory"); return t; };
+    // s_memrealtime: the 100 MHz reference clock, one time base for the whole device (s_memtime runs per XCD / SE)
+    auto tl_now = []() { unsigned long long t; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory"); return t; };
     tl_[0] = tl_now();
 #endif
 

@@ -28,11 +28,9 @@ nw = (batch + 3) // 4
 T = np.stack([c[8 * i: 8 * i + 4] for i in range(nw) if 8 * i + 4 <= len(c)])
 its = np.array([w[8 * i + 1] for i in range(len(T))])
 hw = np.array([w[8 * i] for i in range(len(T))]).astype(np.uint32)
-# every XCD has a clock of its own: times are taken relative to the first wave start on the same XCD
 xcc = np.array([w[8 * i + 2] for i in range(len(T))]).astype(np.int64)
-for x in np.unique(xcc):
-    T[xcc == x] -= T[xcc == x, 0].min()
-clk = float(os.environ.get("CVX_SCLK_HZ", "2.4e9"))  # s_memtime ticks at the shader clock (MI355X guide)
+T -= T[:, 0].min()
+clk = 100e6  # s_memrealtime: the 100 MHz reference clock, common to the whole device
 us = T / clk * 1e6
 out = {"batch": batch, "waves": len(T), "span_us": float(us[:, 3].max()),
        "start_us_pct": {str(p): float(np.percentile(us[:, 0], p)) for p in (1, 25, 50, 75, 90, 99, 100)},
@@ -40,7 +38,8 @@ out = {"batch": batch, "waves": len(T), "span_us": float(us[:, 3].max()),
        "dur_us_pct": {str(p): float(np.percentile(us[:, 3] - us[:, 0], p)) for p in (1, 25, 50, 75, 90, 99, 100)},
        "assembly_us_median": float(np.median(us[:, 1] - us[:, 0])), "quadloop_us_median": float(np.median(us[:, 2] - us[:, 1])),
        "tail_us_max": float((us[:, 3] - us[:, 2]).max()), "n_with_tail": int(((us[:, 3] - us[:, 2]) > 1.0).sum()),
-       "iters_hist": np.bincount(its.clip(0, 20)).tolist()}
+       "iters_hist": np.bincount(its.clip(0, 20)).tolist(),
+       "slowest_waves": [{"block": int(i), "start": float(us[i, 0]), "quad_end": float(us[i, 2]), "end": float(us[i, 3]), "it": int(its[i])} for i in np.argsort(-us[:, 3])[:12]]}
 # resident waves over time
 grid = np.linspace(0, us[:, 3].max(), 41)
 out["resident_waves"] = [int(((us[:, 0] <= g) & (us[:, 3] > g)).sum()) for g in grid]
