@@ -203,7 +203,7 @@ CVX_HD void polar3(const double *M, double *R, int iters)
                 dl += (Y[i * 3 + j] - X[i * 3 + j]) * (Y[i * 3 + j] - X[i * 3 + j]);
             }
         CVX_UNROLL for (int i = 0; i < 9; ++i) X[i] = Y[i];
-        if (dl < 1e-30) break; // converged (quadratic: the next step would not change X)
+        if (dl < 1e-22) break; // converged: |dX| < 1e-11 and quadratic convergence put the next step at rounding level
     }
     CVX_UNROLL for (int i = 0; i < 9; ++i) R[i] = X[i];
 }

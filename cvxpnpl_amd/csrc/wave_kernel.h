@@ -1189,7 +1189,7 @@ __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx
 // So every launch leaves the queue as it found it -- no host-side bookkeeping, no memset per launch, nothing
 // that a failed launch or a hipGraph replay could desynchronise -- and every index is range checked, so a
 // corrupted workspace cannot turn into an out-of-bounds write.  entries[] has RESUME_GRID_MAX spare slots.
-constexpr int RESUME_GRID_MAX = 8192;
+constexpr int RESUME_GRID_MAX = 2048; // one block per resident wavefront slot: more blocks only add launch time to the (usual) empty-queue case
 // A block whose first queue slot is empty (every block of most launches) leaves after one load: the arguments of the
 // solve are read from the kernarg segment only behind that test, so that nothing is live -- and nothing spilled -- before
 // it (with by-value arguments the 8192 mostly idle wavefronts of a launch wrote 126 MB of spilled registers at kernel
