@@ -37,10 +37,20 @@ CVX_HD bool assemble(const ProblemView &v, double *B, double *Q9)
     inv3(Kc, Ki, det);
     Gram g;
     gram_zero(g);
+    // The sums are taken about the problem's first 3D point c (P' = P - c): the cost r^T Q r is invariant under that
+    // shift (the translation absorbs R c) and t = -B' r - R c, i.e. B[i][3j+i] += c_j.  Exact, and the Gram difference
+    // C^T C - (N^T C)^T B no longer cancels |c|^2 / spread^2 digits when the world origin is far from the scene.
+    const double *c0 = v.n_p ? v.p3 : v.l3;
+    const double c[3] = {c0[0], c0[1], c0[2]};
     for (int i = 0; i < v.n_p; ++i)
-        gram_add_point(g, Ki, v.p2[2 * i], v.p2[2 * i + 1], v.p3[3 * i], v.p3[3 * i + 1], v.p3[3 * i + 2]);
-    for (int i = 0; i < v.n_l; ++i) gram_add_line(g, Ki, v.l2 + 4 * i, v.l3 + 6 * i);
+        gram_add_point(g, Ki, v.p2[2 * i], v.p2[2 * i + 1], v.p3[3 * i] - c[0], v.p3[3 * i + 1] - c[1], v.p3[3 * i + 2] - c[2]);
+    for (int i = 0; i < v.n_l; ++i) {
+        const double *e = v.l3 + 6 * i;
+        const double l3s[6] = {e[0] - c[0], e[1] - c[1], e[2] - c[2], e[3] - c[0], e[4] - c[1], e[5] - c[2]};
+        gram_add_line(g, Ki, v.l2 + 4 * i, l3s);
+    }
     bool ok = gram_finish(g, B, Q9);
+    CVX_UNROLL for (int i = 0; i < 3; ++i) CVX_UNROLL for (int j = 0; j < 3; ++j) B[i * 9 + 3 * j + i] += c[j];
     return ok && (det == det) && det != 0.0;
 }
 

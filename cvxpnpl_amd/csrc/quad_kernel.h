@@ -328,6 +328,9 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
             rqa[m] = 6 + qa; rqb[m] = 6 + qb; rte[m] = te;
         }
         const int nrec = pv.n_p + 2 * pv.n_l;
+        // sums about the problem's first 3D point (cvx::assemble: exact, and well conditioned far from the world origin)
+        const double *c0p = pv.n_p ? pv.p3 : pv.l3;
+        const double cs0 = c0p[0], cs1 = c0p[1], cs2 = c0p[2];
         for (int base = 0; base < nrec; base += 16) {
             const int cnt = nrec - base < 16 ? nrec - base : 16;
             if (gl < cnt) {
@@ -339,7 +342,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
                     const double n2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
                     T[0] = n2 - p[0] * p[0]; T[1] = -p[0] * p[1]; T[2] = -p[0] * p[2];
                     T[3] = n2 - p[1] * p[1]; T[4] = -p[1] * p[2]; T[5] = n2 - p[2] * p[2];
-                    P[0] = pv.p3[3 * r]; P[1] = pv.p3[3 * r + 1]; P[2] = pv.p3[3 * r + 2];
+                    P[0] = pv.p3[3 * r] - cs0; P[1] = pv.p3[3 * r + 1] - cs1; P[2] = pv.p3[3 * r + 2] - cs2;
                 } else {
                     const int li = (r - pv.n_p) >> 1, en = (r - pv.n_p) & 1;
                     const double *l2 = pv.l2 + 4 * li, *l3 = pv.l3 + 6 * li + 3 * en;
@@ -350,7 +353,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
                     const double inv = cvx::rsqrt_(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
                     n[0] *= inv; n[1] *= inv; n[2] *= inv;
                     T[0] = n[0] * n[0]; T[1] = n[0] * n[1]; T[2] = n[0] * n[2]; T[3] = n[1] * n[1]; T[4] = n[1] * n[2]; T[5] = n[2] * n[2];
-                    P[0] = l3[0]; P[1] = l3[1]; P[2] = l3[2];
+                    P[0] = l3[0] - cs0; P[1] = l3[1] - cs1; P[2] = l3[2] - cs2;
                 }
                 double *rec = L + Q_WF + gl * 10;
 #pragma unroll
@@ -395,7 +398,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
                 double v = 0;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) v += L[Q_X + i * 3 + k] * m1[psym(k, j)];
-                L[Q_B + i * 9 + 3 * bb + j] = v; // B[i][3 bb + j]
+                L[Q_B + i * 9 + 3 * bb + j] = v; // B'[i][3 bb + j] (about the shifted origin)
             }
         }
         CVXW_SYNC();
@@ -411,6 +414,8 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
             }
             Qs[m] = v;
         }
+        CVXW_SYNC(); // (every read of B' for Q is done: the shift goes back into B, t = -B' r - R c)
+        if (gl < 9) L[Q_B + (gl / 3) * 9 + 3 * (gl % 3) + gl / 3] += (gl % 3 == 0 ? cs0 : (gl % 3 == 1 ? cs1 : cs2));
     }
     CVXW_SYNC();
 #pragma unroll

@@ -537,6 +537,9 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
             q[0] = l2[0]; q[1] = l2[1]; q[2] = l2[2]; q[3] = l2[3];
             q[4] = l3[0]; q[5] = l3[1]; q[6] = l3[2];
         };
+        // sums about the problem's first 3D point (cvx::assemble: exact, and well conditioned far from the world origin)
+        const double *c0p = pv.n_p ? pv.p3 : pv.l3;
+        const double cs0 = c0p[0], cs1 = c0p[1], cs2 = c0p[2];
         double rawp[5] = {0, 0, 0, 0, 0}, rawl[7] = {0, 0, 0, 0, 0, 0, 0};
         {
             const int cnt0 = nrec < CHUNK ? nrec : CHUNK;
@@ -578,7 +581,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
                     double n2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
                     T[0] = n2 - p[0] * p[0]; T[1] = -p[0] * p[1]; T[2] = -p[0] * p[2];
                     T[3] = n2 - p[1] * p[1]; T[4] = -p[1] * p[2]; T[5] = n2 - p[2] * p[2];
-                    P[0] = rawp[2]; P[1] = rawp[3]; P[2] = rawp[4];
+                    P[0] = rawp[2] - cs0; P[1] = rawp[3] - cs1; P[2] = rawp[4] - cs2;
                 } else {
                     if (base > 0) load_line(r, rawl);
                     double u[3], v[3];
@@ -588,7 +591,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
                     double inv = cvx::rsqrt_(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
                     n[0] *= inv; n[1] *= inv; n[2] *= inv;
                     T[0] = n[0] * n[0]; T[1] = n[0] * n[1]; T[2] = n[0] * n[2]; T[3] = n[1] * n[1]; T[4] = n[1] * n[2]; T[5] = n[2] * n[2];
-                    P[0] = rawl[4]; P[1] = rawl[5]; P[2] = rawl[6];
+                    P[0] = rawl[4] - cs0; P[1] = rawl[5] - cs1; P[2] = rawl[6] - cs2;
                 }
                 double *rec = L + L_EX + lane * 10;
     #pragma unroll
@@ -625,7 +628,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
             double v = 0;
     #pragma unroll
             for (int k = 0; k < 3; ++k) v += L[L_X + i * 3 + k] * m1[psym(k, j)];
-            L[L_B + i * 9 + 3 * bb + j] = v; // B[i][3 bb + j]
+            L[L_B + i * 9 + 3 * bb + j] = v; // B'[i][3 bb + j] (about the shifted origin; the shift goes in once Q is formed)
         }
         CVXW_SYNC();
         if (ej < 9) {
@@ -636,6 +639,8 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
             for (int k = 0; k < 3; ++k) v -= m1[psym(qi, k)] * L[L_B + k * 9 + 3 * qb + qj];
             Qe = v;
         }
+        CVXW_SYNC(); // (every read of B' for Q is done)
+        if (lane < 9) L[L_B + (lane / 3) * 9 + 3 * (lane % 3) + lane / 3] += (lane % 3 == 0 ? cs0 : (lane % 3 == 1 ? cs1 : cs2)); // t = -B' r - R c
     }
     L[L_X + el] = Qe;
     CVXW_SYNC();

@@ -283,3 +283,34 @@ def test_pose_reuse_does_not_go_stale(n_p, n_l, sigma, seed, i):
                             d["line_3d"][sl] if n_l else None, d["K"])
     assert r["status"][0] == 0 and r["iters"][0] < 60
     assert 0 <= r["cost"][0, 0] - r["cost"][0, 1] <= 1e-9
+
+
+def test_assembly_far_from_the_world_origin(orc):
+    """Advisor finding (round 1): the Gram difference C^T C - (N^T C)^T B loses |P|^2 / spread^2 digits when the world
+    origin is far from the scene.  The sums are now taken about the problem's first 3D point (exact: the shift goes back
+    into B): Q and B against the reference's explicit A = C - N B (cvxpnpl.py:545-549) with the origin 1e3 scene sizes
+    away, and the certified pose against the oracle."""
+    import hostsim
+    from cvxpnpl_amd import synth
+
+    d = synth.make_pnpl(12, 6, 3, 0.5, seed=17)
+    c = np.random.RandomState(2).normal(size=(12, 1, 3)) * 600.0
+    d["pts_3d"] = d["pts_3d"] + c
+    d["line_3d"] = d["line_3d"] + c[:, None]
+    worst_q = worst_b = 0.0
+    for i in range(12):
+        (c1, c2, c3), (n1, n2, n3) = orc.point_constraints(d["pts_2d"][i], d["pts_3d"][i], d["K"])
+        cl, nl = orc.line_constraints(d["line_2d"][i], d["line_3d"][i], d["K"])
+        B, A = orc.eliminate(np.vstack((c1, c2, c3, cl)), np.vstack((n1, n2, n3, nl)))
+        rc, Bh, Qh = hostsim.assemble(d["pts_2d"][i], d["pts_3d"][i], d["line_2d"][i], d["line_3d"][i], d["K"])
+        assert rc == 0
+        Q = A.T @ A
+        worst_q = max(worst_q, np.abs(Qh - Q).max() / np.abs(Q).max())
+        worst_b = max(worst_b, np.abs(Bh - B).max() / np.abs(B).max())
+    # (the reference's own A^T A carries the cancellation of C - N B at this offset: ~1e-10 relative)
+    assert worst_q < 1e-8 and worst_b < 1e-9, (worst_q, worst_b)
+    h = hostsim.solve_batch(d["pts_2d"], d["pts_3d"], d["line_2d"], d["line_3d"], d["K"])
+    o = orc.pnpl_batch(d["pts_2d"], d["line_2d"], d["pts_3d"], d["line_3d"], d["K"], eps=1e-11, max_iters=200000)
+    ok = (h["status"] == 0) & (o["n_poses"] == 1)
+    assert ok.sum() >= 10
+    assert synth.geodesic(h["R"], o["R"][:, 0])[ok].max() < 1e-6
