@@ -94,31 +94,19 @@ __global__ void __launch_bounds__(64) assemble_kernel(BatchArgs a, double *Bout,
 // cvxpnpl_release_workspace) or memory the caller registered with cvxpnpl_set_workspace (e.g. from torch's
 // caching allocator).  The queue is self-cleaning (cvxw::resume_wave_kernel): it is initialised once.
 // Offsets depend on the CAPACITY (problems) of the allocation, not on the batch of a launch, so that launches of
-// different sizes agree on where the queue ends and the iterates begin.
-struct Workspace { void *ptr = nullptr; size_t bytes = 0; int64_t cap = 0; bool owned = true; };
+// different sizes agree on where the queue ends and the iterates begin.  The parked region is sized for the slot stride
+// of the schedule that asked for the most (lane: 56 doubles per problem, quad: 240).
+struct Workspace { void *ptr = nullptr; size_t bytes = 0; int64_t cap = 0; size_t parked_bytes = 0; bool owned = true; };
 std::mutex g_ws_mutex;
 std::map<std::pair<int, void *>, Workspace> g_ws;
 thread_local char g_err[512] = "";
 
-void launch_wave(int64_t wgrid, hipStream_t s, const cvxw::WaveArgs &w, const cvx::Opts &o)
-{
-    if (o.variant == cvx::VAR_RC) hipLaunchKernelGGL(cvxw::solve_wave_kernel<cvx::VAR_RC>, dim3((unsigned)wgrid), dim3(64 * cvxw::WPB), 0, s, w, o);
-    else hipLaunchKernelGGL(cvxw::solve_wave_kernel<cvx::VAR_FULL>, dim3((unsigned)wgrid), dim3(64 * cvxw::WPB), 0, s, w, o);
-}
-
-void launch_resume(int64_t rgrid, hipStream_t s, const cvxw::WaveArgs &w, const cvx::Opts &o, int32_t *count, int32_t *entries, const double *ws)
-{
-    cvxw::ResumeArgs ra;
-    ra.a = w; ra.o = o; ra.count_p = count; ra.entries = entries; ra.ws = ws;
-    hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64), 0, s, ra);
-}
-
 size_t hybrid_queue_bytes(int64_t cap) { return 256 + (((size_t)(cap + cvxw::RESUME_GRID_MAX) * sizeof(int32_t) + 255) & ~(size_t)255); }
-size_t hybrid_ws_bytes(int64_t cap) { return hybrid_queue_bytes(cap) + (size_t)cap * 56 * sizeof(double); }
-int64_t hybrid_capacity(size_t bytes) // largest capacity whose layout fits
+size_t hybrid_ws_bytes(int64_t cap) { return hybrid_queue_bytes(cap) + (size_t)cap * cvxw::RS_FULL * sizeof(double); } // any schedule
+int64_t hybrid_capacity(size_t bytes) // largest capacity whose layout fits (any schedule)
 {
     if (bytes < hybrid_ws_bytes(1)) return 0;
-    int64_t cap = (int64_t)(bytes / (sizeof(int32_t) + 56 * sizeof(double))) + 1; // an upper bound, then down to the first fit
+    int64_t cap = (int64_t)(bytes / (sizeof(int32_t) + cvxw::RS_FULL * sizeof(double))) + 1; // an upper bound, then down to the first fit
     while (cap > 0 && hybrid_ws_bytes(cap) > bytes) --cap;
     return cap;
 }
@@ -132,33 +120,50 @@ bool init_workspace(void *p, int64_t cap, void *stream)
 
 struct WsView { int32_t *count, *entries; double *parked; };
 
-bool get_workspace(int64_t batch, void *stream, WsView &v)
+bool get_workspace(int64_t batch, int stride, void *stream, WsView &v)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { snprintf(g_err, sizeof(g_err), "cvxpnpl: hipGetDevice failed"); return false; }
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     Workspace &w = g_ws[std::make_pair(dev, stream)];
-    if (w.cap < batch) {
+    const size_t need_parked = (size_t)batch * stride * sizeof(double);
+    if (w.cap < batch || w.parked_bytes < need_parked) {
         if (!w.owned) {
             snprintf(g_err, sizeof(g_err), "cvxpnpl: the registered workspace holds %lld problems, the launch has %lld (cvxpnpl_workspace_bytes)",
                      (long long)w.cap, (long long)batch);
             return false;
         }
+        const int64_t cap = w.cap > batch ? w.cap : batch;
+        const size_t parked = w.parked_bytes > need_parked ? w.parked_bytes : need_parked;
         if (w.ptr) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(w.ptr); }
-        w.ptr = nullptr; w.bytes = 0; w.cap = 0;
-        const size_t bytes = hybrid_ws_bytes(batch);
-        if (hipMalloc(&w.ptr, bytes) != hipSuccess || !init_workspace(w.ptr, batch, stream)) {
+        w.ptr = nullptr; w.bytes = 0; w.cap = 0; w.parked_bytes = 0;
+        const size_t bytes = hybrid_queue_bytes(cap) + parked;
+        if (hipMalloc(&w.ptr, bytes) != hipSuccess || !init_workspace(w.ptr, cap, stream)) {
             if (w.ptr) (void)hipFree(w.ptr);
             w.ptr = nullptr;
             snprintf(g_err, sizeof(g_err), "cvxpnpl: workspace allocation failed (%zu bytes)", bytes);
             return false;
         }
-        w.bytes = bytes; w.cap = batch;
+        w.bytes = bytes; w.cap = cap; w.parked_bytes = parked;
     }
     v.count = (int32_t *)w.ptr;
     v.entries = (int32_t *)((char *)w.ptr + 256);
     v.parked = (double *)((char *)w.ptr + hybrid_queue_bytes(w.cap));
     return true;
+}
+
+void launch_wave(int64_t wgrid, hipStream_t s, const cvxw::WaveArgs &w, const cvx::Opts &o)
+{
+    if (o.variant == cvx::VAR_RC) hipLaunchKernelGGL(cvxw::solve_wave_kernel<cvx::VAR_RC>, dim3((unsigned)wgrid), dim3(64 * cvxw::WPB), 0, s, w, o);
+    else hipLaunchKernelGGL(cvxw::solve_wave_kernel<cvx::VAR_FULL>, dim3((unsigned)wgrid), dim3(64 * cvxw::WPB), 0, s, w, o);
+}
+
+void launch_resume(int64_t rgrid, hipStream_t s, const cvxw::WaveArgs &w, const cvx::Opts &o, int32_t *count, int32_t *entries, const double *ws, bool full)
+{
+    cvxw::ResumeArgs ra;
+    ra.a = w; ra.o = o; ra.count_p = count; ra.entries = entries; ra.ws = ws;
+    ra.ws_stride = full ? cvxw::RS_FULL : cvxw::RS_LANE; ra.ws_full = full ? 1 : 0;
+    hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64), 0, s, ra);
 }
 
 int set_err(const char *what, hipError_t e)
@@ -266,7 +271,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
         // are queued for the resume kernel behind it -- an empty queue costs that launch a few microseconds.
         // The resume kernel leaves the queue counter at zero for the next launch: no memset per call.)
         WsView wv;
-        if (!get_workspace(batch, stream, wv)) return -2;
+        if (!get_workspace(batch, cvxw::RS_FULL, stream, wv)) return -2;
         int32_t *count = wv.count, *entries = wv.entries;
         double *ws = wv.parked;
         const int64_t qgrid = (batch + 3) / 4;
@@ -275,7 +280,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
         if (opts && opts->layout == 9) hipLaunchKernelGGL((cvxq::solve_quad_kernel<1, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // experiment
         else hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         const int64_t rgrid = batch < cvxw::RESUME_GRID_MAX ? batch : cvxw::RESUME_GRID_MAX;
-        launch_resume(rgrid, s, w, o, count, entries, ws);
+        launch_resume(rgrid, s, w, o, count, entries, ws, true);
     } else if (layout == CVXPNPL_LAYOUT_WAVE) {
         int64_t wgrid = (batch + cvxw::WPB - 1) / cvxw::WPB;
         if (wgrid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }
@@ -292,12 +297,12 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
         if (o.max_iters > lane_iters) {
             // hybrid: lanes for the first lane_iters iterations, survivors resumed one per wavefront
             WsView wv;
-            if (!get_workspace(batch, stream, wv)) return -2;
+            if (!get_workspace(batch, cvxw::RS_LANE, stream, wv)) return -2;
             int32_t *count = wv.count, *entries = wv.entries;
             double *ws = wv.parked;
             hipLaunchKernelGGL(solve_lane_kernel, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws);
             const int64_t rgrid = batch < cvxw::RESUME_GRID_MAX ? batch : cvxw::RESUME_GRID_MAX;
-            launch_resume(rgrid, s, w, o, count, entries, ws);
+            launch_resume(rgrid, s, w, o, count, entries, ws, false);
         } else {
             // fewer iterations allowed than the lane phase would run: the wave kernel does the whole solve
             int64_t wgrid = (batch + cvxw::WPB - 1) / cvxw::WPB;
@@ -485,7 +490,7 @@ int cvxpnpl_set_workspace(void *d_workspace, size_t bytes, void *stream)
     const int64_t cap = hybrid_capacity(bytes);
     if (cap <= 0) { snprintf(g_err, sizeof(g_err), "cvxpnpl_set_workspace: %zu bytes hold no problem (cvxpnpl_workspace_bytes)", bytes); g_ws.erase(std::make_pair(dev, stream)); return -1; }
     if (!init_workspace(d_workspace, cap, stream)) { g_ws.erase(std::make_pair(dev, stream)); return set_err("cvxpnpl_set_workspace", hipGetLastError()); }
-    w.ptr = d_workspace; w.bytes = bytes; w.cap = cap; w.owned = false;
+    w.ptr = d_workspace; w.bytes = bytes; w.cap = cap; w.parked_bytes = bytes - hybrid_queue_bytes(cap); w.owned = false;
     return 0;
 }
 

@@ -250,7 +250,7 @@ __device__ __noinline__ void finish_own(QuadArgsPtr kp, unsigned parked, double 
     const int64_t b0 = (int64_t)blockIdx.x * 4;
     for (int g = 0; g < 4; ++g) { // wave-uniform
         if (!((parked >> g) & 1u)) continue;
-        cvxw::solve_one_wave(a, o, b0 + g, lds, ws + (b0 + g) * 56);
+        cvxw::solve_one_wave(a, o, b0 + g, lds, ws + (b0 + g) * cvxw::RS_FULL, true);
         CVXW_SYNC();
     }
 #endif
@@ -488,11 +488,15 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
         // certify, and the slow ones among them run for hundreds of iterations.  They go to the queue of
         // cvxw::resume_wave_kernel (launched behind this kernel), one wavefront each, scheduled dynamically:
         // finishing them here, four in a row per wavefront, was 1.6x slower on a planar batch.
+        double *slot = ws + b * cvxw::RS_FULL;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-            if (w.ok(m)) ws[b * 56 + w.e(m)] = W[m];
+            if (w.ok(m)) { slot[cvxw::RS_W + w.e(m)] = W[m]; slot[cvxw::RS_Q + w.e(m)] = w.ej(m) < 9 ? L[Q_QF + w.ei(m) * 10 + w.ej(m)] * tr : 0.0; }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+            if (gl + 16 * m < 27) slot[cvxw::RS_B + gl + 16 * m] = L[Q_B + gl + 16 * m];
         if (gl == 0) {
-            ws[b * 56 + 55] = 0.0;
+            slot[cvxw::RS_IT] = 0.0;
             const int q = atomicAdd(qcount, 1);
             qentries[q] = (int32_t)b;
         }
@@ -871,10 +875,22 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
         if (it >= handoff_at) {
             // ---- hand the unfinished problems to the wave-per-problem kernel
             if (!done) {
+                // the iterate, and what this wavefront has that the next one would otherwise rebuild: cost, B, eigenvectors
+                double *slot = ws + b * cvxw::RS_FULL;
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
-                    if (w.ok(m)) park(ws + b * 56 + w.e(m), W[m]);
-                if (gl == 0) park(ws + b * 56 + 55, (double)it);
+                    if (w.ok(m)) {
+                        park(slot + cvxw::RS_W + w.e(m), W[m]);
+                        park(slot + cvxw::RS_Q + w.e(m), w.ej(m) < 9 ? L[Q_QF + w.ei(m) * 10 + w.ej(m)] * tr : 0.0);
+                    }
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    if (gl + 16 * m < 27) park(slot + cvxw::RS_B + gl + 16 * m, L[Q_B + gl + 16 * m]);
+                if (gl < 10) {
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) park(slot + cvxw::RS_V + gl * 10 + i, v[i]);
+                }
+                if (gl == 0) park(slot + cvxw::RS_IT, (double)it);
                 parked = true;
             }
             break;

@@ -484,11 +484,19 @@ struct WaveArgs {
     const double *Q45, *B27; // cost entry (cvxpnpl_solve_cost_batch): [batch][45] packed A^T A and [batch][27] B instead of correspondences
 };
 
+// Layout of a parked problem in the workspace (doubles).  Every hand-off carries the iterate W (vech order) and the
+// iteration count; the quad schedule (RS_FULL slots) also hands over what its wavefront already had -- the cost entries,
+// the translation map and the unit eigenvectors of the last iterate -- so that the wavefront that takes the problem over
+// neither re-reads and re-assembles the correspondences nor starts its first eigen-solve cold (2-3 iteration-equivalents
+// off the tail of every launch: the slowest problems are exactly the handed-over ones).
+constexpr int RS_W = 0, RS_IT = 55, RS_LANE = 56;           // lane schedule: 56 doubles per problem
+constexpr int RS_Q = 56, RS_B = 112, RS_V = 140, RS_FULL = 240; // quad schedule: + Q (55, vech order, 0 outside the 9x9 block), B (27), V (100: [column][row])
+
 // Solve problem b with the wavefront that calls this.  resume (optional): 56 doubles written by
 // the lane-layout kernel for a problem it handed off -- W (55, vech order) and the iteration
 // count -- the solve then continues from that iterate instead of starting at e9 e9^T.
 template <int VAR = cvx::VAR_FULL>
-__device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opts &o, const int64_t b, double *L, const double *resume)
+__device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opts &o, const int64_t b, double *L, const double *resume, const bool resume_full = false)
 {
     const int lane = threadIdx.x & 63;
     double2 *L2 = reinterpret_cast<double2 *>(L);
@@ -518,6 +526,10 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
         if (ej < 9) Qe = a.Q45[b * 45 + cvx::qidx(ei, ej)];
         if (lane < 27) L[L_B + lane] = a.B27[b * 27 + lane];
         okG = !__any(lane < 27 && !(L[L_B + lane] == L[L_B + lane]));
+    } else if (resume && resume_full) {
+        // handed over by a quad wavefront together with what it had assembled (device-coherent loads: same launch)
+        Qe = __hip_atomic_load(resume + RS_Q + el, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < 27) L[L_B + lane] = __hip_atomic_load(resume + RS_B + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         cvx::ProblemView pv = cvx::make_view(b, a.n_p, a.p2, a.p3, a.n_l, a.l2, a.l3, a.K, a.K_per_problem);
         const int nrec = pv.n_p + 2 * pv.n_l;
@@ -720,9 +732,15 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
             } else acc = rd(54);
             W = acc;
         }
-        it = (int)rd(55);
+        it = (int)rd(RS_IT);
         next_check = it + 1 > o.first_check ? it + 1 : o.first_check;
         cold = true;
+        if (resume_full && it > 0 && !canon) { // the eigenvectors of the last iterate come along: warm start
+            L[L_VN + lane] = rd(RS_V + lane);
+            if (lane < 36) L[L_VN + 64 + lane] = rd(RS_V + 64 + lane);
+            cold = false;
+            CVXW_SYNC();
+        }
         if (o.tail_from > 0 && it >= o.tail_from) { rho = o.rho_tail; irho = 1.0 / rho; }
     }
     double fp_res = 1e300, lam2_prev = -1.0;
@@ -1205,6 +1223,7 @@ struct ResumeArgs {
     cvx::Opts o;
     int32_t *count_p, *entries;
     const double *ws;
+    int ws_stride, ws_full; // doubles per parked problem (RS_LANE / RS_FULL) and whether the slots carry Q, B, V
 };
 typedef const __attribute__((address_space(4))) ResumeArgs *ResumeArgsPtr;
 
@@ -1215,11 +1234,13 @@ __device__ __forceinline__ void resume_body(ResumeArgsPtr kp, int32_t first, dou
     const cvx::Opts o = kp->o;
     int32_t *entries = kp->entries;
     const double *ws = kp->ws;
+    const int stride = kp->ws_stride;
+    const bool full = kp->ws_full != 0;
     int32_t b = first;
     for (int64_t q = blockIdx.x;;) { // wave-uniform
         if ((threadIdx.x & 63) == 0) entries[q] = -1;
         if (b < a.batch) {
-            solve_one_wave(a, o, b, lds, ws + (int64_t)b * 56);
+            solve_one_wave(a, o, b, lds, ws + (int64_t)b * stride, full);
             CVXW_SYNC();
         }
         q += gridDim.x;
