@@ -25,7 +25,7 @@ prof hybrid_125k --workload pnp_n10_125k
 prof large_n --workload pnp_n10000_1k
 cd $root
 # bench lines of the same build (full default run incl. both CPU baselines and the in-run PMC passes)
-python bench.py > $out/bench_default.json 2> $out/bench_default.err
+( time python bench.py > $out/bench_default.json 2> $out/bench_default.err ) 2> $out/bench_default.time
 python bench.py --batch 24000 --no-cpu-baseline > $out/bench_quad_24k.json 2>/dev/null
 python bench.py --workload pnp_n10_125k --no-cpu-baseline > $out/bench_125k.json 2>/dev/null
 python bench.py --workload pnpl_5p5l_100k --no-cpu-baseline > $out/bench_pnpl_100k.json 2>/dev/null
