@@ -262,6 +262,33 @@ def main():
         dt2 = time.perf_counter() - t1
         overlapped = {"streams": 2, "value": batch * args.steps / dt2, "unit": "poses/s", "ms_per_step": 1e3 * dt2 / args.steps}
 
+    graph_replay = None
+    if nstreams == 1 and world == 1 and not args.no_overlap and not blocked:
+        # the same step captured once into a hipGraph and replayed K times on one stream (the launches of a step -- first
+        # kernel + resume kernel -- become one graph launch); reported beside `value`
+        gs = torch.cuda.Stream(dev)
+        try:
+            with torch.cuda.stream(gs):
+                for _ in range(2):  # warm-up on the capture stream (its workspace is allocated here, not during capture)
+                    rc = L.cvxpnpl_solve_batch(batch, n_p, ptr(p2), ptr(p3), n_l, ptr(l2), ptr(l3), ptr(K), 0, C.byref(opts), ptr(R), ptr(t), ptr(status),
+                                               ptr(iters), ptr(cost), C.c_void_p(0), ptr(work), C.c_void_p(gs.cuda_stream))
+            gs.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=gs):
+                rc = L.cvxpnpl_solve_batch(batch, n_p, ptr(p2), ptr(p3), n_l, ptr(l2), ptr(l3), ptr(K), 0, C.byref(opts), ptr(R), ptr(t), ptr(status),
+                                           ptr(iters), ptr(cost), C.c_void_p(0), ptr(work), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                g.replay()
+            torch.cuda.synchronize(dev)
+            dtg = time.perf_counter() - t1
+            graph_replay = {"value": batch * args.steps / dtg, "unit": "poses/s", "ms_per_step": 1e3 * dtg / args.steps}
+        except Exception as e:  # diagnostics only: never fail the bench line over it
+            graph_replay = {"error": str(e)[:200]}
+
     st = status.cpu().numpy()
     it = iters.cpu().numpy()
     wk = work.cpu().numpy()
@@ -314,6 +341,8 @@ def main():
             out["roofline"]["traffic_source"] = "none: rocprofv3 not available and no profile of this library build committed"
     if overlapped:
         out["overlapped"] = overlapped
+    if graph_replay:
+        out["graph_replay"] = graph_replay
     if sigma == 0.0:
         geo = synth.geodesic(R.cpu().numpy(), d["R_gt"])
         out["solver"]["max_rot_err_vs_gt_rad"] = float(geo[st == 0].max())
