@@ -464,6 +464,14 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
 #ifdef CVXQ_TIMELINE
     tl_[1] = tl_now();
 #endif
+#ifdef CVXQ_PHASES // diagnostics (tools/quad_phases.py): shader cycles per phase of this wavefront, summed over its iterations
+    unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t;
+    auto ph_now = []() { unsigned long long t; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory"); return t; };
+    ph_t = ph_now();
+#define CVXQ_PH(k) do { const unsigned long long n_ = ph_now(); ph_[k] += n_ - ph_t; ph_t = n_; } while (0)
+#else
+#define CVXQ_PH(k)
+#endif
     // ---------------------------------------------------------------- ADMM
     double delta = o.eps / (8.0 * tr);
     delta = delta < 1e-13 ? 1e-13 : delta;
@@ -543,6 +551,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
             al = 0.0;
 #pragma unroll
             for (int i = 0; i < 10; ++i) al += g[i] * g[i];
+CVXQ_PH(0); /* fro, LDS copy of W, g = (W + sigma I) v */
             int sweeps = 0;
             bool active = !done; // row-uniform
             do {
@@ -572,6 +581,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
                 if (active) ++sweeps;
                 active = active && grp_more && sweeps < o.jacobi_sweeps;
             } while (__any(active));
+CVXQ_PH(1); /* jacobi */
             total_sweeps += sweeps;
             // ---- Wp = sum_{lam > 0} lam u u^T from (g, w g), w = lam / |g|^2
             const double lp = cvx::sqrt_fast(al), lam = lp - sigma;
@@ -599,6 +609,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
                 }
             }
         }
+CVXQ_PH(2); /* Wp */
         ++it;
         const bool check = MODE == 0 && it >= next_check;
         if (check) {
@@ -626,6 +637,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
             }
             // the four problems polish together; when none needs it (done, or the rounded candidate is the pose
             // the previous check already polished) the Newton iterations are skipped altogether
+CVXQ_PH(3); /* check: top eigenvector, reuse test */
             if (__any(!done && !reuse)) {
                 // (problems whose candidate would be reused polish along: same result, no divergence)
                 d0 = cvxw::coop_round(vloc, Rc);
@@ -747,6 +759,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
                 }
                 CVXW_SYNC();
             }
+CVXQ_PH(4); /* polar + Newton polish */
             // ---- dual half (cvx::dual_certificate): hint S_h = rho (Wp - W); S1 = S_h - P_null(S_h - Qs)
             double S[4];
             {
@@ -800,6 +813,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
             double Se[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) Se[m] = S[m] + (((w.pk[m] >> 23) & 1) ? delta : 0.0);
+CVXQ_PH(5); /* dual fit + correction */
             const double minp = quad_ldl(L, w, Se);
             const bool cok = (minp > 0) && (res < 1e-10) && (d0 > 0) && (pobj == pobj);
             const bool gap_ok = cok && (tr * (fabs(zSz) + 4.0 * delta) <= gap_tol);
@@ -836,6 +850,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
                 done = true;
             }
         }
+CVXQ_PH(6); /* LDL + outputs (or nothing when no check) */
         if (!done && it == o.tail_from) { // smaller penalty for the slow tail; keeps the dual: Wm scales by rho / rho_tail
 #pragma unroll
             for (int m = 0; m < 4; ++m) W[m] = Wp[m] + (W[m] - Wp[m]) * (rho / o.rho_tail);
@@ -872,6 +887,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
                 done = true;
             }
         }
+CVXQ_PH(7); /* projection + update */
         if (it >= handoff_at) {
             // ---- hand the unfinished problems to the wave-per-problem kernel
             if (!done) {
@@ -909,6 +925,14 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
         CVXW_SYNC();
         finish_own((QuadArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), pmask, lds_all);
     }
+#ifdef CVXQ_PHASES
+    if (lane == 0 && a.cost && (int64_t)blockIdx.x * 4 + 3 < a.batch) {
+        double *c = a.cost + 2 * ((int64_t)blockIdx.x * 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c[k] = (double)ph_[k];
+        if (a.work) { a.work[2 * ((int64_t)blockIdx.x * 4)] = it; a.work[2 * ((int64_t)blockIdx.x * 4) + 1] = total_sweeps; }
+    }
+#endif
 #ifdef CVXQ_TIMELINE
     tl_[3] = tl_now();
     if (lane == 0 && a.cost && (int64_t)blockIdx.x * 4 + 1 < a.batch) {
