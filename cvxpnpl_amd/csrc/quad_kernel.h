@@ -217,13 +217,13 @@ __device__ __forceinline__ double quad_ldl(double *L, const Own &w, double *Me)
 // device-scope loads: no cache maintenance, only program order).
 // Tried first: a device-wide queue from which idle wavefronts steal parked problems.  The cache line with
 // its head / tail words bounces between the eight XCDs' L2s: 1.6 ms per launch for 2500 wavefronts, measured.
-// Not inlined on purpose: as a separate function the wave-per-problem solver gets a register allocation of
-// its own and leaves that of the quad phase alone; nothing but the kernel arguments is live across the call.
-// (The arguments go by reference to copies the caller makes inside the branch that calls: handing down the
-// kernel's own a / o made every wavefront of the grid write them to its scratch frame at kernel entry, 190 B per
-// lane = 30 MB of HBM writes per 10 k launch and 4 % of its time.  Also tried: re-reading them from the kernarg
-// segment inside the callee (the segment pointer is null there); handing that pointer down (scalar loads, but the
-// callee's frame grows from 136 to 588 B); through LDS, with or without readfirstlane (callee frame 492 / 552 B).)
+// Inlined (round 2): as a separate function the second phase paid the calling convention -- ~110 callee-saved VGPRs
+// stored on entry and reloaded on exit, 47 KB of scratch traffic per call: 4.7 MB of HBM writes and 3.4 MB of reads
+// per 10 k launch from the ~75 wavefronts that get here, more than all inputs and outputs together (PMC: 14.6 ->
+// 8.7 MB per launch, and 1 % faster).  Its spills (46 registers) sit in this tail only; the quad loop has none.
+// (History of the separate function: handing down the kernel's own a / o made every wavefront of the grid write them
+// to its scratch frame at kernel entry, 190 B per lane = 30 MB of HBM writes per 10 k launch; re-reading them from the
+// kernarg segment inside the callee fixed that.)
 __device__ __forceinline__ void park(double *p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // All kernel arguments as ONE struct, so that the kernarg segment IS this struct: the second phase reads what it needs
@@ -241,7 +241,7 @@ struct QuadArgs {
 };
 typedef const __attribute__((address_space(4))) QuadArgs *QuadArgsPtr;
 
-__device__ __noinline__ void finish_own(QuadArgsPtr kp, unsigned parked, double *lds)
+__device__ __forceinline__ void finish_own(QuadArgsPtr kp, unsigned parked, double *lds)
 {
 #if defined(__HIP_DEVICE_COMPILE__) // (the host pass cannot copy out of the constant address space; it never calls this)
     const WaveArgs a = kp->a; // scalar loads from the kernarg segment, only in the wavefronts that get here
@@ -505,6 +505,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
             if (gl + 16 * m < 27) slot[cvxw::RS_B + gl + 16 * m] = L[Q_B + gl + 16 * m];
         if (gl == 0) {
             slot[cvxw::RS_IT] = 0.0;
+            slot[cvxw::RS_NC] = 0.0;
             const int q = atomicAdd(qcount, 1);
             qentries[q] = (int32_t)b;
         }
@@ -906,7 +907,7 @@ CVXQ_PH(7); /* projection + update */
 #pragma unroll
                     for (int i = 0; i < 10; ++i) park(slot + cvxw::RS_V + gl * 10 + i, v[i]);
                 }
-                if (gl == 0) park(slot + cvxw::RS_IT, (double)it);
+                if (gl == 0) { park(slot + cvxw::RS_IT, (double)it); park(slot + cvxw::RS_NC, (double)next_check); }
                 parked = true;
             }
             break;

@@ -490,7 +490,7 @@ struct WaveArgs {
 // neither re-reads and re-assembles the correspondences nor starts its first eigen-solve cold (2-3 iteration-equivalents
 // off the tail of every launch: the slowest problems are exactly the handed-over ones).
 constexpr int RS_W = 0, RS_IT = 55, RS_LANE = 56;           // lane schedule: 56 doubles per problem
-constexpr int RS_Q = 56, RS_B = 112, RS_V = 140, RS_FULL = 240; // quad schedule: + Q (55, vech order, 0 outside the 9x9 block), B (27), V (100: [column][row])
+constexpr int RS_Q = 56, RS_B = 112, RS_NC = 139, RS_V = 140, RS_FULL = 240; // quad schedule: + Q (55, vech order, 0 outside the 9x9 block), B (27), the iteration of the next certificate attempt, V (100: [column][row])
 
 // Solve problem b with the wavefront that calls this.  resume (optional): 56 doubles written by
 // the lane-layout kernel for a problem it handed off -- W (55, vech order) and the iteration
@@ -734,6 +734,10 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
         }
         it = (int)rd(RS_IT);
         next_check = it + 1 > o.first_check ? it + 1 : o.first_check;
+        if (resume_full) { // the attempt schedule of the first phase goes on (an attempt costs two to three iterations)
+            const int nc = (int)rd(RS_NC);
+            next_check = nc > next_check ? nc : next_check;
+        }
         cold = true;
         if (resume_full && it > 0 && !canon) { // the eigenvectors of the last iterate come along: warm start
             L[L_VN + lane] = rd(RS_V + lane);

@@ -16,12 +16,14 @@ from cvxpnpl_amd import synth  # noqa: E402
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 layout = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+li = int(sys.argv[3]) if len(sys.argv) > 3 else -1  # hand-off iteration of the quad schedule (-1: default)
 dev = torch.device("cuda:0")
 d = synth.make_pnp(batch, 10, 2.0, seed=42)
 p2, p3, K = (torch.as_tensor(d[k], device=dev) for k in ("pts_2d", "pts_3d", "K"))
 for _ in range(3):
-    res = ca.pnp_batch(p2, p3, K, layout=layout)
+    res = ca.pnp_batch(p2, p3, K, layout=layout, lane_iters=li)
 torch.cuda.synchronize()
+pit = res.iters.cpu().numpy()
 c = res.cost.cpu().numpy().reshape(-1)
 w = res.work.cpu().numpy().reshape(-1)
 nw = (batch + 3) // 4
@@ -32,14 +34,14 @@ xcc = np.array([w[8 * i + 2] for i in range(len(T))]).astype(np.int64)
 T -= T[:, 0].min()
 clk = 100e6  # s_memrealtime: the 100 MHz reference clock, common to the whole device
 us = T / clk * 1e6
-out = {"batch": batch, "waves": len(T), "span_us": float(us[:, 3].max()),
+out = {"batch": batch, "lane_iters": li, "waves": len(T), "span_us": float(us[:, 3].max()),
        "start_us_pct": {str(p): float(np.percentile(us[:, 0], p)) for p in (1, 25, 50, 75, 90, 99, 100)},
        "end_us_pct": {str(p): float(np.percentile(us[:, 3], p)) for p in (1, 25, 50, 75, 90, 99, 100)},
        "dur_us_pct": {str(p): float(np.percentile(us[:, 3] - us[:, 0], p)) for p in (1, 25, 50, 75, 90, 99, 100)},
        "assembly_us_median": float(np.median(us[:, 1] - us[:, 0])), "quadloop_us_median": float(np.median(us[:, 2] - us[:, 1])),
        "tail_us_max": float((us[:, 3] - us[:, 2]).max()), "n_with_tail": int(((us[:, 3] - us[:, 2]) > 1.0).sum()),
        "iters_hist": np.bincount(its.clip(0, 20)).tolist(),
-       "slowest_waves": [{"block": int(i), "start": float(us[i, 0]), "quad_end": float(us[i, 2]), "end": float(us[i, 3]), "it": int(its[i])} for i in np.argsort(-us[:, 3])[:12]]}
+       "slowest_waves": [{"block": int(i), "start": float(us[i, 0]), "quad_end": float(us[i, 2]), "end": float(us[i, 3]), "it": int(its[i]), "iters": pit[4 * i: 4 * i + 4].tolist()} for i in np.argsort(-us[:, 3])[:12]]}
 # resident waves over time
 grid = np.linspace(0, us[:, 3].max(), 41)
 out["resident_waves"] = [int(((us[:, 0] <= g) & (us[:, 3] > g)).sum()) for g in grid]
