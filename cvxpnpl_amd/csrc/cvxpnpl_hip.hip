@@ -263,6 +263,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     w.Q45 = a.Q45; w.B27 = a.B27;
     int quad_iters = opts ? opts->lane_iters : -1;
     if (quad_iters <= 0) quad_iters = 7; // measured (4 problem sets at 10 k, same box): 5: 0.242 ms, 7: 0.233, 8: 0.235, 10: 0.240; 24 k: 7 = 10 (round 1, second phase as a call: 8-12)
+    if (quad_iters > 16) quad_iters = 16; // the quad phase runs its eigen-solve sweeps in single precision: fine for the first iterations, not for a slow tail (quad_kernel.h)
     if (layout == 9) layout = CVXPNPL_LAYOUT_QUAD; // experiment (tools/README.md): quad iterations only, 3 waves/SIMD: quad iterations only (solve_quad_kernel<1>)
     if (layout == CVXPNPL_LAYOUT_QUAD && !(quad_iters >= 1 && o.max_iters > quad_iters)) layout = CVXPNPL_LAYOUT_WAVE;
     if (layout == CVXPNPL_LAYOUT_QUAD) {
