@@ -46,7 +46,7 @@ def _kernel_name(layout, batch, blocked=False):
     if blocked:
         return "assemble_large_kernel (dominant: timed on its own) + assemble_finish_kernel + solve_wave_kernel"
     if layout == 0:
-        layout = 2 if batch < 3584 else (3 if batch < 38912 else 1)
+        layout = 2 if batch < 2560 else (3 if batch < 26624 else 1)
     return {1: "solve_lane_kernel + resume_wave_kernel", 2: "solve_wave_kernel",
             3: "solve_quad_kernel (+ resume_wave_kernel: planar scenes only, empty here)"}.get(layout, f"experimental layout {layout}")
 
@@ -303,6 +303,8 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": args.workload, "n_points": n_p, "n_lines": n_l, "problems_per_gpu_per_step": batch,
                    "pixel_noise_sigma": sigma, "eps": opts.eps, "max_iters": opts.max_iters,
+                   "precision": "f64: inputs, iterate, certificate, outputs; the Jacobi sweeps of the PSD projection run in f32 in the "
+                                "first phase of the quad / lane schedules (<= 16 / 5 iterations), in f64 in the wave-per-problem kernel",
                    "streams": nstreams,
                    "parallelism": f"batch-sharded x{world}" + (", RCCL all_gather of results" if gather else ""),
                    "collective": ({"backend": backend + (" (RCCL)" if backend == "nccl" else " (ranks share a device: diagnostics, not RCCL)"),

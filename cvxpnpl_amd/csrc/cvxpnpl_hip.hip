@@ -243,17 +243,17 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     if (grid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }
     int layout = opts ? opts->layout : CVXPNPL_LAYOUT_AUTO;
     // AUTO, by launch size (measured on one MI355X, M poses/s for wave / quad / lane-hybrid, PnP N = 10,
-    // profiles/r01/layout_sweep.txt):
-    //   2 k: 17.2 / 14.1 / 5.7    5 k: 24.1 / 28.0 / 13.6    10 k: 28.1 / 39.2 / 25.3    16 k: 32.7 / 53.2 / 38.3
-    //   24 k: 33.5 / 56.8 / 54.9  32 k: 34.3 / 65.3 / 66.9   50 k: 37.9 / 71.0 / 90.0    125 k: 40.5 / 84.2 / 120.6
-    // * below 3584 problems a wavefront per problem: every SIMD gets work and a finished problem frees
-    //   its slot at once;
-    // * from there four problems per wavefront (one per DPP row): 2.2x fewer instructions per problem;
-    // * from 38912 the lane-hybrid schedule (8 problem sets per size: 36 k 70.8 quad / 68.7 lane, 40 k 69.2 / 75.0) (64 problems per wavefront for the first lane_iters
-    //   iterations): fewest instructions, but it needs tens of thousands of problems to fill the chip.
+    // profiles/r02/layout_sweep.txt; quad and lane phases with single-precision eigen-solve sweeps):
+    //   2 k: 16.8 / 16.0 / 7.3    5 k: 23.9 / 31.3 / 17.3   10 k: 28.1 / 46.3 / 31.5    16 k: 31.8 / 64.4 / 46.6
+    //   24 k: 33.0 / 67.9 / 67.4  32 k: 33.6 / 69.0 / 83.9  50 k: 38.0 / 84.9 / 113.2   125 k: 40.1 / 103.8 / 147.5
+    // * below 2560 problems a wavefront per problem: every SIMD gets work and a finished problem frees
+    //   its slot at once (3 problem sets per size: 2048: 16.8 wave / 15.5 quad, 2560: 17.1 / 19.6, 3072: 17.1 / 21.4);
+    // * from there four problems per wavefront (one per DPP row): 2.5x fewer instructions per problem;
+    // * from 26624 the lane-hybrid schedule (64 problems per wavefront for the first lane_iters iterations; 24 k: 67.9 quad /
+    //   67.4 lane, 28 k: 75.0 / 78.0): fewest instructions, but it needs tens of thousands of problems to fill the chip.
     // The problems the quad phase leaves open are finished by the same wavefront, those of the lane phase
     // by a second kernel, one per wavefront in both cases.
-    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 3584 ? CVXPNPL_LAYOUT_WAVE : (batch < 38912 ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
+    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 2560 ? CVXPNPL_LAYOUT_WAVE : (batch < 26624 ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
     // the 16-equality variant (benchmarks/toolkit/methods/rc.py) is built for the wave-per-problem layout only
     if (o.variant == cvx::VAR_RC) layout = CVXPNPL_LAYOUT_WAVE;
     cvxw::WaveArgs w;

@@ -501,6 +501,193 @@ CVX_HD int eig_solve(Eig &e, int max_sweeps, double tol2)
     return sweeps;
 }
 
+// ---------------------------------------------------------------------------------------
+// The same eigen-solve with the columns in single precision, two rows per packed instruction (v_pk_mul_f32 /
+// v_pk_fma_f32): for the FIRST iterations of a solve -- the lane phase of the hybrid schedule (TWIN = false: at most 5
+// iterations) and the quad kernel.  The columns only have to become orthogonal to the sweep tolerance (6e-2), the
+// iterate they produce is a dual hint whose certificate is verified in double, and ~1e-7 of noise per iteration is far
+// below what the first iterations move.  Measured on the host build, 10 k problems each of PnP N=10 / N=6 sigma 5 / N=4 and
+// PnPL 5+5: with single-precision sweeps in the first 7 iterations the iteration histograms are identical to the double
+// ones; single precision THROUGHOUT only changes tails beyond ~100 iterations (those run in double: wave kernel).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float f2 __attribute__((ext_vector_type(2)));
+CVX_HD f2 f2_set(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+CVX_HD f2 f2_mul(f2 a, f2 b) { return a * b; }
+CVX_HD f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+CVX_HD f2 f2_neg(f2 a) { return -a; }
+#else
+struct f2 { float x, y; };
+CVX_HD f2 f2_set(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+CVX_HD f2 f2_mul(f2 a, f2 b) { return f2_set(a.x * b.x, a.y * b.y); }
+CVX_HD f2 f2_fma(f2 a, f2 b, f2 c) { return f2_set(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)); }
+CVX_HD f2 f2_neg(f2 a) { return f2_set(-a.x, -a.y); }
+#endif
+
+struct EigF {
+    f2 G[10][5];  // G[j][i]: column j, rows 2i and 2i + 1
+    float n2[10]; // squared column norms
+    double sigma;
+};
+CVX_HD double eig_g(const Eig &e, int j, int i) { return e.G[j][i]; }
+CVX_HD double eig_g(const EigF &e, int j, int i) { return (double)((i & 1) ? e.G[j][i >> 1].y : e.G[j][i >> 1].x); }
+CVX_HD void eig_unit(Eig &e)
+{
+    CVX_UNROLL for (int j = 0; j < 10; ++j) {
+        CVX_UNROLL for (int i = 0; i < 10; ++i) e.G[j][i] = (i == j) ? 1.0 : 0.0;
+        e.n2[j] = 1.0;
+    }
+    e.sigma = 0.0;
+}
+CVX_HD void eig_unit(EigF &e)
+{
+    CVX_UNROLL for (int j = 0; j < 10; ++j) {
+        CVX_UNROLL for (int i = 0; i < 5; ++i) e.G[j][i] = f2_set((2 * i == j) ? 1.0f : 0.0f, (2 * i + 1 == j) ? 1.0f : 0.0f);
+        e.n2[j] = 1.0f;
+    }
+    e.sigma = 0.0;
+}
+
+CVX_HD void eig_load(EigF &e, const double *W)
+{
+    double fro = 0;
+    CVX_UNROLL for (int i = 0; i < 10; ++i)
+        CVX_UNROLL for (int j = i; j < 10; ++j) fro += (i == j ? 1.0 : 2.0) * W[sidx(i, j)] * W[sidx(i, j)];
+    e.sigma = 1.5 * sqrt_fast(fro) + 1e-300;
+    CVX_UNROLL for (int j = 0; j < 10; ++j)
+        CVX_UNROLL for (int i = 0; i < 5; ++i)
+            e.G[j][i] = f2_set((float)(W[sidx(2 * i, j)] + (2 * i == j ? e.sigma : 0.0)), (float)(W[sidx(2 * i + 1, j)] + (2 * i + 1 == j ? e.sigma : 0.0)));
+}
+
+// warm start (see eig_load_warm above); the product (W + sigma I) v is formed in double from the double iterate
+CVX_HD void eig_load_warm(EigF &e, const double *W)
+{
+    double fro = 0;
+    CVX_UNROLL for (int i = 0; i < 10; ++i)
+        CVX_UNROLL for (int j = i; j < 10; ++j) fro += (i == j ? 1.0 : 2.0) * W[sidx(i, j)] * W[sidx(i, j)];
+    e.sigma = 1.5 * sqrt_fast(fro) + 1e-300;
+    CVX_UNROLL for (int j = 0; j < 10; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const double il_ = (double)__builtin_amdgcn_rsqf(e.n2[j]);
+#else
+        const double il_ = 1.0 / sqrt((double)e.n2[j]);
+#endif
+        double v[10];
+        CVX_UNROLL for (int i = 0; i < 10; ++i) v[i] = eig_g(e, j, i) * il_;
+        double acc[10];
+        CVX_UNROLL for (int i = 0; i < 10; ++i) {
+            acc[i] = e.sigma * v[i];
+            CVX_UNROLL for (int m = 0; m < 10; ++m) acc[i] += W[sidx(i, m)] * v[m];
+        }
+        CVX_UNROLL for (int i = 0; i < 5; ++i) e.G[j][i] = f2_set((float)acc[2 * i], (float)acc[2 * i + 1]);
+    }
+}
+
+CVX_HD void eig_norms(EigF &e)
+{
+    CVX_UNROLL for (int j = 0; j < 10; ++j) {
+        f2 a = f2_mul(e.G[j][0], e.G[j][0]);
+        CVX_UNROLL for (int i = 1; i < 5; ++i) a = f2_fma(e.G[j][i], e.G[j][i], a);
+        e.n2[j] = a.x + a.y;
+    }
+}
+
+CVX_HD void jacobi_cs(float al, float be, float gam, bool rot, float &c, float &s, float &t)
+{
+    const float d = be - al, g2 = 2.0f * gam;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float h2 = d * d + g2 * g2 + 1e-37f;
+    const float hf = h2 * __builtin_amdgcn_rsqf(h2);
+    float tf = g2 * __builtin_amdgcn_rcpf(fabsf(d) + hf);
+    tf = d < 0.0f ? -tf : tf;
+    t = rot ? tf : 0.0f;
+    c = __builtin_amdgcn_rsqf(1.0f + t * t);
+#else
+    const float h = sqrtf(d * d + g2 * g2 + 1e-37f);
+    float tt = g2 / (fabsf(d) + h);
+    tt = d < 0 ? -tt : tt;
+    t = rot ? tt : 0.0f;
+    c = 1.0f / sqrtf(1.0f + t * t);
+#endif
+    s = t * c;
+}
+
+template <int ST>
+CVX_HD double eig_step5(EigF &e)
+{
+    constexpr int P[5] = {rr_col(ST, 0), rr_col(ST, 1), rr_col(ST, 2), rr_col(ST, 3), rr_col(ST, 4)};
+    constexpr int Q[5] = {rr_col(ST, 5), rr_col(ST, 6), rr_col(ST, 7), rr_col(ST, 8), rr_col(ST, 9)};
+    f2 acc[5];
+    CVX_UNROLL for (int k = 0; k < 5; ++k) acc[k] = f2_mul(e.G[P[k]][0], e.G[Q[k]][0]);
+    CVX_UNROLL for (int i = 1; i < 5; ++i)
+        CVX_UNROLL for (int k = 0; k < 5; ++k) acc[k] = f2_fma(e.G[P[k]][i], e.G[Q[k]][i], acc[k]);
+    float c[5], s[5], worst = 0;
+    CVX_UNROLL for (int k = 0; k < 5; ++k) {
+        const float gam = acc[k].x + acc[k].y;
+        const float al = e.n2[P[k]], be = e.n2[Q[k]];
+        const float g2 = gam * gam, ab = al * be;
+        float t;
+        jacobi_cs(al, be, gam, g2 > 1e-30f * ab, c[k], s[k], t);
+#if defined(__HIP_DEVICE_COMPILE__)
+        const float r = g2 * __builtin_amdgcn_rcpf(ab);
+#else
+        const float r = g2 / ab;
+#endif
+        worst = r > worst ? r : worst;
+        e.n2[P[k]] = al - t * gam;
+        e.n2[Q[k]] = be + t * gam;
+    }
+    CVX_UNROLL for (int i = 0; i < 5; ++i)
+        CVX_UNROLL for (int k = 0; k < 5; ++k) {
+            const f2 gp = e.G[P[k]][i], gq = e.G[Q[k]][i];
+            const f2 cc = f2_set(c[k], c[k]), ss = f2_set(s[k], s[k]);
+            e.G[P[k]][i] = f2_fma(cc, gp, f2_neg(f2_mul(ss, gq)));
+            e.G[Q[k]][i] = f2_fma(ss, gp, f2_mul(cc, gq));
+        }
+    return (double)worst;
+}
+
+CVX_HD int eig_solve(EigF &e, int max_sweeps, double tol2)
+{
+    int sweeps = 0;
+    for (; sweeps < max_sweeps;) {
+        eig_norms(e);
+        double worst = 0, r;
+        r = eig_step5<0>(e); worst = r > worst ? r : worst;
+        r = eig_step5<1>(e); worst = r > worst ? r : worst;
+        r = eig_step5<2>(e); worst = r > worst ? r : worst;
+        r = eig_step5<3>(e); worst = r > worst ? r : worst;
+        r = eig_step5<4>(e); worst = r > worst ? r : worst;
+        r = eig_step5<5>(e); worst = r > worst ? r : worst;
+        r = eig_step5<6>(e); worst = r > worst ? r : worst;
+        r = eig_step5<7>(e); worst = r > worst ? r : worst;
+        r = eig_step5<8>(e); worst = r > worst ? r : worst;
+        ++sweeps;
+        if (!(worst > tol2)) break;
+    }
+    eig_norms(e);
+    return sweeps;
+}
+
+// Wp = sum_{lam_j > 0} lam_j v_j v_j^T  (55 packed), accumulated in double from the single-precision columns
+CVX_HD void eig_pospart(const EigF &e, double *Wp)
+{
+    double w[10];
+    CVX_UNROLL for (int j = 0; j < 10; ++j) {
+        const double n2 = (double)e.n2[j];
+        const double lam = sqrt_fast(n2) - e.sigma;
+        w[j] = lam > 0 ? lam / n2 : 0.0;
+    }
+    CVX_UNROLL for (int i = 0; i < 55; ++i) Wp[i] = 0.0;
+    CVX_UNROLL for (int j = 0; j < 10; ++j) { // column-major: ten conversions live at a time, not a hundred
+        double g[10];
+        CVX_UNROLL for (int i = 0; i < 10; ++i) g[i] = eig_g(e, j, i);
+        CVX_UNROLL for (int i = 0; i < 10; ++i) {
+            const double wg = w[j] * g[i];
+            CVX_UNROLL for (int k = i; k < 10; ++k) Wp[sidx(i, k)] += wg * g[k];
+        }
+    }
+}
+
 // Wp = sum_{lam_j > 0} lam_j v_j v_j^T  (55 packed)
 CVX_HD void eig_pospart(const Eig &e, double *Wp)
 {
@@ -1122,6 +1309,9 @@ CVX_HD void fallback_pose(QV Qs, double tr, const double *v, const double *v2, i
 // schedule: the wave-per-problem kernel resumes it).
 // TWIN = false compiles the two-fold-ambiguity branch out (the lane phase of the hybrid schedule hands
 // off before iteration 6, where that branch starts, and the extra live state costs it registers).
+template <bool TWIN> struct EigOf { typedef Eig type; };
+template <> struct EigOf<false> { typedef EigF type; };
+
 template <bool TWIN = true, class ST = RegStore, int VAR = VAR_FULL>
 CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution &sol, double *Zout, int handoff_at = 0,
                       double *handoff = nullptr, ST st = ST())
@@ -1169,7 +1359,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
     double W[55], Wp[55];
     CVX_UNROLL for (int i = 0; i < 55; ++i) W[i] = 0;
     W[sidx(9, 9)] = 1.0;
-    Eig e;
+    typename EigOf<TWIN>::type e; // (TWIN = false: the lane phase, at most 5 iterations: single-precision sweeps)
     Cert c;
     c.ok = false;
     int it = 0, next_check = o.first_check;
@@ -1191,11 +1381,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
             // the initial iterate W0 = e9 e9^T is diagonal and PSD: its projection is itself and its
             // eigenvectors are the unit vectors -- the first iteration needs no eigen-solve
             CVX_UNROLL for (int i = 0; i < 55; ++i) Wp[i] = W[i];
-            CVX_UNROLL for (int j = 0; j < 10; ++j) {
-                CVX_UNROLL for (int i = 0; i < 10; ++i) e.G[j][i] = (i == j) ? 1.0 : 0.0;
-                e.n2[j] = 1.0;
-            }
-            e.sigma = 0.0;
+            eig_unit(e);
         } else {
             if (o.warm_start && it > 0) eig_load_warm(e, W);
             else eig_load(e, W);
@@ -1210,7 +1396,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
             int jm = 0, j2 = 0;
             double best = -1, second = -1;
             CVX_UNROLL for (int j = 0; j < 10; ++j) {
-                const double n2 = e.n2[j];
+                const double n2 = (double)e.n2[j];
                 const bool b1 = n2 > best, b2 = !b1 && n2 > second;
                 second = b1 ? best : (b2 ? n2 : second);
                 j2 = b1 ? jm : (b2 ? j : j2);
@@ -1235,7 +1421,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
             double vt[10], v2[10], il1 = rsqrt_(best), il2 = rsqrt_(second);
             CVX_UNROLL for (int i = 0; i < 10; ++i) {
                 double s1 = 0, s2 = 0;
-                CVX_UNROLL for (int j = 0; j < 10; ++j) { s1 = (j == jm) ? e.G[j][i] : s1; s2 = (j == j2) ? e.G[j][i] : s2; }
+                CVX_UNROLL for (int j = 0; j < 10; ++j) { s1 = (j == jm) ? eig_g(e, j, i) : s1; s2 = (j == j2) ? eig_g(e, j, i) : s2; }
                 vt[i] = s1 * il1;
                 v2[i] = s2 * il2;
             }
@@ -1388,7 +1574,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
 #ifdef CVX_TRACE
             {
                 double lam[10];
-                for (int j = 0; j < 10; ++j) lam[j] = sqrt(e.n2[j]) - e.sigma;
+                for (int j = 0; j < 10; ++j) lam[j] = sqrt((double)e.n2[j]) - e.sigma;
                 for (int a = 0; a < 10; ++a) for (int b = a + 1; b < 10; ++b) if (lam[b] > lam[a]) { double t_ = lam[a]; lam[a] = lam[b]; lam[b] = t_; }
                 if (it <= 30 || it % 50 == 0)
                     printf("it %4d fp_res %.3e eig+ %.4f %.4f %.4f %.4f  eig- %.2e  cert: ok=%d minpiv %.2e res %.1e pobj %.3e\n", it, fp_res, lam[0], lam[1], lam[2], lam[3], lam[9], (int)c.ok, c.min_piv, c.res, c.pobj);
