@@ -479,9 +479,9 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
     double W[4], Wp[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) { W[m] = (w.e(m) == 54) ? 1.0 : 0.0; Wp[m] = W[m]; }
-    double v[10]; // unit eigenvector owned by this lane (warm start of the next eigen-solve)
+    f2 v[5]; // unit eigenvector owned by this lane (warm start of the next eigen-solve), rows 2i and 2i + 1, single precision
 #pragma unroll
-    for (int i = 0; i < 10; ++i) v[i] = (gl == i) ? 1.0 : 0.0;
+    for (int i = 0; i < 5; ++i) { v[i].x = (gl == 2 * i) ? 1.0f : 0.0f; v[i].y = (gl == 2 * i + 1) ? 1.0f : 0.0f; }
     int it = 0, total_sweeps = 0, next_check = o.first_check;
     bool have_prev = false;
     int reused = 0; // consecutive checks that took over the previous check's pose (cvx::REUSE_MAX, see cvx::solve_sdp)
@@ -536,21 +536,36 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
 #pragma unroll
             for (int m = 0; m < 4; ++m) fro += w.wgt(m) * W[m] * W[m];
             sigma = 1.5 * cvx::sqrt_fast(row_sum(fro)) + 1e-300;
+            // g = (W + sigma I) v in single precision like the sweeps that follow (see there): W goes to LDS as floats, rows
+            // padded to 12 (three b128 reads per row instead of five), two rows of v per packed FMA
+            float *Lf = reinterpret_cast<float *>(L + Q_WF);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
-                if (w.ok(m)) { L[Q_WF + w.ei(m) * 10 + w.ej(m)] = W[m]; L[Q_WF + w.ej(m) * 10 + w.ei(m)] = W[m]; }
+                if (w.ok(m)) { const float wf = (float)W[m]; Lf[w.ei(m) * 12 + w.ej(m)] = wf; Lf[w.ej(m) * 12 + w.ei(m)] = wf; }
             CVXW_SYNC();
-            double g[10];
+            const float sigf = (float)sigma;
+            f2 q[5];
 #pragma unroll
             for (int i = 0; i < 10; ++i) {
-                const double2 *row = L2 + (Q_WF + i * 10) / 2;
-                const double2 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3], r4 = row[4];
-                g[i] = sigma * v[i] + (((r0.x * v[0] + r0.y * v[1]) + (r1.x * v[2] + r1.y * v[3])) + ((r2.x * v[4] + r2.y * v[5]) + (r3.x * v[6] + r3.y * v[7])) +
-                                       (r4.x * v[8] + r4.y * v[9]));
+                const float4 *row = reinterpret_cast<const float4 *>(Lf + i * 12);
+                const float4 r0 = row[0], r1 = row[1];
+                const float2 r2 = *reinterpret_cast<const float2 *>(Lf + i * 12 + 8);
+                f2 a = f2{r0.x, r0.y} * v[0];
+                a = __builtin_elementwise_fma(f2{r0.z, r0.w}, v[1], a);
+                a = __builtin_elementwise_fma(f2{r1.x, r1.y}, v[2], a);
+                a = __builtin_elementwise_fma(f2{r1.z, r1.w}, v[3], a);
+                a = __builtin_elementwise_fma(f2{r2.x, r2.y}, v[4], a);
+                const float vi = (i & 1) ? v[i >> 1].y : v[i >> 1].x;
+                const float gi = fmaf(sigf, vi, a.x + a.y);
+                if (i & 1) q[i >> 1].y = gi; else q[i >> 1].x = gi;
             }
-            al = 0.0;
+            float alf;
+            {
+                f2 a = q[0] * q[0];
 #pragma unroll
-            for (int i = 0; i < 10; ++i) al += g[i] * g[i];
+                for (int i = 1; i < 5; ++i) a = __builtin_elementwise_fma(q[i], q[i], a);
+                alf = a.x + a.y;
+            }
 CVXQ_PH(0); /* fro, LDS copy of W, g = (W + sigma I) v */
             // The sweeps run in single precision, two rows per packed instruction: the columns only have to become
             // orthogonal to the sweep tolerance (6e-2), the iterate is a dual hint whose certificate is verified in
@@ -558,10 +573,6 @@ CVXQ_PH(0); /* fro, LDS copy of W, g = (W + sigma I) v */
             // of PnP N=10 / N=6 sigma 5 / N=4, PnPL 5+5): iteration histograms identical to the double sweeps as long as
             // the first 7-16 iterations are concerned (single precision throughout only hurts tails of > 100 iterations,
             // which are the wave-per-problem kernel's).  Half the exchange (11 ds_bpermute per step), half the arithmetic.
-            f2 q[5];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) { q[i].x = (float)g[2 * i]; q[i].y = (float)g[2 * i + 1]; }
-            float alf = (float)al;
             const float tol2f = (float)tol2;
             int sweeps = 0;
             bool active = !done; // row-uniform
@@ -598,6 +609,7 @@ CVXQ_PH(0); /* fro, LDS copy of W, g = (W + sigma I) v */
                 if (active) ++sweeps;
                 active = active && grp_more && sweeps < o.jacobi_sweeps;
             } while (__any(active));
+            double g[10];
 #pragma unroll
             for (int i = 0; i < 5; ++i) { g[2 * i] = (double)q[i].x; g[2 * i + 1] = (double)q[i].y; }
             al = 0.0;
@@ -609,14 +621,17 @@ CVXQ_PH(1); /* jacobi */
             const double lp = cvx::sqrt_fast(al), lam = lp - sigma;
             const bool col = gl < 10;
             const double wpos = (col && lam > 0) ? lam * cvx::rcp(al) : 0.0;
-            const double ilp = col ? cvx::rsqrt_(al) : 0.0;
             if (col) {
 #pragma unroll
                 for (int i = 0; i < 5; ++i) L2[(Q_Y + gl * 10) / 2 + i] = make_double2(g[2 * i], g[2 * i + 1]);
                 L[Q_Y + 100 + gl] = wpos;
             }
+            {
+                const float ilf = col ? __builtin_amdgcn_rsqf(alf) : 0.0f;
+                const f2 il2 = {ilf, ilf};
 #pragma unroll
-            for (int i = 0; i < 10; ++i) v[i] = g[i] * ilp;
+                for (int i = 0; i < 5; ++i) v[i] = q[i] * il2;
+            }
             const unsigned long long pm = __ballot(wpos > 0);
             const unsigned anypos = (unsigned)((pm | (pm >> 16) | (pm >> 32) | (pm >> 48)) & 0x3FFull);
             CVXW_SYNC();
@@ -642,7 +657,7 @@ CVXQ_PH(2); /* Wp */
             CVXW_SYNC(); // (the Wp gathers above are done with Q_Y)
             if (gl == jmax) {
 #pragma unroll
-                for (int i = 0; i < 10; ++i) L[Q_M + 22 + i] = v[i];
+                for (int i = 0; i < 5; ++i) { L[Q_M + 22 + 2 * i] = (double)v[i].x; L[Q_M + 22 + 2 * i + 1] = (double)v[i].y; }
             }
             CVXW_SYNC();
             double vloc[10];
@@ -926,7 +941,7 @@ CVXQ_PH(7); /* projection + update */
                     if (gl + 16 * m < 27) park(slot + cvxw::RS_B + gl + 16 * m, L[Q_B + gl + 16 * m]);
                 if (gl < 10) {
 #pragma unroll
-                    for (int i = 0; i < 10; ++i) park(slot + cvxw::RS_V + gl * 10 + i, v[i]);
+                    for (int i = 0; i < 5; ++i) { park(slot + cvxw::RS_V + gl * 10 + 2 * i, (double)v[i].x); park(slot + cvxw::RS_V + gl * 10 + 2 * i + 1, (double)v[i].y); }
                 }
                 if (gl == 0) { park(slot + cvxw::RS_IT, (double)it); park(slot + cvxw::RS_NC, (double)next_check); }
                 parked = true;
