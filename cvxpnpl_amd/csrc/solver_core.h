@@ -595,12 +595,16 @@ CVX_HD void jacobi_cs(float al, float be, float gam, bool rot, float &c, float &
 {
     const float d = be - al, g2 = 2.0f * gam;
 #if defined(__HIP_DEVICE_COMPILE__)
+    // half-angle form (two v_rsq_f32 in a row instead of rsq -> rcp -> rsq): cos 2th = |d| / h, c^2 = (1 + cos 2th) / 2
     const float h2 = d * d + g2 * g2 + 1e-37f;
-    const float hf = h2 * __builtin_amdgcn_rsqf(h2);
-    float tf = g2 * __builtin_amdgcn_rcpf(fabsf(d) + hf);
-    tf = d < 0.0f ? -tf : tf;
-    t = rot ? tf : 0.0f;
-    c = __builtin_amdgcn_rsqf(1.0f + t * t);
+    const float ih = __builtin_amdgcn_rsqf(h2);
+    const float c2 = fmaf(0.5f * fabsf(d), ih, 0.5f);
+    const float ic = __builtin_amdgcn_rsqf(c2);
+    const float sg = (0.5f * g2) * ih * ic;
+    c = rot ? c2 * ic : 1.0f;
+    s = rot ? (d < 0.0f ? -sg : sg) : 0.0f;
+    t = s * ic;
+    return;
 #else
     const float h = sqrtf(d * d + g2 * g2 + 1e-37f);
     float tt = g2 / (fabsf(d) + h);
