@@ -46,7 +46,7 @@ def _kernel_name(layout, batch, blocked=False):
     if blocked:
         return "assemble_large_kernel (dominant: timed on its own) + assemble_finish_kernel + solve_wave_kernel"
     if layout == 0:
-        layout = 2 if batch < 2560 else (3 if batch < 26624 else 1)
+        layout = 2 if batch < 2560 else (3 if batch < 24576 else 1)
     return {1: "solve_lane_kernel + resume_wave_kernel", 2: "solve_wave_kernel",
             3: "solve_quad_kernel (+ resume_wave_kernel: planar scenes only, empty here)"}.get(layout, f"experimental layout {layout}")
 

@@ -249,11 +249,11 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     // * below 2560 problems a wavefront per problem: every SIMD gets work and a finished problem frees
     //   its slot at once (3 problem sets per size: 2048: 16.8 wave / 15.5 quad, 2560: 17.1 / 19.6, 3072: 17.1 / 21.4);
     // * from there four problems per wavefront (one per DPP row): 2.5x fewer instructions per problem;
-    // * from 26624 the lane-hybrid schedule (64 problems per wavefront for the first lane_iters iterations; 24 k: 67.9 quad /
+    // * from 24576 the lane-hybrid schedule (64 problems per wavefront for the first lane_iters iterations; 20 k: 69.6 quad / 56.0 lane, 24 k: 71.2 / 72.4, 28 k: 75.2 / 79.7; before the wave kernel went to single-precision sweeps: 24 k: 67.9 quad /
     //   67.4 lane, 28 k: 75.0 / 78.0): fewest instructions, but it needs tens of thousands of problems to fill the chip.
     // The problems the quad phase leaves open are finished by the same wavefront, those of the lane phase
     // by a second kernel, one per wavefront in both cases.
-    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 2560 ? CVXPNPL_LAYOUT_WAVE : (batch < 26624 ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
+    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 2560 ? CVXPNPL_LAYOUT_WAVE : (batch < 24576 ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
     // the 16-equality variant (benchmarks/toolkit/methods/rc.py) is built for the wave-per-problem layout only
     if (o.variant == cvx::VAR_RC) layout = CVXPNPL_LAYOUT_WAVE;
     cvxw::WaveArgs w;
