@@ -48,7 +48,8 @@ def _kernel_name(layout, batch, blocked=False):
     if layout == 0:
         layout = 2 if batch < 2560 else (3 if batch < 24576 else 1)
     return {1: "solve_lane_kernel + resume_wave_kernel", 2: "solve_wave_kernel",
-            3: "solve_quad_kernel (+ resume_wave_kernel: planar scenes only, empty here)"}.get(layout, f"experimental layout {layout}")
+            3: "solve_quad_kernel (+ resume_wave_kernel: planar scenes only, empty here)",
+            4: "solve_quad_kernel<12 lanes per problem> (+ resume_wave_kernel: planar scenes only, empty here)"}.get(layout, f"experimental layout {layout}")
 
 
 def main():
@@ -63,7 +64,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="skip the extra two-stream (overlapped batches) measurement")
     ap.add_argument("--cpu-sample", type=int, default=0, help="problems in the CPU baseline sample (0 = auto)")
-    ap.add_argument("--layout", type=int, default=0, help="kernel layout (0 auto, 1 lane/hybrid, 2 wave, 3 quad/hybrid)")
+    ap.add_argument("--layout", type=int, default=0, help="kernel layout (0 auto, 1 lane/hybrid, 2 wave, 3 quad/hybrid, 4 penta: quad schedule with 12 lanes per problem)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of results when --gpus > 1")
     ap.add_argument("--force-dist", action="store_true", help="diagnostics: run the RCCL path (process group, packed all_gather) "
                     "even with one rank, to measure / smoke-test it on a 1-GPU box")

@@ -264,7 +264,8 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     int quad_iters = opts ? opts->lane_iters : -1;
     if (quad_iters <= 0) quad_iters = 7; // measured (4 problem sets at 10 k, same box): 5: 0.242 ms, 7: 0.233, 8: 0.235, 10: 0.240; 24 k: 7 = 10 (round 1, second phase as a call: 8-12)
     if (quad_iters > 16) quad_iters = 16; // the quad phase runs its eigen-solve sweeps in single precision: fine for the first iterations, not for a slow tail (quad_kernel.h)
-    if (layout == 9) layout = CVXPNPL_LAYOUT_QUAD; // experiment (tools/README.md): quad iterations only, 3 waves/SIMD: quad iterations only (solve_quad_kernel<1>)
+    const bool penta = layout == CVXPNPL_LAYOUT_PENTA;
+    if (layout == 9 || penta) layout = CVXPNPL_LAYOUT_QUAD; // experiment (tools/README.md): quad iterations only, 3 waves/SIMD: quad iterations only (solve_quad_kernel<1>)
     if (layout == CVXPNPL_LAYOUT_QUAD && !(quad_iters >= 1 && o.max_iters > quad_iters)) layout = CVXPNPL_LAYOUT_WAVE;
     if (layout == CVXPNPL_LAYOUT_QUAD) {
         // four problems per wavefront for the first quad_iters iterations, survivors resumed one per wavefront
@@ -275,10 +276,11 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
         if (!get_workspace(batch, cvxw::RS_FULL, stream, wv)) return -2;
         int32_t *count = wv.count, *entries = wv.entries;
         double *ws = wv.parked;
-        const int64_t qgrid = (batch + 3) / 4;
+        const int64_t qgrid = penta ? (batch + 4) / 5 : (batch + 3) / 4;
         cvxq::QuadArgs qa;
         qa.a = w; qa.o = o; qa.handoff_at = quad_iters; qa.qcount = count; qa.qentries = entries; qa.ws = ws;
         if (opts && opts->layout == 9) hipLaunchKernelGGL((cvxq::solve_quad_kernel<1, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // experiment
+        else if (penta) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 12>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         const int64_t rgrid = batch < cvxw::RESUME_GRID_MAX ? batch : cvxw::RESUME_GRID_MAX;
         launch_resume(rgrid, s, w, o, count, entries, ws, true);

@@ -1,4 +1,5 @@
-// quad_kernel.h -- sixteen lanes per problem, four problems per gfx950 wavefront.
+// quad_kernel.h -- sixteen lanes per problem, four problems per gfx950 wavefront (and, as a template parameter, twelve lanes per
+// problem, five per wavefront: CVXPNPL_LAYOUT_PENTA, an experiment that stayed an experiment -- see Geo<> below and DESIGN.md section 3).
 //
 // The 10x10 SDP is too small for 64 lanes: in the wave-per-problem layout most instructions are 3x3 /
 // scalar algebra replicated in every lane, and the kernel is VALU-issue bound on that redundancy.
@@ -38,6 +39,18 @@ constexpr int Q_X = Q_Y + 40; // 56 entry scratch of the affine projection (over
 constexpr int Q_B = 324;   // 28   translation map B (27)
 constexpr int Q_M = 352;   // 36   0.. R out, 12.. previous polished R, 22.. candidate eigenvector
 constexpr int QLDS = 388;
+constexpr int C_RED = 388;  // 12   (twelve-lane groups only) partial values of a reduction over the group
+constexpr int QLDS12 = 404; // slice of a twelve-lane group: 404 * 2 dwords = 40 mod 64 banks, the six slices of a wave start 0, 40, 16, 56, 32, 8 banks in
+// Lanes per problem: 16 (a DPP row; four problems per wavefront) or 12 (five problems per wavefront + four dummy lanes that own a
+// sixth LDS slice and never write results): 2 000 instead of 2 500 wavefronts for 10 k problems -- one round of the chip's 2 048
+// slots instead of two -- for 5 instead of 4 entries per lane and group reductions through LDS instead of DPP butterflies.
+template <int LPP> struct Geo {
+    static constexpr int NPW = LPP == 16 ? 4 : 5;            // problems per wavefront
+    static constexpr int NGRP = LPP == 16 ? 4 : 6;           // LDS slices per wavefront (incl. the dummy group of lanes 60..63)
+    static constexpr int EPL = (55 + LPP - 1) / LPP;         // entries of the symmetric iterate per lane
+    static constexpr int SLICE = LPP == 16 ? QLDS : QLDS12;  // doubles of LDS per group
+    static constexpr int M27 = (27 + LPP - 1) / LPP, M40 = (40 + LPP - 1) / LPP, M36 = (36 + LPP - 1) / LPP, M60 = (60 + LPP - 1) / LPP;
+};
 constexpr int C_XV = Q_Y;         // 40  x-vectors z, a_0, a_1, a_2 (stride 10)
 constexpr int C_YV = Q_Y + 40;    // 40  Qs x
 constexpr int C_H1 = Q_Y + 80;    // 10  a_k . Q a_l
@@ -123,29 +136,60 @@ __device__ __forceinline__ double flip(double x, unsigned neg) // neg in {0, 1}
 {
     return __hiloint2double(__double2hiint(x) ^ (int)(neg << 31), __double2loint(x));
 }
-__device__ __forceinline__ unsigned grp_bits(unsigned long long m, int grp) { return (unsigned)(m >> (16 * grp)) & 0xFFFFu; }
+template <int LPP>
+__device__ __forceinline__ unsigned grp_bits(unsigned long long m, int grp) { return (unsigned)(m >> (LPP * grp)) & ((1u << LPP) - 1u); }
+// all-reduce over the lanes of a group: DPP butterflies inside the row (16) or through the group's LDS slice (12; wave-uniform call)
+template <int LPP>
+__device__ __forceinline__ double grp_sum(double *L, int gl, double x)
+{
+    if (LPP == 16) return row_sum(x);
+    L[C_RED + gl] = x;
+    CVXW_SYNC();
+    const double2 *r = reinterpret_cast<const double2 *>(L + C_RED);
+    const double2 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4], f = r[5];
+    CVXW_SYNC();
+    return ((a.x + a.y) + (b.x + b.y)) + ((c.x + c.y) + (d.x + d.y)) + ((e.x + e.y) + (f.x + f.y));
+}
+template <int LPP>
+__device__ __forceinline__ double grp_max(double *L, int gl, double x)
+{
+    if (LPP == 16) return row_max(x);
+    L[C_RED + gl] = x;
+    CVXW_SYNC();
+    const double2 *r = reinterpret_cast<const double2 *>(L + C_RED);
+    const double2 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4], f = r[5];
+    CVXW_SYNC();
+    return fmax(fmax(fmax(a.x, a.y), fmax(b.x, b.y)), fmax(fmax(fmax(c.x, c.y), fmax(d.x, d.y)), fmax(fmax(e.x, e.y), fmax(f.x, f.y))));
+}
 
 // entries owned by a lane
 // Only the packed words are state; everything else is re-derived where it is used (a few bit-field extracts), and the
 // main loop hides the words behind an empty asm once per iteration so that the compiler cannot hoist the derived values
 // out of the loop and carry ~28 registers of them across every phase (they were the bulk of the kernel's spills).
+template <int LPP>
 struct Own {
-    unsigned pk[4];
+    static constexpr int EPL = Geo<LPP>::EPL;
+    unsigned pk[EPL];
     int gl;
-    __device__ __forceinline__ int e(int m) const { return gl + 16 * m; }
+    __device__ __forceinline__ int e(int m) const { return gl + LPP * m; }
     __device__ __forceinline__ int ei(int m) const { return (int)(pk[m] & 15u); }
     __device__ __forceinline__ int ej(int m) const { return (int)((pk[m] >> 4) & 15u); }
-    __device__ __forceinline__ bool ok(int m) const { return gl + 16 * m < 55; }
+    __device__ __forceinline__ bool ok(int m) const { return gl + LPP * m < 55; }
     __device__ __forceinline__ double wgt(int m) const { return ok(m) ? (ei(m) == ej(m) ? 1.0 : 2.0) : 0.0; }
-    __device__ __forceinline__ void refresh() { asm volatile("" : "+v"(pk[0]), "+v"(pk[1]), "+v"(pk[2]), "+v"(pk[3])); }
+    __device__ __forceinline__ void refresh()
+    {
+#pragma unroll
+        for (int m = 0; m < EPL; ++m) asm volatile("" : "+v"(pk[m]));
+    }
 };
 
 // Projection of the symmetric matrix held 3-4 entries per lane onto { <A_i, Z> = b_i } (tgt = 1) or its
 // direction space (tgt = 0); closed form of cvx::proj_affine.
-__device__ __forceinline__ void quad_proj(double *L, const Own &w, double *X, double tgt)
+template <class OWN>
+__device__ __forceinline__ void quad_proj(double *L, const OWN &w, double *X, double tgt)
 {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < OWN::EPL; ++m)
         if (w.ok(m)) L[Q_X + w.e(m)] = X[m];
     CVXW_SYNC();
     double d[9];
@@ -155,7 +199,7 @@ __device__ __forceinline__ void quad_proj(double *L, const Own &w, double *X, do
     const double c0 = d[0] + d[1] + d[2] - tgt, c1 = d[3] + d[4] + d[5] - tgt, c2 = d[6] + d[7] + d[8] - tgt;
     const double tot = r0 + r1 + r2;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < OWN::EPL; ++m) {
         const unsigned pk = w.pk[m];
         const int ri = w.ei(m) % 3, ci = w.ei(m) / 3; // diagonal entry (ei, ei), ei < 9, is D[ri][ci]
         const double rr = ri == 0 ? r0 : (ri == 1 ? r1 : r2), cc = ci == 0 ? c0 : (ci == 1 ? c1 : c2);
@@ -187,20 +231,21 @@ __device__ __forceinline__ void pair_cs(float d, float gam, bool rot, bool tie_n
 
 // In-place LDL^T of the symmetric matrix held 3-4 entries per lane, pivot rows broadcast through LDS;
 // returns the smallest pivot (cvx::ldl_min_pivot).
-__device__ __forceinline__ double quad_ldl(double *L, const Own &w, double *Me)
+template <class OWN>
+__device__ __forceinline__ double quad_ldl(double *L, const OWN &w, double *Me)
 {
     double minp = 1e300;
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < OWN::EPL; ++m)
             if (w.ok(m) && w.ei(m) == k) L[C_ROW + w.ej(m)] = Me[m];
         CVXW_SYNC();
         const double d = L[C_ROW + k];
         minp = d < minp ? d : minp;
         const double id = cvxw::fast_rcp(d);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < OWN::EPL; ++m) {
             const double ra = L[C_ROW + w.ei(m)], rb = L[C_ROW + w.ej(m)];
             if (w.ei(m) > k) Me[m] -= ra * id * rb;
         }
@@ -209,7 +254,7 @@ __device__ __forceinline__ double quad_ldl(double *L, const Own &w, double *Me)
     return minp;
 }
 
-// Four problems per wavefront: problem b = 4 * blockIdx.x + (lane >> 4).
+// NPW problems per wavefront (four 16-lane or five 12-lane groups): problem b = NPW * blockIdx.x + group.
 // Second phase: the wavefront finishes the problems it could not certify within handoff_at iterations itself,
 // one after the other in the wave-per-problem layout (low latency per problem; they are the slow / ambiguous
 // ones, twin logic included).  The iterate travels through ws[] (written with park(), read back with
@@ -240,14 +285,15 @@ struct QuadArgs {
 };
 typedef const __attribute__((address_space(4))) QuadArgs *QuadArgsPtr;
 
+template <int NPW>
 __device__ __forceinline__ void finish_own(QuadArgsPtr kp, unsigned parked, double *lds)
 {
 #if defined(__HIP_DEVICE_COMPILE__) // (the host pass cannot copy out of the constant address space; it never calls this)
     const WaveArgs a = kp->a; // scalar loads from the kernarg segment, only in the wavefronts that get here
     const cvx::Opts o = kp->o;
     const double *ws = kp->ws;
-    const int64_t b0 = (int64_t)blockIdx.x * 4;
-    for (int g = 0; g < 4; ++g) { // wave-uniform
+    const int64_t b0 = (int64_t)blockIdx.x * NPW;
+    for (int g = 0; g < NPW; ++g) { // wave-uniform
         if (!((parked >> g) & 1u)) continue;
         cvxw::solve_one_wave(a, o, b0 + g, lds, ws + (b0 + g) * cvxw::RS_FULL, true);
         CVXW_SYNC();
@@ -258,20 +304,24 @@ __device__ __forceinline__ void finish_own(QuadArgsPtr kp, unsigned parked, doub
 // MODE 0: the schedule described above.  MODE 1 (experiment, tools/phase_a_time.sh): the iterations only -- no
 // certificate code is compiled in, every problem is parked after handoff_at iterations -- to measure what the
 // iteration phase costs at the occupancy it gets without the certificate's registers.
-template <int MODE, int OCC = 2>
+template <int MODE, int OCC = 2, int LPP = 16>
 __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
 {
+    typedef Geo<LPP> G_;
+    constexpr int NPW = G_::NPW, EPL = G_::EPL, SLICE = G_::SLICE;
     const WaveArgs &a = k.a;
     const cvx::Opts &o = k.o;
     const int handoff_at = k.handoff_at;
     int32_t *const qcount = k.qcount, *const qentries = k.qentries;
     double *const ws = k.ws;
-    __shared__ __attribute__((aligned(16))) double lds_all[4 * QLDS];
-    const int lane = threadIdx.x & 63, gl = lane & 15, grp = lane >> 4;
-    double *L = lds_all + grp * QLDS;
+    __shared__ __attribute__((aligned(16))) double lds_all[G_::NGRP * SLICE];
+    const int lane = threadIdx.x & 63;
+    const int grp = LPP == 16 ? lane >> 4 : (lane * 43) >> 9; // lane / 12: lanes 60..63 are a dummy sixth group (own LDS slice, no problem)
+    const int gl = lane - grp * LPP;
+    double *L = lds_all + grp * SLICE;
     double2 *L2 = reinterpret_cast<double2 *>(L);
-    const int64_t b_raw = (int64_t)blockIdx.x * 4 + grp;
-    const bool gvalid = b_raw < a.batch;
+    const int64_t b_raw = (int64_t)blockIdx.x * NPW + grp;
+    const bool gvalid = grp < NPW && b_raw < a.batch;
     const int64_t b = gvalid ? b_raw : a.batch - 1; // surplus rows redo the last problem, outputs suppressed
 #ifdef CVXQ_TIMELINE // diagnostics build (tools/timeline.py): shader-clock stamps of this wavefront, written over cost[] at the end
     unsigned long long tl_[4];
@@ -281,23 +331,23 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
 #endif
 
     // ---------------------------------------------------------------- roles
-    Own w;
+    Own<LPP> w;
     w.gl = gl;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) w.pk[m] = kETab.w[gl + 16 * m];
+    for (int m = 0; m < EPL; ++m) w.pk[m] = kETab.w[gl + LPP * m];
     const unsigned long long ptab = kPTab.packed[gl];
-    const int lane_base4 = (lane & 48) << 2;
+    const int lane_base4 = (grp * LPP) << 2;
 
     // ---------------------------------------------------------------- assembly (cvxpnpl.py:20-153, :545-549)
     bool okK = true, okG = true;
-    double Qs[4];
+    double Qs[EPL];
     if (a.Q45) {
         // cost entry (the seam of cvxpnpl.py:454-460): A^T A (packed 9x9) and B come from the caller
 #pragma unroll
-        for (int m = 0; m < 4; ++m) Qs[m] = (w.ok(m) && w.ej(m) < 9) ? a.Q45[b * 45 + cvx::qidx(w.ei(m), w.ej(m))] : 0.0;
+        for (int m = 0; m < EPL; ++m) Qs[m] = (w.ok(m) && w.ej(m) < 9) ? a.Q45[b * 45 + cvx::qidx(w.ei(m), w.ej(m))] : 0.0;
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-            if (gl + 16 * m < 27) L[Q_B + gl + 16 * m] = a.B27[b * 27 + gl + 16 * m];
+        for (int m = 0; m < G_::M27; ++m)
+            if (gl + LPP * m < 27) L[Q_B + gl + LPP * m] = a.B27[b * 27 + gl + LPP * m];
     } else {
         cvx::ProblemView pv = cvx::make_view(b, a.n_p, a.p2, a.p3, a.n_l, a.l2, a.l3, a.K, a.K_per_problem);
         double Ki[9];
@@ -310,11 +360,14 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
         }
         // Gram sums: role r = gl + 16 m < 60 is  sum rec[6 + qa] rec[6 + qb] rec[te]  with rec = (T[6], 1, P[3]):
         // M0 (6): qa = qb = 0 | M1 (3 x 6): qa = 1 + a | M2 (6 x 6): qa = 1 + a, qb = 1 + b
-        int rqa[4], rqb[4], rte[4];
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        constexpr int M60 = G_::M60;
+        int rqa[M60], rqb[M60], rte[M60];
+        double acc[M60];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int r = gl + 16 * m;
+        for (int m = 0; m < M60; ++m) acc[m] = 0.0;
+#pragma unroll
+        for (int m = 0; m < M60; ++m) {
+            const int r = gl + LPP * m;
             const int al = r < 60 ? r : 0;
             int qa = 0, qb = 0, te = al;
             if (al >= 6 && al < 24) { qa = 1 + (al - 6) / 6; te = (al - 6) % 6; }
@@ -330,8 +383,8 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
         // sums about the problem's first 3D point (cvx::assemble: exact, and well conditioned far from the world origin)
         const double *c0p = pv.n_p ? pv.p3 : pv.l3;
         const double cs0 = c0p[0], cs1 = c0p[1], cs2 = c0p[2];
-        for (int base = 0; base < nrec; base += 16) {
-            const int cnt = nrec - base < 16 ? nrec - base : 16;
+        for (int base = 0; base < nrec; base += LPP) {
+            const int cnt = nrec - base < LPP ? nrec - base : LPP;
             if (gl < cnt) {
                 const int r = base + gl;
                 double T[6], P[3];
@@ -363,13 +416,13 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
             for (int c = 0; c < cnt; ++c) {
                 const double *rec = L + Q_WF + c * 10;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) acc[m] += rec[rqa[m]] * rec[rqb[m]] * rec[rte[m]];
+                for (int m = 0; m < M60; ++m) acc[m] += rec[rqa[m]] * rec[rqb[m]] * rec[rte[m]];
             }
             CVXW_SYNC();
         }
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-            if (gl + 16 * m < 60) L[Q_WF + gl + 16 * m] = acc[m];
+        for (int m = 0; m < M60; ++m)
+            if (gl + LPP * m < 60) L[Q_WF + gl + LPP * m] = acc[m];
         CVXW_SYNC();
         // B = M0^-1 [M1_0 M1_1 M1_2], Q = M2 - M1^T B
         {
@@ -389,8 +442,8 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
         // packed index of (i, j) in a symmetric 3x3 (00 01 02 11 12 22)
         auto psym = [](int i, int j) { const int lo = i < j ? i : j, hi = i < j ? j : i; return lo * 3 - (lo == 2 ? 1 : 0) + (hi - lo); };
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int idx = gl + 16 * m;
+        for (int m = 0; m < G_::M27; ++m) {
+            const int idx = gl + LPP * m;
             if (idx < 27) {
                 const int bb = idx / 9, i = (idx % 9) / 3, j = idx % 3;
                 const double *m1 = L + Q_WF + 6 + 6 * bb;
@@ -402,7 +455,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
         }
         CVXW_SYNC();
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < EPL; ++m) {
             double v = 0.0;
             if (w.ok(m) && w.ej(m) < 9) {
                 const int qa = w.ei(m) / 3, qi = w.ei(m) % 3, qb = w.ej(m) / 3, qj = w.ej(m) % 3;
@@ -418,7 +471,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
     }
     CVXW_SYNC();
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < EPL; ++m)
         if (w.ok(m)) L[Q_X + w.e(m)] = Qs[m];
     CVXW_SYNC();
     double tr = 0;
@@ -426,8 +479,8 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
     for (int k = 0; k < 9; ++k) tr += L[Q_X + cvx::sidx(k, k)];
     bool finite = okK && okG && (tr == tr) && tr > 0 && tr < 1e300;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) finite = finite && (Qs[m] == Qs[m]);
-    finite = grp_bits(__ballot(!finite), grp) == 0;
+    for (int m = 0; m < EPL; ++m) finite = finite && (Qs[m] == Qs[m]);
+    finite = grp_bits<LPP>(__ballot(!finite), grp) == 0;
     const double itr = finite ? cvx::rcp(tr) : 0.0;
     // a planar scene in a general world frame goes to the wave-per-problem kernel at once: it solves in the
     // canonical frame (cvx::canonicalise_planar), with the D-even certificate and the twin logic
@@ -443,7 +496,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
     }
     CVXW_SYNC();
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < EPL; ++m) {
         Qs[m] *= itr;
         if (w.ok(m) && w.ej(m) < 9) { L[Q_QF + w.ei(m) * 10 + w.ej(m)] = Qs[m]; L[Q_QF + w.ej(m) * 10 + w.ei(m)] = Qs[m]; }
     }
@@ -453,12 +506,12 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
     {
         bool zero = true;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) zero = zero && !(w.ok(m) && w.ej(m) >= 6 && w.ej(m) < 9 && !(fabs(Qs[m]) < 1e-13));
-        symm = grp_bits(__ballot(!zero), grp) == 0;
+        for (int m = 0; m < EPL; ++m) zero = zero && !(w.ok(m) && w.ej(m) >= 6 && w.ej(m) < 9 && !(fabs(Qs[m]) < 1e-13));
+        symm = grp_bits<LPP>(__ballot(!zero), grp) == 0;
     }
-    bool odd[4];
+    bool odd[EPL];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) odd[m] = symm && ((w.ei(m) < 6) != (w.ej(m) < 6));
+    for (int m = 0; m < EPL; ++m) odd[m] = symm && ((w.ei(m) < 6) != (w.ej(m) < 6));
 
 #ifdef CVXQ_TIMELINE
     tl_[1] = tl_now();
@@ -476,9 +529,9 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
     delta = delta < 1e-13 ? 1e-13 : delta;
     const double gap_tol = o.eps > 8e-13 * tr ? o.eps : 8e-13 * tr;
     double rho = o.rho, irho = 1.0 / o.rho;
-    double W[4], Wp[4];
+    double W[EPL], Wp[EPL];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) { W[m] = (w.e(m) == 54) ? 1.0 : 0.0; Wp[m] = W[m]; }
+    for (int m = 0; m < EPL; ++m) { W[m] = (w.e(m) == 54) ? 1.0 : 0.0; Wp[m] = W[m]; }
     f2 v[5]; // unit eigenvector owned by this lane (warm start of the next eigen-solve), rows 2i and 2i + 1, single precision
 #pragma unroll
     for (int i = 0; i < 5; ++i) { v[i].x = (gl == 2 * i) ? 1.0f : 0.0f; v[i].y = (gl == 2 * i + 1) ? 1.0f : 0.0f; }
@@ -497,11 +550,11 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
         // finishing them here, four in a row per wavefront, was 1.6x slower on a planar batch.
         double *slot = ws + b * cvxw::RS_FULL;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < EPL; ++m)
             if (w.ok(m)) { slot[cvxw::RS_W + w.e(m)] = W[m]; slot[cvxw::RS_Q + w.e(m)] = w.ej(m) < 9 ? L[Q_QF + w.ei(m) * 10 + w.ej(m)] * tr : 0.0; }
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-            if (gl + 16 * m < 27) slot[cvxw::RS_B + gl + 16 * m] = L[Q_B + gl + 16 * m];
+        for (int m = 0; m < G_::M27; ++m)
+            if (gl + LPP * m < 27) slot[cvxw::RS_B + gl + LPP * m] = L[Q_B + gl + LPP * m];
         if (gl == 0) {
             slot[cvxw::RS_IT] = 0.0;
             slot[cvxw::RS_NC] = 0.0;
@@ -522,7 +575,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
         }
         if (a.Z) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < EPL; ++m)
                 if (w.ok(m)) a.Z[b * 55 + w.e(m)] = NAN;
         }
     }
@@ -534,13 +587,13 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
             // ---- eigendecomposition of W: one-sided Jacobi on G = (W + sigma I) V_prev, column gl in this lane
             double fro = 0.0;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) fro += w.wgt(m) * W[m] * W[m];
-            sigma = 1.5 * cvx::sqrt_fast(row_sum(fro)) + 1e-300;
+            for (int m = 0; m < EPL; ++m) fro += w.wgt(m) * W[m] * W[m];
+            sigma = 1.5 * cvx::sqrt_fast(grp_sum<LPP>(L, gl, fro)) + 1e-300;
             // g = (W + sigma I) v in single precision like the sweeps that follow (see there): W goes to LDS as floats, rows
             // padded to 12 (three b128 reads per row instead of five), two rows of v per packed FMA
             float *Lf = reinterpret_cast<float *>(L + Q_WF);
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < EPL; ++m)
                 if (w.ok(m)) { const float wf = (float)W[m]; Lf[w.ei(m) * 12 + w.ej(m)] = wf; Lf[w.ej(m) * 12 + w.ei(m)] = wf; }
             CVXW_SYNC();
             const float sigf = (float)sigma;
@@ -605,7 +658,7 @@ CVXQ_PH(0); /* fro, LDS copy of W, g = (W + sigma I) v */
                     for (int i = 1; i < 5; ++i) acc = __builtin_elementwise_fma(q[i], q[i], acc);
                     alf = acc.x + acc.y;
                 }
-                const bool grp_more = grp_bits(__ballot(coarse && active), grp) != 0;
+                const bool grp_more = grp_bits<LPP>(__ballot(coarse && active), grp) != 0;
                 if (active) ++sweeps;
                 active = active && grp_more && sweeps < o.jacobi_sweeps;
             } while (__any(active));
@@ -633,16 +686,19 @@ CVXQ_PH(1); /* jacobi */
                 for (int i = 0; i < 5; ++i) v[i] = q[i] * il2;
             }
             const unsigned long long pm = __ballot(wpos > 0);
-            const unsigned anypos = (unsigned)((pm | (pm >> 16) | (pm >> 32) | (pm >> 48)) & 0x3FFull);
+            unsigned long long pu = pm;
+#pragma unroll
+            for (int g = 1; g < NPW; ++g) pu |= pm >> (LPP * g);
+            const unsigned anypos = (unsigned)(pu & 0x3FFull);
             CVXW_SYNC();
 #pragma unroll
-            for (int m = 0; m < 4; ++m) Wp[m] = 0.0;
+            for (int m = 0; m < EPL; ++m) Wp[m] = 0.0;
 #pragma unroll
             for (int s = 0; s < 10; ++s) {
                 if ((anypos >> s) & 1u) { // wave-uniform; a column with no weight in THIS problem adds 0
                     const double ws_ = L[Q_Y + 100 + s];
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) Wp[m] += ws_ * L[Q_Y + s * 10 + w.ei(m)] * L[Q_Y + s * 10 + w.ej(m)];
+                    for (int m = 0; m < EPL; ++m) Wp[m] += ws_ * L[Q_Y + s * 10 + w.ei(m)] * L[Q_Y + s * 10 + w.ej(m)];
                 }
             }
         }
@@ -651,8 +707,8 @@ CVXQ_PH(2); /* Wp */
         const bool check = MODE == 0 && it >= next_check;
         if (check) {
             // ---- certificate attempt (cvx::solve_sdp, non-twin branch): top eigenvector of Wp
-            const double best = row_max(gl < 10 ? al : -1.0);
-            const unsigned tm = grp_bits(__ballot(gl < 10 && al == best), grp);
+            const double best = grp_max<LPP>(L, gl, gl < 10 ? al : -1.0);
+            const unsigned tm = grp_bits<LPP>(__ballot(gl < 10 && al == best), grp);
             const int jmax = __builtin_ctz(tm | 0x10000u);
             CVXW_SYNC(); // (the Wp gathers above are done with Q_Y)
             if (gl == jmax) {
@@ -679,11 +735,11 @@ CVXQ_PH(3); /* check: top eigenvector, reuse test */
                 // (problems whose candidate would be reused polish along: same result, no divergence)
                 d0 = cvxw::coop_round(vloc, Rc);
                 // ---- Newton on SO(3) for f(R) = r^T Qs r (cvx::so3_newton)
-                int xsrc[3];
-                double xsgn[3];
+                int xsrc[G_::M40];
+                double xsgn[G_::M40];
 #pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    const int idx = gl + 16 * m < 40 ? gl + 16 * m : 0;
+                for (int m = 0; m < G_::M40; ++m) {
+                    const int idx = gl + LPP * m < 40 ? gl + LPP * m : 0;
                     xsrc[m] = cvxw::kXTab.src[idx];
                     xsgn[m] = (double)cvxw::kXTab.sgn[idx];
                 }
@@ -694,14 +750,14 @@ CVXQ_PH(3); /* check: top eigenvector, reuse test */
                     }
                     CVXW_SYNC();
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) {
-                        const int idx = gl + 16 * m;
+                    for (int m = 0; m < G_::M40; ++m) {
+                        const int idx = gl + LPP * m;
                         if (idx < 40) L[C_XV + idx] = (idx == 9) ? 1.0 : xsgn[m] * L[C_RL + xsrc[m]];
                     }
                     CVXW_SYNC();
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) {
-                        const int idx = gl + 16 * m;
+                    for (int m = 0; m < G_::M36; ++m) {
+                        const int idx = gl + LPP * m;
                         if (idx < 36) {
                             const int vv = idx / 9, i = idx % 9;
                             L[C_YV + vv * 10 + i] = cvxw::dot10(L2 + (Q_QF + i * 10) / 2, L2 + (C_XV + vv * 10) / 2);
@@ -781,7 +837,7 @@ CVXQ_PH(3); /* check: top eigenvector, reuse test */
                 CVXW_SYNC();
                 double part = 0.0;
                 if (gl < 9) part = L[C_XV + gl] * cvxw::dot10(L2 + (Q_QF + gl * 10) / 2, L2 + C_XV / 2);
-                pobj = row_sum(part);
+                pobj = grp_sum<LPP>(L, gl, part);
             } else {
 #pragma unroll
                 for (int i = 0; i < 9; ++i) Rc[i] = L[Q_M + 12 + i];
@@ -798,14 +854,14 @@ CVXQ_PH(3); /* check: top eigenvector, reuse test */
             }
 CVXQ_PH(4); /* polar + Newton polish */
             // ---- dual half (cvx::dual_certificate): hint S_h = rho (Wp - W); S1 = S_h - P_null(S_h - Qs)
-            double S[4];
+            double S[EPL];
             {
-                double T[4];
+                double T[EPL];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) { S[m] = rho * (Wp[m] - W[m]); T[m] = S[m] - (w.ej(m) < 9 ? L[Q_QF + w.ei(m) * 10 + w.ej(m)] : 0.0); }
+                for (int m = 0; m < EPL; ++m) { S[m] = rho * (Wp[m] - W[m]); T[m] = S[m] - (w.ej(m) < 9 ? L[Q_QF + w.ei(m) * 10 + w.ej(m)] : 0.0); }
                 quad_proj(L, w, T, 0.0);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
+                for (int m = 0; m < EPL; ++m) {
                     S[m] = odd[m] ? 0.0 : S[m] - T[m];
                     if (w.ok(m)) { L[Q_WF + w.ei(m) * 10 + w.ej(m)] = S[m]; L[Q_WF + w.ej(m) * 10 + w.ei(m)] = S[m]; }
                 }
@@ -825,15 +881,15 @@ CVXQ_PH(4); /* polar + Newton polish */
             }
             CVXW_SYNC();
             {   // S2 = S1 - P_range(sym(lam z^T))
-                double E[4], Nn[4];
+                double E[EPL], Nn[EPL];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
+                for (int m = 0; m < EPL; ++m) {
                     E[m] = odd[m] ? 0.0 : 0.5 * (L[C_LAM + w.ei(m)] * L[C_XV + w.ej(m)] + L[C_XV + w.ei(m)] * L[C_LAM + w.ej(m)]);
                     Nn[m] = E[m];
                 }
                 quad_proj(L, w, Nn, 0.0);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
+                for (int m = 0; m < EPL; ++m) {
                     S[m] -= E[m] - Nn[m];
                     if (w.ok(m)) { L[Q_WF + w.ei(m) * 10 + w.ej(m)] = S[m]; L[Q_WF + w.ej(m) * 10 + w.ei(m)] = S[m]; }
                 }
@@ -843,13 +899,13 @@ CVXQ_PH(4); /* polar + Newton polish */
             {
                 const int aa = gl < 10 ? gl : 0;
                 const double sz = cvxw::dot10(L2 + (Q_WF + aa * 10) / 2, L2 + C_XV / 2);
-                res = row_max(gl < 10 ? fabs(sz) : 0.0);
-                zSz = row_sum(gl < 10 ? L[C_XV + aa] * sz : 0.0);
+                res = grp_max<LPP>(L, gl, gl < 10 ? fabs(sz) : 0.0);
+                zSz = grp_sum<LPP>(L, gl, gl < 10 ? L[C_XV + aa] * sz : 0.0);
             }
             CVXW_SYNC();
-            double Se[4];
+            double Se[EPL];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) Se[m] = S[m] + (((w.pk[m] >> 23) & 1) ? delta : 0.0);
+            for (int m = 0; m < EPL; ++m) Se[m] = S[m] + (((w.pk[m] >> 23) & 1) ? delta : 0.0);
 CVXQ_PH(5); /* dual fit + correction */
             const double minp = quad_ldl(L, w, Se);
             const bool cok = (minp > 0) && (res < 1e-10) && (d0 > 0) && (pobj == pobj);
@@ -881,7 +937,7 @@ CVXQ_PH(5); /* dual fit + correction */
                 }
                 if (a.Z) { // Z = z z^T with z = [vec_colmajor(R); 1]
 #pragma unroll
-                    for (int m = 0; m < 4; ++m)
+                    for (int m = 0; m < EPL; ++m)
                         if (w.ok(m)) a.Z[b * 55 + w.e(m)] = L[C_XV + w.ei(m)] * L[C_XV + w.ej(m)];
                 }
                 done = true;
@@ -890,23 +946,23 @@ CVXQ_PH(5); /* dual fit + correction */
 CVXQ_PH(6); /* LDL + outputs (or nothing when no check) */
         if (!done && it == o.tail_from) { // smaller penalty for the slow tail; keeps the dual: Wm scales by rho / rho_tail
 #pragma unroll
-            for (int m = 0; m < 4; ++m) W[m] = Wp[m] + (W[m] - Wp[m]) * (rho / o.rho_tail);
+            for (int m = 0; m < EPL; ++m) W[m] = Wp[m] + (W[m] - Wp[m]) * (rho / o.rho_tail);
         }
         if (it == o.tail_from) { rho = o.rho_tail; irho = 1.0 / rho; }
         // ---- X = Pi_aff(2 Wp - W - Qs / rho);  W <- W + alpha (X - Wp)
         {
-            double X[4];
+            double X[EPL];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) X[m] = 2.0 * Wp[m] - W[m] - irho * (w.ej(m) < 9 ? L[Q_QF + w.ei(m) * 10 + w.ej(m)] : 0.0); // (the cost entries stay in LDS: 8 registers less to carry through the loop)
+            for (int m = 0; m < EPL; ++m) X[m] = 2.0 * Wp[m] - W[m] - irho * (w.ej(m) < 9 ? L[Q_QF + w.ei(m) * 10 + w.ej(m)] : 0.0); // (the cost entries stay in LDS: 8 registers less to carry through the loop)
             quad_proj(L, w, X, 1.0);
             double r2 = 0.0;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < EPL; ++m) {
                 const double dd = X[m] - Wp[m];
                 W[m] += o.alpha * dd;
                 r2 += w.wgt(m) * dd * dd;
             }
-            const double fp_res = cvx::sqrt_fast(row_sum(r2));
+            const double fp_res = cvx::sqrt_fast(grp_sum<LPP>(L, gl, r2));
             if (!done && !(fp_res == fp_res)) { // NaN guard
                 if (gl < 9) a.R[b * 9 + gl] = NAN;
                 if (gl < 3) a.t[b * 3 + gl] = NAN;
@@ -918,7 +974,7 @@ CVXQ_PH(6); /* LDL + outputs (or nothing when no check) */
                 }
                 if (a.Z) {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m)
+                    for (int m = 0; m < EPL; ++m)
                         if (w.ok(m)) a.Z[b * 55 + w.e(m)] = NAN;
                 }
                 done = true;
@@ -931,14 +987,14 @@ CVXQ_PH(7); /* projection + update */
                 // the iterate, and what this wavefront has that the next one would otherwise rebuild: cost, B, eigenvectors
                 double *slot = ws + b * cvxw::RS_FULL;
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < EPL; ++m)
                     if (w.ok(m)) {
                         park(slot + cvxw::RS_W + w.e(m), W[m]);
                         park(slot + cvxw::RS_Q + w.e(m), w.ej(m) < 9 ? L[Q_QF + w.ei(m) * 10 + w.ej(m)] * tr : 0.0);
                     }
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
-                    if (gl + 16 * m < 27) park(slot + cvxw::RS_B + gl + 16 * m, L[Q_B + gl + 16 * m]);
+                for (int m = 0; m < G_::M27; ++m)
+                    if (gl + LPP * m < 27) park(slot + cvxw::RS_B + gl + LPP * m, L[Q_B + gl + LPP * m]);
                 if (gl < 10) {
 #pragma unroll
                     for (int i = 0; i < 5; ++i) { park(slot + cvxw::RS_V + gl * 10 + 2 * i, (double)v[i].x); park(slot + cvxw::RS_V + gl * 10 + 2 * i + 1, (double)v[i].y); }
@@ -955,31 +1011,33 @@ CVXQ_PH(7); /* projection + update */
 #endif
     // ---------------------------------------------------------------- second phase (wave per problem)
     const unsigned long long pm = __ballot(parked);
-    const unsigned pmask = (unsigned)((pm & 1ull) | ((pm >> 15) & 2ull) | ((pm >> 30) & 4ull) | ((pm >> 45) & 8ull));
+    unsigned pmask = 0;
+#pragma unroll
+    for (int g = 0; g < NPW; ++g) pmask |= (unsigned)((pm >> (LPP * g)) & 1ull) << g;
     if (MODE == 1) { if (gvalid && gl == 0) a.status[b] = cvx::ST_UNCERTIFIED; return; }
     if (pmask) { // wave-uniform
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // every park() acknowledged before the iterate is read back
         CVXW_SYNC();
-        finish_own((QuadArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), pmask, lds_all);
+        finish_own<NPW>((QuadArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), pmask, lds_all);
     }
 #ifdef CVXQ_PHASES
-    if (lane == 0 && a.cost && (int64_t)blockIdx.x * 4 + 3 < a.batch) {
-        double *c = a.cost + 2 * ((int64_t)blockIdx.x * 4);
+    if (lane == 0 && a.cost && (int64_t)blockIdx.x * NPW + 3 < a.batch) {
+        double *c = a.cost + 2 * ((int64_t)blockIdx.x * NPW);
 #pragma unroll
         for (int k = 0; k < 8; ++k) c[k] = (double)ph_[k];
-        if (a.work) { a.work[2 * ((int64_t)blockIdx.x * 4)] = it; a.work[2 * ((int64_t)blockIdx.x * 4) + 1] = total_sweeps; }
+        if (a.work) { a.work[2 * ((int64_t)blockIdx.x * NPW)] = it; a.work[2 * ((int64_t)blockIdx.x * NPW) + 1] = total_sweeps; }
     }
 #endif
 #ifdef CVXQ_TIMELINE
     tl_[3] = tl_now();
-    if (lane == 0 && a.cost && (int64_t)blockIdx.x * 4 + 1 < a.batch) {
+    if (lane == 0 && a.cost && (int64_t)blockIdx.x * NPW + 1 < a.batch) {
         unsigned hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        double *c = a.cost + 2 * ((int64_t)blockIdx.x * 4);
+        double *c = a.cost + 2 * ((int64_t)blockIdx.x * NPW);
         c[0] = (double)tl_[0]; c[1] = (double)tl_[1]; c[2] = (double)tl_[2]; c[3] = (double)tl_[3];
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        if (a.work) { int32_t *wk = a.work + 2 * ((int64_t)blockIdx.x * 4); wk[0] = (int)hw; wk[1] = it; wk[2] = (int)(xcc & 15); }
+        if (a.work) { int32_t *wk = a.work + 2 * ((int64_t)blockIdx.x * NPW); wk[0] = (int)hw; wk[1] = it; wk[2] = (int)(xcc & 15); }
     }
 #endif
 }

@@ -44,8 +44,9 @@ enum {
     CVXPNPL_LAYOUT_LANE = 1, /* one problem per lane, 64 per wavefront, for the first lane_iters iterations;
                                 unfinished problems are then resumed one per wavefront (hybrid schedule) */
     CVXPNPL_LAYOUT_WAVE = 2, /* one problem per wavefront (cooperative lanes) */
-    CVXPNPL_LAYOUT_QUAD = 3  /* one problem per DPP row: 16 lanes, four per wavefront, for the first lane_iters
+    CVXPNPL_LAYOUT_QUAD = 3, /* one problem per DPP row: 16 lanes, four per wavefront, for the first lane_iters
                                 iterations; the wavefront then finishes its unfinished ones itself, one at a time */
+    CVXPNPL_LAYOUT_PENTA = 4 /* the same schedule with 12 lanes per problem, five per wavefront */
 };
 
 /* constraint sets of the relaxation */

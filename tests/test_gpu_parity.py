@@ -39,7 +39,7 @@ def _solve(gpu, d, n_p, n_l, **kw):
 
 CASES = [(10, 0, 0.0, 256), (10, 0, 2.0, 256), (5, 5, 0.0, 128), (5, 5, 1.0, 128), (0, 6, 1.0, 64), (6, 0, 1.0, 64), (4, 0, 1.0, 64),
          (20, 9, 1.0, 67)]  # the last one: 38 records = more than one staging chunk in every layout, ragged batch
-LAYOUTS = {"lane": 1, "wave": 2, "quad": 3}  # CVXPNPL_LAYOUT_*
+LAYOUTS = {"lane": 1, "wave": 2, "quad": 3, "penta": 4}  # CVXPNPL_LAYOUT_* (penta: the quad schedule with 12 lanes per problem)
 
 
 _ORACLE_CACHE = {}
@@ -203,7 +203,7 @@ def test_hybrid_lane_then_wave_schedule(gpu):
 
     d = synth.make_pnpl(3000, 5, 5, 1.0, seed=31)
     ref = _solve(gpu, d, 5, 5, layout=LAYOUTS["wave"])
-    for layout, li in (("lane", 3), ("lane", 4), ("lane", 5), ("lane", 0), ("quad", 3), ("quad", 6), ("quad", 12)):
+    for layout, li in (("lane", 3), ("lane", 4), ("lane", 5), ("lane", 0), ("quad", 3), ("quad", 6), ("quad", 12), ("penta", 0), ("penta", 4)):
         r = _solve(gpu, d, 5, 5, layout=LAYOUTS[layout], lane_iters=li)
         assert (r["status"] == ref["status"]).mean() > 0.995, (layout, li)
         both = (r["status"] == 0) & (ref["status"] == 0)
@@ -217,7 +217,7 @@ def test_hybrid_lane_then_wave_schedule(gpu):
     # minimal problems: many hand-offs, uncertifiable ones included
     d4 = synth.make_pnp(2000, 4, 1.0, seed=9)
     a = _solve(gpu, d4, 4, 0, layout=LAYOUTS["wave"], max_iters=300)
-    for layout in ("lane", "quad"):
+    for layout in ("lane", "quad", "penta"):
         b = _solve(gpu, d4, 4, 0, layout=LAYOUTS[layout], lane_iters=5 if layout == "lane" else 6, max_iters=300)
         assert (a["status"] == b["status"]).mean() > 0.97, layout
         both = (a["status"] == 0) & (b["status"] == 0)
@@ -427,8 +427,8 @@ def test_hybrid_queue_counters_alternate_between_launches(gpu):
     plain = synth.make_pnp(1500, 10, 1.0, seed=22)
     bigger = synth.make_pnp(4100, 6, 1.0, seed=23)
     ref = {id(d): _solve(gpu, d, d["pts_3d"].shape[1], 0, layout=LAYOUTS["wave"], max_iters=300) for d in (planar, plain, bigger)}
-    seq = [(planar, "quad"), (plain, "quad"), (planar, "lane"), (planar, "quad"), (bigger, "lane"), (plain, "quad"), (bigger, "quad"),
-           (planar, "quad"), (planar, "quad")]
+    seq = [(planar, "quad"), (plain, "quad"), (planar, "lane"), (planar, "quad"), (bigger, "lane"), (plain, "penta"), (bigger, "quad"),
+           (planar, "penta"), (planar, "quad"), (bigger, "penta")]
     for d, layout in seq:
         r = _solve(gpu, d, d["pts_3d"].shape[1], 0, layout=LAYOUTS[layout], max_iters=300)
         w = ref[id(d)]
@@ -542,7 +542,7 @@ def test_planar_scene_returns_both_poses_through_dropin_api(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("layout", [1, 2, 3])
+@pytest.mark.parametrize("layout", [1, 2, 3, 4])
 def test_planar_batch_is_certified_two_fold_in_few_iterations(gpu, orc, layout):
     """Planar scenes are exactly two-fold ambiguous for the relaxation (R and R diag(-1,-1,1) have the
     same cost), so the solution is rank 2 (cvxpnpl.py:509-545).  The parity-even dual correction
@@ -590,7 +590,7 @@ def test_planar_batch_is_certified_two_fold_in_few_iterations(gpu, orc, layout):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("layout", [1, 2, 3])
+@pytest.mark.parametrize("layout", [1, 2, 3, 4])
 def test_planar_scene_in_a_general_frame(gpu, layout):
     """A plane that is not Z = 0 (random plane, random offset per problem): the kernels detect the direction the
     cost is blind to and solve in the frame whose third axis it is (the first phase of the hybrid schedules

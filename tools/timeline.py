@@ -26,11 +26,13 @@ torch.cuda.synchronize()
 pit = res.iters.cpu().numpy()
 c = res.cost.cpu().numpy().reshape(-1)
 w = res.work.cpu().numpy().reshape(-1)
-nw = (batch + 3) // 4
-T = np.stack([c[8 * i: 8 * i + 4] for i in range(nw) if 8 * i + 4 <= len(c)])
-its = np.array([w[8 * i + 1] for i in range(len(T))])
-hw = np.array([w[8 * i] for i in range(len(T))]).astype(np.uint32)
-xcc = np.array([w[8 * i + 2] for i in range(len(T))]).astype(np.int64)
+npw = 5 if layout == 4 else 4  # problems per wavefront: quad 4, penta 5
+nw = (batch + npw - 1) // npw
+st_ = 2 * npw
+T = np.stack([c[st_ * i: st_ * i + 4] for i in range(nw) if st_ * i + 4 <= len(c)])
+its = np.array([w[st_ * i + 1] for i in range(len(T))])
+hw = np.array([w[st_ * i] for i in range(len(T))]).astype(np.uint32)
+xcc = np.array([w[st_ * i + 2] for i in range(len(T))]).astype(np.int64)
 T -= T[:, 0].min()
 clk = 100e6  # s_memrealtime: the 100 MHz reference clock, common to the whole device
 us = T / clk * 1e6
@@ -41,7 +43,10 @@ out = {"batch": batch, "lane_iters": li, "waves": len(T), "span_us": float(us[:,
        "assembly_us_median": float(np.median(us[:, 1] - us[:, 0])), "quadloop_us_median": float(np.median(us[:, 2] - us[:, 1])),
        "tail_us_max": float((us[:, 3] - us[:, 2]).max()), "n_with_tail": int(((us[:, 3] - us[:, 2]) > 1.0).sum()),
        "iters_hist": np.bincount(its.clip(0, 20)).tolist(),
-       "slowest_waves": [{"block": int(i), "start": float(us[i, 0]), "quad_end": float(us[i, 2]), "end": float(us[i, 3]), "it": int(its[i]), "iters": pit[4 * i: 4 * i + 4].tolist()} for i in np.argsort(-us[:, 3])[:12]]}
+       "slowest_waves": [{"block": int(i), "start": float(us[i, 0]), "quad_end": float(us[i, 2]), "end": float(us[i, 3]), "it": int(its[i]), "iters": pit[npw * i: npw * i + npw].tolist()} for i in np.argsort(-us[:, 3])[:12]]}
+first = np.where(us[:, 0] < 10.0)[0]  # wavefronts of the first round
+out["slowest_first_round"] = [{"block": int(i), "start": float(us[i, 0]), "quad_end": float(us[i, 2]), "end": float(us[i, 3]), "iters": pit[npw * i: npw * i + npw].tolist()}
+                              for i in first[np.argsort(-us[first, 3])[:8]]]
 # resident waves over time
 grid = np.linspace(0, us[:, 3].max(), 41)
 out["resident_waves"] = [int(((us[:, 0] <= g) & (us[:, 3] > g)).sum()) for g in grid]
