@@ -72,7 +72,7 @@ for c, (kind, n_p, n_l, sigma) in enumerate(CONFIGS):
                        d["line_3d"] if n_l else None, d["K"], eps=1e-11, max_iters=200000)
     line = f"{kind:14s} n_p {n_p:2d} n_l {n_l:2d} sigma {sigma:4.1f}: oracle 1-pose {np.mean(o['n_poses'] == 1):.2f} |"
     ref_st = None
-    for name, layout in (("wave", 2), ("quad", 3), ("lane", 1)):
+    for name, layout in (("wave", 2), ("quad", 3), ("lane", 1), ("penta", 4)):
         r = ca.pnpl_batch(tt(d["pts_2d"]) if n_p else None, tt(d["line_2d"]) if n_l else None, tt(d["pts_3d"]) if n_p else None,
                           tt(d["line_3d"]) if n_l else None, tt(d["K"]), layout=layout)
         st = r.status.cpu().numpy()

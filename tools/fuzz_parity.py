@@ -35,7 +35,7 @@ for c in range(ncfg):
     o = orc.pnpl_batch(d["pts_2d"] if n_p else None, d["line_2d"] if n_l else None, d["pts_3d"] if n_p else None,
                        d["line_3d"] if n_l else None, d["K"], eps=1e-11, max_iters=200000)
     line = f"cfg {c:2d} {kind:4s} n_p {n_p:2d} n_l {n_l:2d} sigma {sigma:3.1f}:"
-    for name, layout in (("wave", 2), ("quad", 3), ("lane", 1)):
+    for name, layout in (("wave", 2), ("quad", 3), ("lane", 1), ("penta", 4)):
         r = ca.pnpl_batch(tt(d["pts_2d"]) if n_p else None, tt(d["line_2d"]) if n_l else None, tt(d["pts_3d"]) if n_p else None,
                           tt(d["line_3d"]) if n_l else None, tt(d["K"]), layout=layout)
         st = r.status.cpu().numpy()
@@ -49,6 +49,6 @@ for c in range(ncfg):
         tot += nprob; cert += int((st == 0).sum()); cmp_ += int(ok.sum()); mism += bad
         line += f" {name} cert {np.mean(st == 0):.3f} rot {g:.1e} t {e:.1e}" + (f" MISMATCH {bad}" if bad else "")
     print(line, flush=True)
-print(f"summary: {ncfg} configurations x {nprob} problems x 3 layouts = {tot} solves, {cert} certified, {cmp_} compared with a "
+print(f"summary: {ncfg} configurations x {nprob} problems x 4 layouts = {tot} solves, {cert} certified, {cmp_} compared with a "
       f"converged single-pose oracle solve, {mism} beyond 1e-6; worst rotation {worst['rot']:.2e} rad, worst relative "
       f"translation {worst['t']:.2e}; {time.time() - t0:.0f} s")
