@@ -282,7 +282,7 @@ __device__ __forceinline__ double coop_round(const double *v, double *R)
 #pragma unroll
         for (int i = 0; i < 9; ++i) X[i] = -X[i];
     }
-    cvx::polar3(X, R, 8);
+    cvx::near_rotation(X, R);
     return d0;
 }
 
@@ -1267,12 +1267,14 @@ __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx
 }
 
 // Second phase of the hybrid schedules: the problems the first kernel parked, one wavefront each.  The queue is
-// self-cleaning: entries[] is -1 wherever nothing is queued; the first kernel appends problem indices at
-// atomicAdd(count) positions, a resume block walks q = blockIdx.x, + gridDim.x, ... until it meets a -1, and
-// puts -1 back over every entry it consumes; block 0 zeroes the counter (no block of this kernel reads it).
-// So every launch leaves the queue as it found it -- no host-side bookkeeping, no memset per launch, nothing
-// that a failed launch or a hipGraph replay could desynchronise -- and every index is range checked, so a
-// corrupted workspace cannot turn into an out-of-bounds write.  entries[] has RESUME_GRID_MAX spare slots.
+// self-cleaning: entries[] is -1 wherever nothing is queued and the three counters (count[0]: positions filled by the first
+// kernel, count[1]: positions drawn, count[2]: blocks that have left) are zero between launches.  The first kernel appends problem
+// indices at atomicAdd(count[0]) positions; resume block i owns position i and, when that is done, draws further positions from
+// count[1] (dynamic: a slow problem does not hold up a fixed share of the queue) until it meets a -1; it puts -1 back over every
+// entry it consumes, and the last block to leave zeroes the counters.  A block whose own position is empty leaves at once without
+// touching anything -- with an empty queue (most launches) that is every block.  So every launch leaves the queue as it found it --
+// no host-side bookkeeping, no memset per launch, nothing a hipGraph replay could desynchronise -- and every index is range
+// checked, so a corrupted workspace cannot turn into an out-of-bounds write.  entries[] has RESUME_GRID_MAX spare slots.
 constexpr int RESUME_GRID_MAX = 2048; // one block per resident wavefront slot: more blocks only add launch time to the (usual) empty-queue case
 // A block whose first queue slot is empty (every block of most launches) leaves after one load: the arguments of the
 // solve are read from the kernarg segment only behind that test, so that nothing is live -- and nothing spilled -- before
@@ -1294,6 +1296,8 @@ __device__ __forceinline__ void resume_body(ResumeArgsPtr kp, int32_t first, dou
     const WaveArgs a = kp->a;
     const cvx::Opts o = kp->o;
     int32_t *entries = kp->entries;
+    int32_t *count_p = kp->count_p;
+    const int pushed = __hip_atomic_load(count_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (stable until the last block resets it)
     const double *ws = kp->ws;
     const int stride = kp->ws_stride;
     const bool full = kp->ws_full != 0;
@@ -1304,10 +1308,23 @@ __device__ __forceinline__ void resume_body(ResumeArgsPtr kp, int32_t first, dou
             solve_one_wave(a, o, b, lds, ws + (int64_t)b * stride, full);
             CVXW_SYNC();
         }
-        q += gridDim.x;
-        if (q >= a.batch + RESUME_GRID_MAX) break;
-        b = entries[q];
-        if (b < 0) break;
+        // The next position nobody has taken yet: blocks own the positions below gridDim.x by index and DRAW the ones behind them
+        // from count_p[1] -- a wavefront that got a 40-iteration problem must not also own every 2048th entry behind it.
+        int pn = 0;
+        if ((threadIdx.x & 63) == 0) pn = atomicAdd(count_p + 1, 1);
+        q = (int64_t)gridDim.x + __builtin_amdgcn_readfirstlane(pn);
+        b = q < a.batch + RESUME_GRID_MAX ? entries[q] : -1;
+        if (b < 0) break; // an empty position: the queue is exhausted -- every drawing block ends with exactly one such draw
+    }
+    // The last block to leave puts the counters back to zero for the next launch (pushed = positions the first kernel filled; the
+    // blocks that draw are the ones whose own position was filled: min(pushed, gridDim.x) of them).
+    if ((threadIdx.x & 63) == 0) {
+        const int drawing = pushed < (int)gridDim.x ? pushed : (int)gridDim.x;
+        if (atomicAdd(count_p + 2, 1) == drawing - 1) {
+            __hip_atomic_store(count_p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(count_p + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(count_p + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 #endif
 }
@@ -1315,7 +1332,6 @@ __device__ __forceinline__ void resume_body(ResumeArgsPtr kp, int32_t first, dou
 __global__ void __launch_bounds__(64, 2) resume_wave_kernel(ResumeArgs k)
 {
     __shared__ __attribute__((aligned(16))) double lds_all[LDSW];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *k.count_p = 0;
     const int32_t first = k.entries[blockIdx.x];
     if (first < 0) return;
     resume_body((ResumeArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), first, lds_all);
