@@ -209,7 +209,7 @@ void cvxpnpl_default_opts(cvxpnpl_opts_t *opts)
 {
     cvx::Opts o = cvx::default_opts();
     opts->eps = o.eps; opts->max_iters = o.max_iters; opts->rho = o.rho; opts->alpha = o.alpha;
-    opts->first_check = o.first_check; opts->check_every = o.check_every; opts->res_tol = o.res_tol;
+    opts->first_check = 0 /* by layout, see cvxpnpl_amd.h */; opts->check_every = o.check_every; opts->res_tol = o.res_tol;
     opts->jacobi_sweeps = o.jacobi_sweeps; opts->jacobi_tol = o.jacobi_tol; opts->warm_start = o.warm_start; opts->rho_tail = o.rho_tail; opts->tail_from = o.tail_from; opts->lane_iters = -1; opts->layout = CVXPNPL_LAYOUT_AUTO; opts->variant = CVXPNPL_VARIANT_FULL;
     opts->adapt_every = o.adapt_every; opts->adapt_from = o.adapt_from; opts->adapt_mu = o.adapt_mu; opts->adapt_tau = o.adapt_tau;
     opts->stall_from = o.stall_from; opts->stall_lam = o.stall_lam; opts->stall_res = o.stall_res; opts->stall_drop = o.stall_drop;
@@ -230,13 +230,14 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
 {
     const int64_t batch = a.batch;
     if (!a.R || !a.t || !a.status) { snprintf(g_err, sizeof(g_err), "cvxpnpl: R, t and status outputs are required"); return -1; }
-    if (opts && (opts->max_iters < 1 || !(opts->rho > 0) || !(opts->eps > 0) || opts->check_every < 1 || opts->first_check < 1 ||
+    if (opts && (opts->max_iters < 1 || !(opts->rho > 0) || !(opts->eps > 0) || opts->check_every < 1 || opts->first_check < 0 ||
                  (opts->variant != CVXPNPL_VARIANT_FULL && opts->variant != CVXPNPL_VARIANT_RC) || opts->adapt_every < 0 ||
                  (opts->adapt_every > 0 && !(opts->adapt_mu >= 1.0 && opts->adapt_tau > 1.0)))) {
         snprintf(g_err, sizeof(g_err), "cvxpnpl: bad options");
         return -1;
     }
     cvx::Opts o = to_core(opts);
+    if (!opts) o.first_check = 0; // (by layout, below)
     hipStream_t s = (hipStream_t)stream;
     const int block = 64;
     int64_t grid = (batch + block - 1) / block;
@@ -267,6 +268,11 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     const bool penta = layout == CVXPNPL_LAYOUT_PENTA;
     if (layout == 9 || penta) layout = CVXPNPL_LAYOUT_QUAD; // experiment (tools/README.md): quad iterations only, 3 waves/SIMD: quad iterations only (solve_quad_kernel<1>)
     if (layout == CVXPNPL_LAYOUT_QUAD && !(quad_iters >= 1 && o.max_iters > quad_iters)) layout = CVXPNPL_LAYOUT_WAVE;
+    // First certificate attempt (0 = by layout): after 5 iterations 94 % of N = 10 problems certify, after 6 99 %.  In the lane-hybrid
+    // schedule every problem that fails the first attempt is parked and resumed one per wavefront, so the later attempt pays for its
+    // extra iteration: 125 k problems 157 -> 164 M poses/s, PnPL 100 k 116 -> 126 M.  The quad and wave layouts keep 5 (quad: +2.5 % at
+    // 10 k and +4 % at 24 k with 6, but -6 % at 16 k, over 3-6 problem sets each; wave: -12 % at 2 k).
+    if (o.first_check <= 0) o.first_check = layout == CVXPNPL_LAYOUT_LANE ? 6 : 5;
     if (layout == CVXPNPL_LAYOUT_QUAD) {
         // four problems per wavefront for the first quad_iters iterations, survivors resumed one per wavefront
         // (a wavefront finishes its own survivors; only planar scenes, recognised before the first iteration,
@@ -289,14 +295,14 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
         if (wgrid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }
         launch_wave(wgrid, s, w, o);
     } else {
-        // hand-off point of the hybrid schedule (<= 0: default): right after the first certificate attempt, which
-        // comes at iteration 5 (opts.first_check) -- 6 and 7 are slower: 110 / 105 / 100 M poses/s at 125 k.
+        // hand-off point of the hybrid schedule (<= 0: default): right after the first certificate attempt (opts.first_check: 6
+        // by default in this layout) -- later is slower (round 1, first attempt at 5: hand-off at 5 / 6 / 7: 110 / 105 / 100 M at 125 k).
         int lane_iters = opts ? opts->lane_iters : -1;
-        if (lane_iters <= 0) lane_iters = 5;
-        // The lane phase never runs past 5 iterations: from the sixth on the few problems still open are the
+        if (lane_iters <= 0) lane_iters = o.first_check;
+        // The lane phase never runs past 6 iterations: from then on the few problems still open are the
         // slow / ambiguous ones (twin candidates, tails), which belong to the wave-per-problem kernel -- one of
         // them would hold 63 idle lanes, so the lane kernel is built without that logic.
-        if (lane_iters > 5) lane_iters = 5;
+        if (lane_iters > 6) lane_iters = 6;
         if (o.max_iters > lane_iters) {
             // hybrid: lanes for the first lane_iters iterations, survivors resumed one per wavefront
             WsView wv;

@@ -187,13 +187,19 @@ def test_hip_equals_host_build_of_device_algorithm(gpu):
     d = synth.make_pnp(512, 10, 1.0, seed=77)
     hs = hostsim.solve_batch(d["pts_2d"], d["pts_3d"], None, None, d["K"], want_Z=True)
     for layout in LAYOUTS.values():
-        r = _solve(gpu, d, 10, 0, want_Z=True, layout=layout)
+        # first_check = 5 is the host build's schedule; left at its default (0) the library attempts first after 6 iterations in
+        # the lane-hybrid layout (checked at the end)
+        r = _solve(gpu, d, 10, 0, want_Z=True, layout=layout, first_check=5)
         assert (r["status"] == hs["status"]).mean() > 0.99
         same = (r["status"] == 0) & (hs["status"] == 0)
         assert synth.geodesic(r["R"], hs["R"])[same].max() < 1e-10
         assert np.abs(r["t"] - hs["t"])[same].max() < 1e-10
         assert np.abs(r["Z"] - hs["Z"])[same].max() < 1e-9
         assert np.abs(r["iters"] - hs["iters"])[same].mean() < 0.1  # same algorithm, same path
+    dflt = {name: _solve(gpu, d, 10, 0, layout=layout) for name, layout in LAYOUTS.items()}
+    assert dflt["lane"]["iters"].min() == 6 and dflt["wave"]["iters"].min() == 5 and dflt["quad"]["iters"].min() == 5
+    both = (dflt["lane"]["status"] == 0) & (dflt["wave"]["status"] == 0)
+    assert both.mean() > 0.99 and synth.geodesic(dflt["lane"]["R"], dflt["wave"]["R"])[both].max() < 1e-9
 
 
 def test_hybrid_lane_then_wave_schedule(gpu):
@@ -204,7 +210,8 @@ def test_hybrid_lane_then_wave_schedule(gpu):
     d = synth.make_pnpl(3000, 5, 5, 1.0, seed=31)
     ref = _solve(gpu, d, 5, 5, layout=LAYOUTS["wave"])
     for layout, li in (("lane", 3), ("lane", 4), ("lane", 5), ("lane", 0), ("quad", 3), ("quad", 6), ("quad", 12), ("penta", 0), ("penta", 4)):
-        r = _solve(gpu, d, 5, 5, layout=LAYOUTS[layout], lane_iters=li)
+        # (first_check = 5 for all: the iteration counts are compared; by default the lane layout attempts first after 6)
+        r = _solve(gpu, d, 5, 5, layout=LAYOUTS[layout], lane_iters=li, first_check=5)
         assert (r["status"] == ref["status"]).mean() > 0.995, (layout, li)
         both = (r["status"] == 0) & (ref["status"] == 0)
         assert both.mean() > 0.99
