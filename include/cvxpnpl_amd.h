@@ -70,8 +70,8 @@ typedef struct {
     double rho_tail;    /* penalty from iteration tail_from on (dual rescaled at the switch), default 0.05 */
     int32_t tail_from;  /* default 3; <= 0 never */
     int32_t lane_iters; /* lane and quad layouts: iterations before unfinished problems are handed to one
-                           wavefront each (hybrid schedule).  <= 0: default (lane: 5;
-                           quad: 10).  The lane phase is capped at 5 iterations. */
+                           wavefront each (hybrid schedule).  <= 0: default (lane: first_check, i.e. right after the
+                           first attempt; quad: 7).  The lane phase is capped at 6 iterations, the quad phase at 16. */
     int32_t layout;    /* CVXPNPL_LAYOUT_* */
     int32_t variant;   /* CVXPNPL_VARIANT_*, default FULL */
     int32_t adapt_every; /* residual balancing of the penalty for long solves: every this many iterations (default 10; 0 never) */
