@@ -650,6 +650,11 @@ def test_ransac_default_device_and_workspace_entry_points(gpu):
         for layout in ("quad", "lane", "quad"):
             r = _solve(gpu, dd, 8, 0, layout=LAYOUTS[layout], max_iters=200)
             assert (r["status"] == ref["status"]).mean() > 0.995
+            # the queue is self-cleaning: its three counters are back at zero and every entry at -1 after each launch
+            head = buf[:256].view(torch.int32).cpu().numpy()
+            assert (head[:3] == 0).all(), head[:3]
+            entries = buf[256:256 + 4 * (700 + 2048)].view(torch.int32).cpu().numpy()
+            assert (entries == -1).all()
         with pytest.raises(RuntimeError, match="workspace"):
             _solve(gpu, big, 6, 0, layout=LAYOUTS["quad"])
     finally:
