@@ -270,8 +270,9 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     if (layout == CVXPNPL_LAYOUT_QUAD && !(quad_iters >= 1 && o.max_iters > quad_iters)) layout = CVXPNPL_LAYOUT_WAVE;
     // First certificate attempt (0 = by layout): after 5 iterations 94 % of N = 10 problems certify, after 6 99 %.  In the lane-hybrid
     // schedule every problem that fails the first attempt is parked and resumed one per wavefront, so the later attempt pays for its
-    // extra iteration: 125 k problems 157 -> 164 M poses/s, PnPL 100 k 116 -> 126 M.  The quad and wave layouts keep 5 (quad: +2.5 % at
-    // 10 k and +4 % at 24 k with 6, but -6 % at 16 k, over 3-6 problem sets each; wave: -12 % at 2 k).
+    // extra iteration: 125 k problems 157 -> 164 M poses/s, PnPL 100 k 116 -> 126 M.  The quad and wave layouts keep 5 (quad with 6, launch
+    // time relative to 5 over 4 problem sets per size: 3 k 0.93, 5 k 1.07, 8 k 1.02, 10 k 0.98, 12 k 1.07, 16 k 1.03, 20 k 1.02, 24 k 0.97;
+    // wave: -12 % at 2 k).
     if (o.first_check <= 0) o.first_check = layout == CVXPNPL_LAYOUT_LANE ? 6 : 5;
     if (layout == CVXPNPL_LAYOUT_QUAD) {
         // four problems per wavefront for the first quad_iters iterations, survivors resumed one per wavefront
