@@ -88,8 +88,9 @@ __global__ void __launch_bounds__(64) assemble_kernel(BatchArgs a, double *Bout,
         for (int i = 0; i < 45; ++i) Qout[b * 45 + i] = ok ? Q9[i] : NAN;
 }
 
-// Scratch of the hybrid schedules, one per (device, stream): [0, 256) the queue counter, then the queue entries
-// (int32, -1 = empty; batch + RESUME_GRID_MAX of them) and the parked iterates [batch][56] doubles (only the
+// Scratch of the hybrid schedules, one per (device, stream): [0, 256) the counters of the two queues (resume: ints 0..2,
+// rescue: ints 16..18), then the entries of the resume queue and of the rescue queue
+// (int32, -1 = empty; batch + RESUME_GRID_MAX of them each) and the parked iterates [batch][56] doubles (only the
 // slots of parked problems are touched).  Either the library's own allocation (grow-only while in use, freed by
 // cvxpnpl_release_workspace) or memory the caller registered with cvxpnpl_set_workspace (e.g. from torch's
 // caching allocator).  The queue is self-cleaning (cvxw::resume_wave_kernel): it is initialised once.
@@ -101,12 +102,13 @@ std::mutex g_ws_mutex;
 std::map<std::pair<int, void *>, Workspace> g_ws;
 thread_local char g_err[512] = "";
 
-size_t hybrid_queue_bytes(int64_t cap) { return 256 + (((size_t)(cap + cvxw::RESUME_GRID_MAX) * sizeof(int32_t) + 255) & ~(size_t)255); }
+size_t queue_entries_bytes(int64_t cap) { return ((size_t)(cap + cvxw::RESUME_GRID_MAX) * sizeof(int32_t) + 255) & ~(size_t)255; }
+size_t hybrid_queue_bytes(int64_t cap) { return 256 + 2 * queue_entries_bytes(cap); }
 size_t hybrid_ws_bytes(int64_t cap) { return hybrid_queue_bytes(cap) + (size_t)cap * cvxw::RS_FULL * sizeof(double); } // any schedule
 int64_t hybrid_capacity(size_t bytes) // largest capacity whose layout fits (any schedule)
 {
     if (bytes < hybrid_ws_bytes(1)) return 0;
-    int64_t cap = (int64_t)(bytes / (sizeof(int32_t) + cvxw::RS_FULL * sizeof(double))) + 1; // an upper bound, then down to the first fit
+    int64_t cap = (int64_t)(bytes / (2 * sizeof(int32_t) + cvxw::RS_FULL * sizeof(double))) + 1; // an upper bound, then down to the first fit
     while (cap > 0 && hybrid_ws_bytes(cap) > bytes) --cap;
     return cap;
 }
@@ -118,7 +120,7 @@ bool init_workspace(void *p, int64_t cap, void *stream)
     return hipMemsetAsync(p, 0, 256, (hipStream_t)stream) == hipSuccess;
 }
 
-struct WsView { int32_t *count, *entries; double *parked; };
+struct WsView { int32_t *count, *entries, *rq_count, *rq_entries; double *parked; };
 
 bool get_workspace(int64_t batch, int stride, void *stream, WsView &v)
 {
@@ -148,6 +150,8 @@ bool get_workspace(int64_t batch, int stride, void *stream, WsView &v)
     }
     v.count = (int32_t *)w.ptr;
     v.entries = (int32_t *)((char *)w.ptr + 256);
+    v.rq_count = v.count + 16;
+    v.rq_entries = (int32_t *)((char *)w.ptr + 256 + queue_entries_bytes(w.cap));
     v.parked = (double *)((char *)w.ptr + hybrid_queue_bytes(w.cap));
     return true;
 }
@@ -163,7 +167,20 @@ void launch_resume(int64_t rgrid, hipStream_t s, const cvxw::WaveArgs &w, const 
     cvxw::ResumeArgs ra;
     ra.a = w; ra.o = o; ra.count_p = count; ra.entries = entries; ra.ws = ws;
     ra.ws_stride = full ? cvxw::RS_FULL : cvxw::RS_LANE; ra.ws_full = full ? 1 : 0;
+    ra.count2 = nullptr; ra.entries2 = nullptr; ra.grid1 = 0;
     hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64), 0, s, ra);
+}
+
+// last launch of a solve with opts.rescue_from in force: the problems the other kernels gave up on (w.rq_count / w.rq_entries) and,
+// in the quad layout (count != null), the parked problems of the resume queue as well -- one launch for both
+void launch_rescue(int64_t batch, hipStream_t s, const cvxw::WaveArgs &w, const cvx::Opts &o, int32_t *count = nullptr, int32_t *entries = nullptr,
+                   const double *ws = nullptr)
+{
+    const int64_t rgrid = batch < cvxw::RESUME_GRID_MAX ? batch : cvxw::RESUME_GRID_MAX;
+    cvxw::ResumeArgs ra;
+    ra.a = w; ra.o = o; ra.count_p = w.rq_count; ra.entries = w.rq_entries; ra.ws = ws; ra.ws_stride = cvxw::RS_FULL; ra.ws_full = 1;
+    ra.count2 = count; ra.entries2 = entries; ra.grid1 = (int)rgrid;
+    hipLaunchKernelGGL(cvxw::rescue_wave_kernel, dim3((unsigned)(count ? 2 * rgrid : rgrid)), dim3(64), 0, s, ra);
 }
 
 int set_err(const char *what, hipError_t e)
@@ -182,6 +199,7 @@ cvx::Opts to_core(const cvxpnpl_opts_t *opts)
         o.variant = opts->variant;
         o.adapt_every = opts->adapt_every; o.adapt_from = opts->adapt_from; o.adapt_mu = opts->adapt_mu; o.adapt_tau = opts->adapt_tau;
         o.stall_from = opts->stall_from; o.stall_lam = opts->stall_lam; o.stall_res = opts->stall_res; o.stall_drop = opts->stall_drop;
+        o.rescue_from = opts->rescue_from;
     }
     return o;
 }
@@ -213,6 +231,7 @@ void cvxpnpl_default_opts(cvxpnpl_opts_t *opts)
     opts->jacobi_sweeps = o.jacobi_sweeps; opts->jacobi_tol = o.jacobi_tol; opts->warm_start = o.warm_start; opts->rho_tail = o.rho_tail; opts->tail_from = o.tail_from; opts->lane_iters = -1; opts->layout = CVXPNPL_LAYOUT_AUTO; opts->variant = CVXPNPL_VARIANT_FULL;
     opts->adapt_every = o.adapt_every; opts->adapt_from = o.adapt_from; opts->adapt_mu = o.adapt_mu; opts->adapt_tau = o.adapt_tau;
     opts->stall_from = o.stall_from; opts->stall_lam = o.stall_lam; opts->stall_res = o.stall_res; opts->stall_drop = o.stall_drop;
+    opts->rescue_from = o.rescue_from;
 }
 
 static int check_args(int64_t batch, int32_t n_p, const double *p2, const double *p3, int32_t n_l, const double *l2,
@@ -232,7 +251,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     if (!a.R || !a.t || !a.status) { snprintf(g_err, sizeof(g_err), "cvxpnpl: R, t and status outputs are required"); return -1; }
     if (opts && (opts->max_iters < 1 || !(opts->rho > 0) || !(opts->eps > 0) || opts->check_every < 1 || opts->first_check < 0 ||
                  (opts->variant != CVXPNPL_VARIANT_FULL && opts->variant != CVXPNPL_VARIANT_RC) || opts->adapt_every < 0 ||
-                 (opts->adapt_every > 0 && !(opts->adapt_mu >= 1.0 && opts->adapt_tau > 1.0)))) {
+                 (opts->adapt_every > 0 && !(opts->adapt_mu >= 1.0 && opts->adapt_tau > 1.0)) || opts->rescue_from < 0)) {
         snprintf(g_err, sizeof(g_err), "cvxpnpl: bad options");
         return -1;
     }
@@ -262,6 +281,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     w.p2 = a.p2; w.p3 = a.p3; w.l2 = a.l2; w.l3 = a.l3; w.K = a.K;
     w.R = a.R; w.t = a.t; w.cost = a.cost; w.Z = a.Z; w.status = a.status; w.iters = a.iters; w.work = a.work;
     w.Q45 = a.Q45; w.B27 = a.B27;
+    w.rq_count = nullptr; w.rq_entries = nullptr;
     int quad_iters = opts ? opts->lane_iters : -1;
     if (quad_iters <= 0) quad_iters = 7; // measured (4 problem sets at 10 k, same box): 5: 0.242 ms, 7: 0.233, 8: 0.235, 10: 0.240; 24 k: 7 = 10 (round 1, second phase as a call: 8-12)
     if (quad_iters > 16) quad_iters = 16; // the quad phase runs its eigen-solve sweeps in single precision: fine for the first iterations, not for a slow tail (quad_kernel.h)
@@ -274,6 +294,14 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     // time relative to 5 over 4 problem sets per size: 3 k 0.93, 5 k 1.07, 8 k 1.02, 10 k 0.98, 12 k 1.07, 16 k 1.03, 20 k 1.02, 24 k 0.97;
     // wave: -12 % at 2 k).
     if (o.first_check <= 0) o.first_check = layout == CVXPNPL_LAYOUT_LANE ? 6 : 5;
+    // interior-point path for the problems still open after rescue_from iterations (ipm_wave.h): its queue lives in the workspace
+    const bool rescue = o.variant == cvx::VAR_FULL && o.rescue_from > 0 && o.max_iters > o.rescue_from;
+    if (rescue) {
+        WsView wv;
+        const bool hybrid = layout == CVXPNPL_LAYOUT_QUAD || (layout == CVXPNPL_LAYOUT_LANE && o.max_iters > 1);
+        if (!get_workspace(batch, layout == CVXPNPL_LAYOUT_QUAD ? cvxw::RS_FULL : (hybrid ? cvxw::RS_LANE : 0), stream, wv)) return -2;
+        w.rq_count = wv.rq_count; w.rq_entries = wv.rq_entries;
+    }
     if (layout == CVXPNPL_LAYOUT_QUAD) {
         // four problems per wavefront for the first quad_iters iterations, survivors resumed one per wavefront
         // (a wavefront finishes its own survivors; only planar scenes, recognised before the first iteration,
@@ -290,7 +318,8 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
         else if (penta) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 12>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         const int64_t rgrid = batch < cvxw::RESUME_GRID_MAX ? batch : cvxw::RESUME_GRID_MAX;
-        launch_resume(rgrid, s, w, o, count, entries, ws, true);
+        if (rescue) launch_rescue(batch, s, w, o, count, entries, ws); // (both queues in one launch)
+        else launch_resume(rgrid, s, w, o, count, entries, ws, true);
     } else if (layout == CVXPNPL_LAYOUT_WAVE) {
         int64_t wgrid = (batch + cvxw::WPB - 1) / cvxw::WPB;
         if (wgrid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }
@@ -319,6 +348,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
             launch_wave(wgrid, s, w, o);
         }
     }
+    if (rescue && layout != CVXPNPL_LAYOUT_QUAD) launch_rescue(batch, s, w, o);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err("solve kernel launch", e);
     return 0;

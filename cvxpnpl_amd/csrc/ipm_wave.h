@@ -1,0 +1,345 @@
+// ipm_wave.h -- the interior-point solve of ipm_core.h with the 64 lanes of one wavefront working on ONE problem.
+//
+// cvxw::solve_one_wave calls this once for a problem that is still open after opts.rescue_from first-order iterations
+// (minimal and near-ambiguous configurations need hundreds to thousands of them, and a launch lasts as long as its slowest
+// problem): ~12 second-order iterations of ~20 us each whatever the conditioning, then the Douglas-Rachford iteration goes on
+// from W = Z - S / rho -- whose positive part is Z and whose dual hint rho (W+ - W) is S -- so that the usual attempt
+// (rounding, Newton polish, dual certificate, twin logic for rank 2, the reference's recovery) finishes the problem one
+// iteration later.  Same mathematics as cvx::ipm_solve (HKM direction, Mehrotra predictor-corrector, feasible start);
+// what is different is the step length: six candidate steps are Cholesky-tested side by side (one ten-lane group each).
+// All matrices are full 10 x 10 (row-major) / 21 x 21 in LDS; nothing of the first-order solver's LDS state survives
+// except the translation map and the canonical frame, which lie outside [0, 684) u [908, LDSW).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ipm_core.h" // (the scalar statement of the same solve; host-tested, and the constraint tables)
+
+namespace cvxw {
+
+#ifdef CVXW_IPM_CLOCK // diagnostic build (tools/ipm_clock.py): 100 MHz ticks per stage of the solve, summed at L[I_COL + 100 + stage]
+#define IPM_CLK(k) do { const long long now_ = wall_clock64(); if (lane == 0) L[I_COL + 100 + (k)] += (double)(now_ - clk_); clk_ = now_; } while (0)
+#else
+#define IPM_CLK(k) do { } while (0)
+#endif
+
+constexpr int I_Z = 0, I_S = 100, I_SI = 200, I_DZ = 300, I_DS = 400, I_RC = 500, I_DY = 600, I_RHS = 624;               // [0, 684)
+constexpr int I_M = 908, I_T1 = 1350, I_T2 = 1450, I_TEST = 1550, I_COL = 2150, I_TAB = 2272;                            // [908, 2304)
+constexpr int I_QS = I_T1, I_W = I_M; // hand-over between cvxw::solve_pass and the solve: cost in (64), iterate out (55)
+constexpr int LDS_IPM_END = 2304;
+static_assert(LDS_IPM_END <= LDSW_IPM, "the interior-point solve needs LDSW_IPM doubles per wavefront");
+
+struct IpmTab { signed char r[21][3], c[21][3], s[21][3]; signed char ent_con[55], ent_sgn[55]; };
+constexpr IpmTab make_ipm_tab()
+{
+    IpmTab t{};
+    for (int i = 0; i < 21; ++i)
+        for (int k = 0; k < 3; ++k) {
+            int r = 9, c = 9, s = 0;
+            if (i < 15) { r = cvx::tri_i(i, k); c = cvx::tri_j(i, k); s = cvx::tri_s(i, k) < 0 ? -1 : 1; }
+            else if (i < 18) { r = c = 3 * k + (i - 15); s = 1; }
+            else if (i < 20) { r = c = 3 * (i - 18) + k; s = 1; }
+            else { r = c = 9; s = k == 0 ? 1 : 0; }
+            t.r[i][k] = (signed char)r; t.c[i][k] = (signed char)c; t.s[i][k] = (signed char)s;
+        }
+    for (int e = 0; e < 55; ++e) { t.ent_con[e] = -1; t.ent_sgn[e] = 0; }
+    for (int i = 0; i < 15; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const int e = cvx::sidx(cvx::tri_i(i, k), cvx::tri_j(i, k));
+            t.ent_con[e] = (signed char)i;
+            t.ent_sgn[e] = (signed char)(cvx::tri_s(i, k) < 0 ? -1 : 1);
+        }
+    return t;
+}
+constexpr bool ipm_tab_ok()
+{
+    const IpmTab t = make_ipm_tab();
+    int hit[55] = {};
+    for (int i = 0; i < 15; ++i)
+        for (int k = 0; k < 3; ++k) {
+            if (cvx::tri_i(i, k) == cvx::tri_j(i, k)) return false;
+            ++hit[cvx::sidx(cvx::tri_i(i, k), cvx::tri_j(i, k))];
+        }
+    for (int e = 0; e < 55; ++e)
+        if (hit[e] > 1) return false;
+    return t.ent_con[0] == -1;
+}
+static_assert(ipm_tab_ok(), "coop_ipm builds dS entry-wise: every off-diagonal entry belongs to at most one of the 15 triples");
+__device__ const IpmTab kIpmTab = make_ipm_tab();
+
+// Cholesky of the n x n matrix at A (row stride ld, lower triangle, in place) by n lanes, one row each (`mine`; several groups
+// of lanes may factor different matrices side by side); `col` is n doubles of scratch per group.  Every lane of the wavefront must
+// call (wave-uniform syncs).  Returns false in the lanes of a group whose matrix is not positive definite (the factor is then
+// garbage).  (A variant with the rows in registers and one published column per step was slower: it spilled.)
+template <int N>
+__device__ __forceinline__ bool coop_chol(double *A, int ld, double *col, int row, bool mine)
+{
+    constexpr int n = N;
+    bool ok = true;
+    for (int j = 0; j < n; ++j) {
+        if (mine && row >= j) {
+            // fixed trip count with a select instead of `k < j` as the loop bound: all 2 N loads are in flight together (with the
+            // bound in the loop every multiply-add waited for its own pair of loads: 26 000 cycles for N = 21)
+            double s0 = A[row * ld + j], s1 = 0.0;
+#pragma unroll
+            for (int k = 0; k + 1 < N; k += 2) {
+                const double p0 = A[row * ld + k] * A[j * ld + k], p1 = A[row * ld + k + 1] * A[j * ld + k + 1];
+                s0 -= k < j ? p0 : 0.0;
+                s1 -= k + 1 < j ? p1 : 0.0;
+            }
+            if (N & 1) { const double p0 = A[row * ld + N - 1] * A[j * ld + N - 1]; s0 -= N - 1 < j ? p0 : 0.0; }
+            col[row] = s0 + s1;
+        }
+        CVXW_SYNC();
+        const double d = mine ? col[j] : 1.0;
+        ok = ok && (d > 0.0);
+        const double il = cvx::rsqrt_(d > 0.0 ? d : 1.0);
+        CVXW_SYNC();
+        if (mine && row >= j) A[row * ld + j] = col[row] * il; // (row == j: d / sqrt(d) = sqrt(d))
+        CVXW_SYNC();
+    }
+    CVXW_SYNC();
+    return ok;
+}
+
+// C = A B for 10 x 10 matrices in LDS (entries e and e + 64 per lane)
+__device__ __forceinline__ void coop_mul10(const double *A, const double *B, double *C, int lane)
+{
+    for (int e = lane; e < 100; e += 64) {
+        const int i = e / 10, j = e % 10;
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) s += A[i * 10 + k] * B[k * 10 + j];
+        C[e] = s;
+    }
+    CVXW_SYNC();
+}
+
+// Step lengths for Z and S in one go: ten-lane groups 0..2 Cholesky-test Z + a dZ for a = {1, .7, .45} x scale_z, groups 3..5
+// S + a dS for {1, .7, .45} x scale_s; the largest step that keeps the matrix positive definite each (0 if none).
+__device__ __forceinline__ void coop_steps(double *L, const double *Z, const double *dZ, const double *S, const double *dS, int lane,
+                                           double scale_z, double scale_s, double &ap, double &ad)
+{
+    const int g = lane / 10, r = lane % 10;
+    const bool mine = lane < 60;
+    const int c = g % 3;
+    const double f = c == 0 ? 1.0 : (c == 1 ? 0.7 : 0.45);
+    const bool isz = g < 3;
+    const double cand = (isz ? scale_z : scale_s) * f;
+    const double *X = isz ? Z : S, *dX = isz ? dZ : dS;
+    double *T = L + I_TEST + (mine ? g : 0) * 100;
+    if (mine) {
+        for (int j = 0; j <= r; ++j) T[r * 10 + j] = X[r * 10 + j] + cand * dX[r * 10 + j];
+    }
+    CVXW_SYNC();
+    const bool ok = coop_chol<10>(T, 10, L + I_COL + (mine ? g : 0) * 10, r, mine);
+    const unsigned long long m = __ballot(mine && ok && r == 0);
+    ap = ((m >> 0) & 1ull) ? scale_z : (((m >> 10) & 1ull) ? 0.7 * scale_z : (((m >> 20) & 1ull) ? 0.45 * scale_z : 0.0));
+    ad = ((m >> 30) & 1ull) ? scale_s : (((m >> 40) & 1ull) ? 0.7 * scale_s : (((m >> 50) & 1ull) ? 0.45 * scale_s : 0.0));
+}
+
+// The solve.  qe: this lane's entry (ei, ej) of the trace-normalised cost (lanes < 55, 0 outside the 9 x 9 block).
+// On exit Z and S (full, symmetric) are at L[I_Z], L[I_S]; returns the iterations, gap = <Z, S>.
+__device__ __noinline__ int coop_ipm(double *L, int lane, double qe, int ei, int ej, double tol, int max_iters, double *gap_out)
+{
+    double *Z = L + I_Z, *S = L + I_S, *Si = L + I_SI, *dZ = L + I_DZ, *dS = L + I_DS, *Rc = L + I_RC, *dy = L + I_DY, *rhs = L + I_RHS;
+    double *M = L + I_M, *T1 = L + I_T1, *T2 = L + I_T2;
+    CVXW_SYNC();
+    for (int e = lane; e < 100; e += 64) {
+        const int i = e / 10, j = e % 10;
+        Z[e] = (i == j) ? (i < 9 ? 1.0 / 3.0 : 1.0) : 0.0;
+        S[e] = (i == j) ? 1.0 : 0.0;
+    }
+    CVXW_SYNC();
+    if (lane < 55 && ej < 9) { S[ei * 10 + ej] += qe; if (ei != ej) S[ej * 10 + ei] += qe; }
+    CVXW_SYNC();
+    // The constraint tables, once per solve (kIpmTab lives in global memory: read inside the iteration -- nine dependent byte
+    // loads per Schur entry -- it was most of the solve's time).  The 63 terms, packed r | c << 4 | (s + 1) << 8, go to LDS;
+    // rhs: the terms of row `lane`;  dS entries e = lane + 64 r (r < 2): dS[e] = c1 dy[i1] + c2 dy[i2].
+    auto pack_term = [&](int i, int k) { return (int)kIpmTab.r[i][k] | ((int)kIpmTab.c[i][k] << 4) | (((int)kIpmTab.s[i][k] + 1) << 8); };
+    int *TI = reinterpret_cast<int *>(L + I_TAB);
+    if (lane < 63) TI[lane] = pack_term(lane / 3, lane % 3);
+    int rhs_t[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rhs_t[k] = lane < 21 ? pack_term(lane, k) : 0x100;
+    int ds_i1[2], ds_i2[2];
+    double ds_c1[2], ds_c2[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int e = lane + 64 * r;
+        const int i = (e < 100 ? e : 0) / 10, j = (e < 100 ? e : 0) % 10;
+        ds_i1[r] = 0; ds_i2[r] = 0; ds_c1[r] = 0.0; ds_c2[r] = 0.0;
+        if (i != j) {
+            const int se = cvx::sidx(i, j), t = kIpmTab.ent_con[se];
+            if (t >= 0) { ds_i1[r] = t; ds_c1[r] = -0.5 * (double)kIpmTab.ent_sgn[se]; }
+        } else if (i == 9) { ds_i1[r] = 20; ds_c1[r] = -1.0; }
+        else {
+            ds_i1[r] = 15 + i % 3; ds_c1[r] = -1.0;
+            if (i / 3 < 2) { ds_i2[r] = 18 + i / 3; ds_c2[r] = -1.0; }
+        }
+    }
+    auto frob = [&](const double *A, const double *B) { // <A, B> over all 100 entries
+        double s = 0;
+        for (int e = lane; e < 100; e += 64) s += A[e] * B[e];
+        return wave_sum(s);
+    };
+    double gap = frob(Z, S);
+    int it = 0;
+#ifdef CVXW_IPM_CLOCK
+    if (lane < 16) L[I_COL + 100 + lane] = 0.0;
+    long long clk_ = wall_clock64();
+#endif
+    for (; it < max_iters; ++it) {
+        if (gap < tol) break;
+        const double mu = gap * 0.1;
+        // ---- Si = S^-1: Cholesky in T1 (lanes 0..9 own a row), then one column of the inverse per lane
+        for (int e = lane; e < 100; e += 64) T1[e] = S[e];
+        CVXW_SYNC();
+        const bool oks = coop_chol<10>(T1, 10, L + I_COL, lane, lane < 10);
+        if (!__all(lane >= 10 || oks)) break;
+        IPM_CLK(0);
+        if (lane < 10) {
+            double x[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                double s = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < 10; ++k)
+                    if (k < i) s -= T1[i * 10 + k] * x[k];
+                x[i] = s / T1[i * 10 + i];
+            }
+#pragma unroll
+            for (int i = 9; i >= 0; --i) {
+                double s = x[i];
+#pragma unroll
+                for (int k = 0; k < 10; ++k)
+                    if (k > i) s -= T1[k * 10 + i] * x[k];
+                x[i] = s / T1[i * 10 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 10; ++i) Si[i * 10 + lane] = x[i];
+        }
+        CVXW_SYNC();
+        IPM_CLK(1);
+        // ---- Schur matrix M_ij = <A_i, Z A_j Si>, lower triangle: 231 entries dealt to the lanes
+#pragma unroll 1
+        for (int e = lane; e < 231; e += 64) {
+            int i = 0, acc = 0;
+            while (acc + i + 1 <= e) { acc += i + 1; ++i; } // row i starts at i (i + 1) / 2
+            const int j = e - acc;
+            int wi[3], wj[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { wi[k] = TI[i * 3 + k]; wj[k] = TI[j * 3 + k]; }
+            double s = 0;
+#pragma unroll
+            for (int ka = 0; ka < 3; ++ka) {
+                const int a = wi[ka] & 15, b = (wi[ka] >> 4) & 15;
+                const double ca = (double)(((wi[ka] >> 8) & 3) - 1);
+#pragma unroll
+                for (int kb = 0; kb < 3; ++kb) {
+                    const int p = wj[kb] & 15, q = (wj[kb] >> 4) & 15;
+                    const double cb = (double)(((wj[kb] >> 8) & 3) - 1);
+                    s += ca * cb * 0.25 * (Z[a * 10 + p] * Si[q * 10 + b] + Z[a * 10 + q] * Si[p * 10 + b] + Z[b * 10 + p] * Si[q * 10 + a] + Z[b * 10 + q] * Si[p * 10 + a]);
+                }
+            }
+            M[i * 21 + j] = s;
+        }
+        CVXW_SYNC();
+        IPM_CLK(2);
+        const bool okm = coop_chol<21>(M, 21, L + I_COL, lane, lane < 21);
+        if (!__all(lane >= 21 || okm)) break;
+        IPM_CLK(3);
+        // the factor into registers for the two solves of this iteration: lane i keeps row i (left of the diagonal) and column i
+        // (below it), zero elsewhere, and 1 / L_ii -- a substitution step is then two lane reads and one multiply-add, not two
+        // round trips through LDS
+        double Lr[21], Lc[21];
+        const int li = lane < 21 ? lane : 0;
+#pragma unroll
+        for (int k = 0; k < 21; ++k) {
+            Lr[k] = (lane < 21 && k < lane) ? M[li * 21 + k] : 0.0;
+            Lc[k] = (lane < 21 && k > lane) ? M[k * 21 + li] : 0.0;
+        }
+        const double dinv = 1.0 / M[li * 21 + li];
+        IPM_CLK(4);
+        // ---- predictor (sigma = 0), then corrector
+        double sig_mu = 0.0, ap = 0.0, ad = 0.0;
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) { // second-order term of the predictor: (dZ dS Si + its transpose) / 2
+                coop_mul10(dZ, dS, T1, lane);
+                coop_mul10(T1, Si, T2, lane);
+            }
+            for (int e = lane; e < 100; e += 64) {
+                const int i = e / 10, j = e % 10;
+                Rc[e] = sig_mu * Si[e] - Z[e] - (pass == 1 ? 0.5 * (T2[e] + T2[j * 10 + i]) : 0.0);
+            }
+            CVXW_SYNC();
+            if (lane < 21) {
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) s += (double)(((rhs_t[k] >> 8) & 3) - 1) * Rc[(rhs_t[k] & 15) * 10 + ((rhs_t[k] >> 4) & 15)];
+                rhs[lane] = -s;
+            }
+            CVXW_SYNC();
+            {
+                double r = lane < 21 ? rhs[lane] : 0.0;
+#pragma unroll
+                for (int k = 0; k < 21; ++k) { // forward
+                    const double xk = wave_lane(r, k) * wave_lane(dinv, k);
+                    r = lane == k ? xk : r - Lr[k] * xk;
+                }
+#pragma unroll
+                for (int k = 20; k >= 0; --k) { // backward
+                    const double xk = wave_lane(r, k) * wave_lane(dinv, k);
+                    r = lane == k ? xk : r - Lc[k] * xk;
+                }
+                if (lane < 21) dy[lane] = r;
+            }
+            CVXW_SYNC();
+            // dS = - sum dy_i A_i, entry-wise: an off-diagonal entry belongs to one triple, a diagonal one to a row and a column sum
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (lane + 64 * r < 100) dS[lane + 64 * r] = ds_c1[r] * dy[ds_i1[r]] + ds_c2[r] * dy[ds_i2[r]];
+            CVXW_SYNC();
+            IPM_CLK(5);
+            coop_mul10(Z, dS, T1, lane);
+            coop_mul10(T1, Si, T2, lane);
+            for (int e = lane; e < 100; e += 64) {
+                const int i = e / 10, j = e % 10;
+                dZ[e] = Rc[e] - 0.5 * (T2[e] + T2[j * 10 + i]);
+            }
+            CVXW_SYNC();
+            IPM_CLK(6);
+            ap = 0.0; ad = 0.0;
+            {
+                double sz = 1.0, ss = 1.0;
+                for (int round = 0; round < 4 && (ap == 0.0 || ad == 0.0); ++round) { // (wave-uniform)
+                    double tp, td;
+                    coop_steps(L, Z, dZ, S, dS, lane, sz, ss, tp, td);
+                    if (ap == 0.0) { ap = tp; sz *= 0.3; }
+                    if (ad == 0.0) { ad = td; ss *= 0.3; }
+                }
+            }
+            IPM_CLK(7);
+            if (ap < 1.0) ap *= 0.95;
+            if (ad < 1.0) ad *= 0.95;
+            if (pass == 0) {
+                double s = 0;
+                for (int e = lane; e < 100; e += 64) s += (Z[e] + ap * dZ[e]) * (S[e] + ad * dS[e]);
+                const double r = wave_sum(s) / gap;
+                sig_mu = r * r * r * mu;
+            }
+        }
+        if (ap == 0.0 || ad == 0.0) break;
+        double s = 0;
+        for (int e = lane; e < 100; e += 64) s += (Z[e] + ap * dZ[e]) * (S[e] + ad * dS[e]);
+        const double g = wave_sum(s);
+        if (!(g == g) || !(g < gap)) break; // no progress: rounding has taken over; the last good iterate stands
+        for (int e = lane; e < 100; e += 64) { Z[e] += ap * dZ[e]; S[e] += ad * dS[e]; }
+        CVXW_SYNC();
+        gap = g;
+        IPM_CLK(8);
+    }
+    *gap_out = gap;
+    return it;
+}
+
+} // namespace cvxw

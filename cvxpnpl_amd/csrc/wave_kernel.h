@@ -39,6 +39,7 @@ constexpr int L_V = 776;    // 20   candidate eigenvectors (top, runner-up)
 constexpr int L_VN = 796;   // 100  unit eigenvectors of the previous iterate [position][row] (warm start)
 constexpr int L_U = 896;    // 10   planar scene in a general frame: the rotation U to the canonical frame (row-major)
 constexpr int LDSW = 908;
+constexpr int LDSW_IPM = 2304; // with the interior-point solve (ipm_wave.h uses [908, 2304) on top): cvxw::rescue_wave_kernel
 
 struct LaneTab {
     signed char ei[64], ej[64], p1[64], p2[64], s0[64], s1[64], s2[64], diag[64];
@@ -104,6 +105,10 @@ __device__ __forceinline__ double wave_max(double x)
     x = fmax(x, wave_dpp<0x140>(x));
     return fmax(fmax(wave_lane(x, 0), wave_lane(x, 16)), fmax(wave_lane(x, 32), wave_lane(x, 48)));
 }
+
+} // namespace cvxw
+#include "ipm_wave.h" // cvxw::coop_ipm (needs CVXW_SYNC, wave_sum and LDSW from above)
+namespace cvxw {
 
 // ---------------------------------------------------------------------------------------
 // cooperative certificate: constant tables
@@ -482,6 +487,7 @@ struct WaveArgs {
     double *R, *t, *cost, *Z;
     int32_t *status, *iters, *work;
     const double *Q45, *B27; // cost entry (cvxpnpl_solve_cost_batch): [batch][45] packed A^T A and [batch][27] B instead of correspondences
+    int32_t *rq_count, *rq_entries; // queue of cvxw::rescue_wave_kernel (or null): problems still open after opts.rescue_from iterations
 };
 
 // Layout of a parked problem in the workspace (doubles).  Every hand-off carries the iterate W (vech order) and the
@@ -496,8 +502,17 @@ constexpr int RS_Q = 56, RS_B = 112, RS_NC = 139, RS_V = 140, RS_FULL = 240; // 
 // Solve problem b with the wavefront that calls this.  resume (optional): 56 doubles written by
 // the lane-layout kernel for a problem it handed off -- W (55, vech order) and the iteration
 // count -- the solve then continues from that iterate instead of starting at e9 e9^T.
-template <int VAR = cvx::VAR_FULL>
-__device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opts &o, const int64_t b, double *L, const double *resume, const bool resume_full = false)
+//
+// A problem that is still open after opts.rescue_from iterations leaves this function: with IPM = false (every kernel but
+// cvxw::rescue_wave_kernel) it is put on the rescue queue (status ST_PENDING + its iteration count) and the function returns
+// false; with IPM = true it returns true (wave-uniform) with the cost in the solver's frame at L[I_QS..], the caller
+// (solve_one_wave) runs the interior-point solve and calls again with after_ipm set: the problem is assembled once more and
+// the iteration goes on from the iterate at L[I_W..].  The interior-point solve is kept OUT of the kernels every problem runs
+// through: merely compiled into their loop (never executed) it cost 4 % (10 000 problems) to 17 % (2 000) through the
+// register allocation of the hot path -- 8 % more vector instructions executed.
+template <int VAR, bool IPM>
+__device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o, const int64_t b, double *L, const double *resume, const bool resume_full,
+                                           const bool after_ipm, int &it_io, int &sweeps_io)
 {
     const int lane = threadIdx.x & 63;
     double2 *L2 = reinterpret_cast<double2 *>(L);
@@ -702,7 +717,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
 
     CVXW_PH(PH_ASSEMBLE);
 #ifdef CVXW_STOP_AFTER_ASSEMBLY // timing ablation (tools/ablate.sh): assembly only
-    { const double chk = wave_sum(Qs); if (lane == 0) a.status[b] = chk > 1e300 ? 1 : 0; return; }
+    { const double chk = wave_sum(Qs); if (lane == 0) a.status[b] = chk > 1e300 ? 1 : 0; return false; }
 #endif
     // ---------------------------------------------------------------- ADMM
     double delta = o.eps / (8.0 * tr);
@@ -717,7 +732,14 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
     double f_tp = 0.0, f_tm = 0.0;
     int tw_reused = 0;
     bool cold = false; // resumed solves have no previous eigenvectors for their first eigen-solve
-    if (resume) {
+    if (IPM && after_ipm) { // the interior-point solve's W = Z - S / rho, already in the solver's frame
+        W = L[I_W + el];
+        it = it_io; total_sweeps = sweeps_io;
+        next_check = it + 1;
+        cold = true;
+    } else if (IPM && !resume) { // from the rescue queue: only its cost is wanted (the test at the top of the loop)
+        it = it_io; total_sweeps = sweeps_io;
+    } else if (resume) {
         // device-coherent loads: the iterate may have been parked by a wavefront of this very launch (quad_kernel.h)
         auto rd = [&](int i) { return __hip_atomic_load(resume + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
         W = rd(el);
@@ -753,7 +775,9 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
     bool done = !finite;
     bool certified = false;
 
-    while (!done) {
+    // a problem that is still open after rescue_cap iterations leaves the loop for the interior-point solve (below)
+    const int rescue_cap = (VAR == cvx::VAR_FULL && !(IPM && after_ipm) && o.rescue_from > 0 && (IPM || a.rq_count)) ? o.rescue_from : 0x7fffffff;
+    while (!done && it < rescue_cap) {
         double sigma = 0.0;
         if (it == 0 && !resume && o.first_check > 1 && o.max_iters > 1) {
             // W0 = e9 e9^T is diagonal and PSD: Wp = W0, eigenvectors = unit vectors, no eigen-solve
@@ -1193,6 +1217,21 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
             CVXW_PH(PH_UPDATE);
         }
     }
+    if (!done) { // wave-uniform: a slow one
+        if (IPM) {
+            L[I_QS + lane] = (lane < 55 && ej < 9) ? Qs : 0.0;
+            CVXW_SYNC();
+            it_io = it; sweeps_io = total_sweeps;
+            return true;
+        }
+        if (lane == 0) {
+            a.status[b] = cvx::ST_PENDING + (it << 8);
+            if (a.work) a.work[2 * b + 1] = total_sweeps;
+            const int q = atomicAdd(a.rq_count, 1);
+            a.rq_entries[q] = (int32_t)b;
+        }
+        return false;
+    }
 
     // ---------------------------------------------------------------- outputs
     if (canon) { // back to the caller's frame: R = R' U^T for the pose and the twins, Z = Pt^T Z' Pt for an uncertified Z
@@ -1254,6 +1293,49 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
     }
     CVXW_PH(PH_OUTPUT);
     CVXW_PH_FLUSH();
+    return false;
+}
+
+// Solve problem b with the wavefront that calls this.  IPM (cvxw::rescue_wave_kernel only; L then has LDSW_IPM doubles): a
+// problem that comes from the rescue queue (resume == nullptr, it0 iterations behind it) or reaches opts.rescue_from
+// iterations here goes through the interior-point solve of ipm_wave.h (~12 second-order
+// iterations whatever the conditioning), then the first-order iteration from W = Z - S / rho, whose positive part is Z and
+// whose dual hint rho (W+ - W) is S: the attempt of the next iteration certifies (or finds the twin pair, or reports the rank)
+// from the interior-point solution, with the rounding, polish, certificate and recovery every other problem goes through.
+template <int VAR = cvx::VAR_FULL, bool IPM = false>
+__device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opts &o, const int64_t b, double *L, const double *resume, const bool resume_full = false,
+                                               const int it0 = 0, const int sweeps0 = 0)
+{
+    int it = it0, sweeps = sweeps0;
+    if constexpr (!IPM) {
+        (void)solve_pass<VAR, false>(a, o, b, L, resume, resume_full, false, it, sweeps);
+    } else {
+#ifdef CVXW_IPM_CLOCK // diagnostic build (tools/ipm_clock.py): 100 MHz ticks of the three stages into cost[2b], cost[2b+1], t[3b]
+    const long long c0 = wall_clock64();
+#endif
+    if (solve_pass<VAR, true>(a, o, b, L, resume, resume_full, false, it, sweeps)) {
+        const int lane = threadIdx.x & 63;
+        const unsigned lw = kLanePack.w[lane];
+        const int ei = (int)(lw & 15), ej = (int)((lw >> 4) & 15);
+        double gap;
+#ifdef CVXW_IPM_CLOCK
+        const long long c1 = wall_clock64();
+#endif
+        const int nit = coop_ipm(L, lane, L[I_QS + lane], ei, ej, 1e-10, 40, &gap);
+#ifdef CVXW_IPM_CLOCK
+        const long long c2 = wall_clock64();
+#endif
+        const double w = L[I_Z + ei * 10 + ej] - L[I_S + ei * 10 + ej] / o.rho;
+        CVXW_SYNC();
+        if (lane < 55) L[I_W + lane] = w;
+        CVXW_SYNC();
+        it += nit;
+        (void)solve_pass<VAR, true>(a, o, b, L, resume, resume_full, true, it, sweeps);
+#ifdef CVXW_IPM_CLOCK
+        if (lane == 0 && a.cost) { a.cost[2 * b] = (double)(c2 - c1) + 1e-3 * nit; a.cost[2 * b + 1] = (double)(wall_clock64() - c2); a.t[3 * b] = (double)(c1 - c0); for (int k = 0; k < 9; ++k) a.R[9 * b + k] = L[I_COL + 100 + k]; }
+#endif
+    }
+    }
 }
 
 template <int VAR>
@@ -1287,39 +1369,53 @@ struct ResumeArgs {
     int32_t *count_p, *entries;
     const double *ws;
     int ws_stride, ws_full; // doubles per parked problem (RS_LANE / RS_FULL) and whether the slots carry Q, B, V
+    // rescue_wave_kernel only: the blocks from grid1 on serve this second queue (parked problems; null: none)
+    int32_t *count2, *entries2;
+    int grid1;
 };
 typedef const __attribute__((address_space(4))) ResumeArgs *ResumeArgsPtr;
 
+template <bool IPM>
 __device__ __forceinline__ void resume_body(ResumeArgsPtr kp, int32_t first, double *lds)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     const WaveArgs a = kp->a;
     const cvx::Opts o = kp->o;
-    int32_t *entries = kp->entries;
-    int32_t *count_p = kp->count_p;
+    // (rescue_wave_kernel: two queues, each with its own range of blocks)
+    const bool second = IPM && (int)blockIdx.x >= kp->grid1;
+    const int bid = second ? (int)blockIdx.x - kp->grid1 : (int)blockIdx.x;
+    const int gsz = !IPM ? (int)gridDim.x : (second ? (int)gridDim.x - kp->grid1 : kp->grid1);
+    int32_t *entries = second ? kp->entries2 : kp->entries;
+    int32_t *count_p = second ? kp->count2 : kp->count_p;
     const int pushed = __hip_atomic_load(count_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (stable until the last block resets it)
     const double *ws = kp->ws;
     const int stride = kp->ws_stride;
     const bool full = kp->ws_full != 0;
     int32_t b = first;
-    for (int64_t q = blockIdx.x;;) { // wave-uniform
+    for (int64_t q = bid;;) { // wave-uniform
         if ((threadIdx.x & 63) == 0) entries[q] = -1;
         if (b < a.batch) {
-            solve_one_wave(a, o, b, lds, ws + (int64_t)b * stride, full);
+            if constexpr (IPM) {
+                if (second) solve_one_wave<cvx::VAR_FULL, true>(a, o, b, lds, ws + (int64_t)b * stride, full); // a parked problem
+                else { // rescue queue: nothing parked but the iteration count, in the status word
+                    const int st = a.status[b];
+                    solve_one_wave<cvx::VAR_FULL, true>(a, o, b, lds, nullptr, false, st >> 8, a.work ? a.work[2 * b + 1] : 0);
+                }
+            } else solve_one_wave(a, o, b, lds, ws + (int64_t)b * stride, full);
             CVXW_SYNC();
         }
         // The next position nobody has taken yet: blocks own the positions below gridDim.x by index and DRAW the ones behind them
         // from count_p[1] -- a wavefront that got a 40-iteration problem must not also own every 2048th entry behind it.
         int pn = 0;
         if ((threadIdx.x & 63) == 0) pn = atomicAdd(count_p + 1, 1);
-        q = (int64_t)gridDim.x + __builtin_amdgcn_readfirstlane(pn);
+        q = (int64_t)gsz + __builtin_amdgcn_readfirstlane(pn);
         b = q < a.batch + RESUME_GRID_MAX ? entries[q] : -1;
         if (b < 0) break; // an empty position: the queue is exhausted -- every drawing block ends with exactly one such draw
     }
     // The last block to leave puts the counters back to zero for the next launch (pushed = positions the first kernel filled; the
     // blocks that draw are the ones whose own position was filled: min(pushed, gridDim.x) of them).
     if ((threadIdx.x & 63) == 0) {
-        const int drawing = pushed < (int)gridDim.x ? pushed : (int)gridDim.x;
+        const int drawing = pushed < gsz ? pushed : gsz;
         if (atomicAdd(count_p + 2, 1) == drawing - 1) {
             __hip_atomic_store(count_p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(count_p + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1334,7 +1430,19 @@ __global__ void __launch_bounds__(64, 2) resume_wave_kernel(ResumeArgs k)
     __shared__ __attribute__((aligned(16))) double lds_all[LDSW];
     const int32_t first = k.entries[blockIdx.x];
     if (first < 0) return;
-    resume_body((ResumeArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), first, lds_all);
+    resume_body<false>((ResumeArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), first, lds_all);
+}
+
+// Last phase of a solve with opts.rescue_from in force: the problems the other kernels put on the rescue queue (k.count_p =
+// rq_count, k.entries = rq_entries; same self-cleaning queue discipline), one wavefront each, through the interior-point solve.
+// In the quad layout the same launch also takes the place of resume_wave_kernel: its blocks from k.grid1 on serve the resume queue
+// (k.count2, k.entries2, k.ws), and a parked problem that reaches opts.rescue_from goes through the interior-point solve right here.
+__global__ void __launch_bounds__(64, 2) rescue_wave_kernel(ResumeArgs k)
+{
+    __shared__ __attribute__((aligned(16))) double lds_all[LDSW_IPM];
+    const int32_t first = (int)blockIdx.x < k.grid1 ? k.entries[blockIdx.x] : k.entries2[(int)blockIdx.x - k.grid1];
+    if (first < 0) return;
+    resume_body<true>((ResumeArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), first, lds_all);
 }
 
 } // namespace cvxw

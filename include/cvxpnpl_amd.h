@@ -84,6 +84,12 @@ typedef struct {
                             attempts), fixed-point residual below stall_res (1e-3) -- stops as CVXPNPL_RANK_GT1: the relaxation
                             is not tight and the first-order iteration would crawl to max_iters (the reference's solve does) */
     double stall_lam, stall_res, stall_drop;
+    int32_t rescue_from; /* a problem still open after this many first-order iterations is finished by the interior-point path
+                            (default 40; 0 never; full variant only): ~12 second-order iterations whatever the conditioning, then
+                            the first-order iteration goes on from the interior-point solution -- same rounding, polish, certificate
+                            and recovery -- so that a launch no longer waits for a 1 000-iteration straggler (minimal and
+                            near-ambiguous configurations; measured on 50 k four-point RANSAC hypotheses: 7.4 -> 3.6 ms).
+                            Costs one more (mostly idle) kernel launch per solve in the wave and lane layouts. */
 } cvxpnpl_opts_t;
 
 void cvxpnpl_default_opts(cvxpnpl_opts_t *opts);

@@ -18,11 +18,11 @@ class Opts(C.Structure):
                 ("first_check", C.c_int), ("check_every", C.c_int), ("res_tol", C.c_double), ("jacobi_sweeps", C.c_int),
                 ("jacobi_tol", C.c_double), ("warm_start", C.c_int), ("rho_tail", C.c_double), ("tail_from", C.c_int),
                 ("adapt_every", C.c_int), ("adapt_from", C.c_int), ("adapt_mu", C.c_double), ("adapt_tau", C.c_double),
-                ("stall_from", C.c_int), ("stall_lam", C.c_double), ("stall_res", C.c_double), ("stall_drop", C.c_double), ("variant", C.c_int)]
+                ("stall_from", C.c_int), ("stall_lam", C.c_double), ("stall_res", C.c_double), ("stall_drop", C.c_double), ("variant", C.c_int), ("rescue_from", C.c_int)]
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, "hostsim.cpp"), os.path.join(_CSRC, "solver_core.h"), os.path.join(_CSRC, "problem_io.h")]
+    srcs = [os.path.join(_HERE, "hostsim.cpp"), os.path.join(_CSRC, "solver_core.h"), os.path.join(_CSRC, "problem_io.h"), os.path.join(_CSRC, "ipm_core.h")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off",
                                "-o", _SO, srcs[0]])
@@ -63,6 +63,23 @@ def solve_batch(pts_2d, pts_3d, line_2d, line_3d, K, opts=None, want_Z=False):
     lib().hs_solve_batch(Bn, n_p, _p(a[0]), _p(a[1]), n_l, _p(a[2]), _p(a[3]), _p(K), int(K.ndim == 3), C.byref(o), _p(R), _p(t),
                          st.ctypes.data_as(_ip), it.ctypes.data_as(_ip), _p(cost), rk.ctypes.data_as(_ip), sw.ctypes.data_as(_ip), _p(Z))
     return {"R": R, "t": t, "status": st, "iters": it, "cost": cost, "rank": rk, "sweeps": sw, "Z": Z}
+
+
+def ipm_batch(pts_2d, pts_3d, line_2d, line_3d, K, opts=None, want_Z=False):
+    """The interior-point path (csrc/ipm_core.h) on the host: same outputs as solve_batch."""
+    a = [np.ascontiguousarray(v, dtype=np.float64) if v is not None else None for v in (pts_2d, pts_3d, line_2d, line_3d)]
+    K = np.ascontiguousarray(K, dtype=np.float64)
+    Bn = len(a[1]) if a[1] is not None else len(a[3])
+    n_p = a[1].shape[1] if a[1] is not None else 0
+    n_l = a[3].shape[1] if a[3] is not None else 0
+    o = opts or default_opts()
+    R, t = np.zeros((Bn, 3, 3)), np.zeros((Bn, 3))
+    st, it, rk = (np.zeros(Bn, np.int32) for _ in range(3))
+    cost = np.zeros((Bn, 2))
+    Z = np.zeros((Bn, 55)) if want_Z else None
+    lib().hs_ipm_batch(Bn, n_p, _p(a[0]), _p(a[1]), n_l, _p(a[2]), _p(a[3]), _p(K), int(K.ndim == 3), C.byref(o), _p(R), _p(t),
+                       st.ctypes.data_as(_ip), it.ctypes.data_as(_ip), _p(cost), rk.ctypes.data_as(_ip), _p(Z))
+    return {"R": R, "t": t, "status": st, "iters": it, "cost": cost, "rank": rk, "Z": Z}
 
 
 def assemble(pts_2d, pts_3d, line_2d, line_3d, K):

@@ -3,6 +3,7 @@
 // GPU.  Never imported by the cvxpnpl_amd package; built by tests/hostsim/__init__.py.
 #include "../../cvxpnpl_amd/csrc/solver_core.h"
 #include "../../cvxpnpl_amd/csrc/problem_io.h"
+#include "../../cvxpnpl_amd/csrc/ipm_core.h"
 
 extern "C" {
 
@@ -32,6 +33,30 @@ int hs_solve_batch(int batch, int n_p, const double *pts_2d, const double *pts_3
         if (cost) { cost[2 * (size_t)b] = sol.cost; cost[2 * (size_t)b + 1] = sol.dobj; }
         if (rank) rank[b] = sol.rank;
         if (sweeps) sweeps[b] = sol.sweeps;
+        if (Z_out) for (int i = 0; i < 55; ++i) Z_out[(size_t)b * 55 + i] = Z[i];
+    }
+    return 0;
+}
+
+// the interior-point path (ipm_core.h) for a batch: same outputs as hs_solve_batch
+int hs_ipm_batch(int batch, int n_p, const double *pts_2d, const double *pts_3d, int n_l, const double *line_2d,
+                 const double *line_3d, const double *K, int K_per_problem, const cvx::Opts *opts,
+                 double *R_out, double *t_out, int *status, int *iters, double *cost, int *rank, double *Z_out)
+{
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int b = 0; b < batch; ++b) {
+        cvx::ProblemView pv = cvx::make_view(b, n_p, pts_2d, pts_3d, n_l, line_2d, line_3d, K, K_per_problem);
+        double B[27], Q9[45], Z[55];
+        cvx::Solution sol;
+        sol.iters = 0;
+        if (!cvx::assemble(pv, B, Q9)) { for (int i = 0; i < 45; ++i) Q9[i] = NAN; for (int i = 0; i < 27; ++i) B[i] = NAN; }
+        cvx::ipm_problem(Q9, B, *opts, sol, Z_out ? Z : nullptr);
+        for (int i = 0; i < 9; ++i) R_out[(size_t)b * 9 + i] = sol.R[i];
+        for (int i = 0; i < 3; ++i) t_out[(size_t)b * 3 + i] = sol.t[i];
+        if (status) status[b] = sol.status;
+        if (iters) iters[b] = sol.iters;
+        if (cost) { cost[2 * (size_t)b] = sol.cost; cost[2 * (size_t)b + 1] = sol.dobj; }
+        if (rank) rank[b] = sol.rank;
         if (Z_out) for (int i = 0; i < 55; ++i) Z_out[(size_t)b * 55 + i] = Z[i];
     }
     return 0;

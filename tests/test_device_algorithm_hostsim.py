@@ -314,3 +314,41 @@ def test_assembly_far_from_the_world_origin(orc):
     ok = (h["status"] == 0) & (o["n_poses"] == 1)
     assert ok.sum() >= 10
     assert synth.geodesic(h["R"], o["R"][:, 0])[ok].max() < 1e-6
+
+
+def test_interior_point_path_examples_and_first_order_agreement(golden):
+    """The interior-point path (csrc/ipm_core.h: the scalar statement of what cvxw::coop_ipm runs for the problems still open
+    after opts.rescue_from iterations) reproduces the reference's three examples and agrees with the first-order solve -- it is
+    the same SDP, and its solution goes through the same rounding, polish and certificate."""
+    for name, args in (
+        ("pnp", (golden["ex_pnp_pts2d"][None], golden["ex_pnp_pts3d"][None], None, None)),
+        ("pnl", (None, None, golden["ex_pnl_line2d"][None], golden["ex_pnl_line3d"][None])),
+        ("pnpl", (golden["ex_pnpl_pts2d"][None], golden["ex_pnpl_pts3d"][None], golden["ex_pnpl_line2d"][None], golden["ex_pnpl_line3d"][None])),
+    ):
+        ip = hostsim.ipm_batch(*args, golden[f"ex_{name}_K"])
+        assert ip["status"][0] == 0 and ip["iters"][0] <= 20
+        assert synth.geodesic(ip["R"][0], golden[f"ex_{name}_R"]) < 1e-6
+        tg = golden[f"ex_{name}_t"]
+        assert np.linalg.norm(ip["t"][0] - tg) / np.linalg.norm(tg) < 1e-6
+    # minimal problems: where the first-order iteration is slow (hundreds of iterations) the interior-point path is not
+    d = synth.make_pnp(300, 4, 2.0, seed=3)
+    fo = hostsim.solve_batch(d["pts_2d"], d["pts_3d"], None, None, d["K"], want_Z=True)
+    ip = hostsim.ipm_batch(d["pts_2d"], d["pts_3d"], None, None, d["K"], want_Z=True)
+    assert ip["iters"].max() <= 25 and fo["iters"].max() > 200
+    assert (ip["status"] == 0).sum() >= (fo["status"] == 0).sum()
+    both = (fo["status"] == 0) & (ip["status"] == 0)
+    assert both.mean() > 0.95
+    assert synth.geodesic(ip["R"], fo["R"])[both].max() < 1e-7
+    assert (np.linalg.norm(ip["t"] - fo["t"], axis=1) / np.linalg.norm(fo["t"], axis=1))[both].max() < 1e-7
+    # a certified Z is the rank-one z z^T of the same pose in both paths
+    np.testing.assert_allclose(ip["Z"][both], fo["Z"][both], atol=1e-6)
+    # planar scenes (two-fold ambiguous, rank 2): both paths report the rank and the same pair of poses
+    dp = synth.make_planar_pnp(60, 8, 0.5, seed=21, general=True)
+    fo = hostsim.solve_batch(dp["pts_2d"], dp["pts_3d"], None, None, dp["K"])
+    ip = hostsim.ipm_batch(dp["pts_2d"], dp["pts_3d"], None, None, dp["K"])
+    assert (ip["status"] == fo["status"]).mean() > 0.95
+    same = (ip["status"] == fo["status"]) & ~np.isnan(fo["R"]).any(axis=(1, 2)) & ~np.isnan(ip["R"]).any(axis=(1, 2))
+    g = synth.geodesic(ip["R"], fo["R"])[same]  # (which of the two poses comes first is arbitrary: the mirror twin is half a turn away)
+    g = np.minimum(g, np.abs(g - np.pi))
+    # (a pair that is not exactly two-fold ambiguous -- noisy image points -- is rounded from an uncertified Z: close, not identical)
+    assert same.sum() > 40 and (g < 1e-6).mean() > 0.9 and g.max() < 2e-2

@@ -449,6 +449,34 @@ def test_hybrid_queue_counters_alternate_between_launches(gpu):
             assert (np.isnan(r["R"][fl]).any(axis=(1, 2)) == np.isnan(w["R"][fl]).any(axis=(1, 2))).mean() > 0.995
 
 
+@pytest.mark.gpu
+def test_interior_point_rescue_matches_first_order_solve(gpu):
+    """opts.rescue_from: the problems still open after that many first-order iterations are finished by the interior-point path
+    (cvxw::rescue_wave_kernel).  Same SDP, same rounding / polish / certificate: every problem certified both ways has the same
+    pose, nothing certified is lost, the iteration counts are bounded by rescue_from + the ~12 second-order iterations + a
+    few, and a launch leaves no problem pending -- in every layout, on minimal problems (slow for the first-order iteration)."""
+    from cvxpnpl_amd import synth
+
+    d = synth.make_pnp(3000, 4, 2.0, seed=3)
+    ref = _solve(gpu, d, 4, 0, layout=LAYOUTS["wave"], max_iters=2500, rescue_from=0)
+    assert ref["iters"].max() > 400
+    for layout in ("wave", "quad", "lane", "penta"):
+        for rf in (48, 0):
+            r = _solve(gpu, d, 4, 0, layout=LAYOUTS[layout], max_iters=2500, rescue_from=rf)
+            assert (r["status"] < 5).all() and (r["status"] >= 0).all()
+            both = (r["status"] == 0) & (ref["status"] == 0)
+            assert both.mean() > 0.97
+            assert synth.geodesic(r["R"], ref["R"])[both].max() < 1e-6
+            assert (np.linalg.norm(r["t"] - ref["t"], axis=1) / np.linalg.norm(ref["t"], axis=1))[both].max() < 1e-6
+            if rf:
+                assert (r["status"] == 0).sum() >= (ref["status"] == 0).sum()
+                assert r["iters"].max() <= rf + 120, r["iters"].max()
+                assert (r["iters"] > rf).sum() > 20  # the path was taken
+    # the default options have it on
+    r = _solve(gpu, d, 4, 0, max_iters=2500)
+    assert r["iters"].max() < 400 and (r["status"] == 0).sum() >= (ref["status"] == 0).sum()
+
+
 def test_pack_results_kernel_matches_host_packing(gpu):
     """cvxpnpl_pack_results (the [n,13] records the multi-GPU gather exchanges) is bit-identical to the torch
     packing the gloo tests use on host tensors; ragged size, statuses 0..4, NaN poses kept."""
@@ -651,10 +679,14 @@ def test_ransac_default_device_and_workspace_entry_points(gpu):
             r = _solve(gpu, dd, 8, 0, layout=LAYOUTS[layout], max_iters=200)
             assert (r["status"] == ref["status"]).mean() > 0.995
             # the queue is self-cleaning: its three counters are back at zero and every entry at -1 after each launch
+            # (both queues: the resume queue and the rescue queue of the interior-point path -- planar problems need ~140 first-order
+            # iterations, so most of them go through it here)
             head = buf[:256].view(torch.int32).cpu().numpy()
-            assert (head[:3] == 0).all(), head[:3]
-            entries = buf[256:256 + 4 * (700 + 2048)].view(torch.int32).cpu().numpy()
+            assert (head[:3] == 0).all() and (head[16:19] == 0).all(), (head[:3], head[16:19])
+            qbytes = (4 * (700 + 2048) + 255) // 256 * 256
+            entries = buf[256:256 + 2 * qbytes].view(torch.int32).cpu().numpy()
             assert (entries == -1).all()
+            assert (r["status"] < 5).all()  # nothing left pending
         with pytest.raises(RuntimeError, match="workspace"):
             _solve(gpu, big, 6, 0, layout=LAYOUTS["quad"])
     finally:
