@@ -52,9 +52,10 @@ def _kernel_name(layout, batch, blocked=False):
         return "assemble_large_kernel (dominant: timed on its own) + assemble_finish_kernel + solve_wave_kernel"
     if layout == 0:
         layout = 2 if batch < 2560 else (3 if batch < 24576 else 1)
-    return {1: "solve_lane_kernel + resume_wave_kernel", 2: "solve_wave_kernel",
-            3: "solve_quad_kernel (+ resume_wave_kernel: planar scenes only, empty here)",
-            4: "solve_quad_kernel<12 lanes per problem> (+ resume_wave_kernel: planar scenes only, empty here)"}.get(layout, f"experimental layout {layout}")
+    return {1: "solve_lane_kernel + resume_wave_kernel (+ rescue_wave_kernel: problems beyond opts.rescue_from iterations)",
+            2: "solve_wave_kernel (+ rescue_wave_kernel: problems beyond opts.rescue_from iterations)",
+            3: "solve_quad_kernel (+ rescue_wave_kernel: planar scenes and problems beyond opts.rescue_from iterations)",
+            4: "solve_quad_kernel<12 lanes per problem> (+ rescue_wave_kernel: planar scenes and problems beyond opts.rescue_from iterations)"}.get(layout, f"experimental layout {layout}")
 
 
 def main():
