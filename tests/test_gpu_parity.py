@@ -475,6 +475,26 @@ def test_interior_point_rescue_matches_first_order_solve(gpu):
     # the default options have it on
     r = _solve(gpu, d, 4, 0, max_iters=2500)
     assert r["iters"].max() < 400 and (r["status"] == 0).sum() >= (ref["status"] == 0).sum()
+    # lines, points + lines, and the cost seam (cvxpnpl_solve_cost_batch: the problem is re-assembled from Q45 / B27 on the way)
+    import torch
+
+    import cvxpnpl_amd as ca
+
+    for n_p, n_l, seed in ((0, 4, 11), (2, 2, 12), (3, 1, 13)):
+        dl = synth.make_pnpl(1500, n_p, n_l, 2.0, seed=seed)
+        a = _solve(gpu, dl, n_p, n_l, max_iters=2500, rescue_from=0)
+        b = _solve(gpu, dl, n_p, n_l, max_iters=2500, rescue_from=40)
+        both = (a["status"] == 0) & (b["status"] == 0)
+        assert (b["status"] < 5).all() and (b["iters"] > 40).sum() > 5 and both.mean() > 0.9
+        assert (b["status"] == 0).sum() >= (a["status"] == 0).sum() - 2
+        assert synth.geodesic(a["R"], b["R"])[both].max() < 1e-6
+    tt = lambda x: torch.as_tensor(x, device=gpu)  # noqa: E731
+    Bt, Qt = ca.assemble_batch(tt(d["pts_2d"]), None, tt(d["pts_3d"]), None, tt(d["K"]))
+    for layout in ("wave", "quad", "lane"):
+        c = {k: v.cpu().numpy() for k, v in ca.solve_cost_batch(Qt, Bt, max_iters=2500, rescue_from=48, layout=LAYOUTS[layout]).items()}
+        both = (c["status"] == 0) & (ref["status"] == 0)
+        assert (c["status"] < 5).all() and c["iters"].max() <= 48 + 120 and both.mean() > 0.97
+        assert synth.geodesic(c["R"], ref["R"])[both].max() < 1e-6
 
 
 def test_pack_results_kernel_matches_host_packing(gpu):
