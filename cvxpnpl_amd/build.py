@@ -26,7 +26,9 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in deps):
         return OUT
     srcs = [SRC] + ([HOST_SRC] if os.path.exists(HOST_SRC) else [])
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-o", OUT] + srcs
+    # -enable-ipra=0: the one non-inlined device function (cvxw::coop_ipm) is called from the rescue kernel only; with
+    # inter-procedural register allocation the CALLER's first-order loop around it came out 40 % slower (profiles/r02/ipm_clock.jsonl)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-mllvm", "-enable-ipra=0", "-o", OUT] + srcs
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))

@@ -296,10 +296,11 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     if (o.first_check <= 0) o.first_check = layout == CVXPNPL_LAYOUT_LANE ? 6 : 5;
     // interior-point path for the problems still open after rescue_from iterations (ipm_wave.h): its queue lives in the workspace
     // -1 (default): by problem size.  Slow convergence is a property of minimal and near-minimal configurations; with ten
-    // correspondences a problem that is still open after 48 iterations usually finishes within the next ~15, and the ~0.5 ms of the
-    // interior-point path would then end the launch later (profiles/r02/rescue_sweep.jsonl, launch time with 48 against 96:
-    // 1.98 / 2.54 ms for 10 k problems with N = 4, 1.43 / 1.76 for N = 5, 1.06 / 1.23 for N = 6, but 4.95 / 4.43 ms for 1 M with N = 10).
-    if (o.rescue_from < 0) o.rescue_from = (!a.Q45 && a.n_p + a.n_l <= 6) ? 48 : 96;
+    // correspondences a problem that is still open after 32 or 48 iterations usually finishes within the next ~15, and the ~0.35 ms of
+    // the interior-point path would then end the launch later (profiles/r02/rescue_sweep.jsonl, launch time with 32 / 48 / 96:
+    // 1.81 / 1.84 / 2.36 ms for 10 k problems with N = 4, 1.09 / 1.26 / 1.58 for N = 5, 0.83 / 0.91 / 1.05 for N = 6, but
+    // 4.79 / 4.80 / 4.46 ms for 1 M with N = 10).
+    if (o.rescue_from < 0) o.rescue_from = (!a.Q45 && a.n_p + a.n_l <= 6) ? 32 : 96;
     const bool rescue = o.variant == cvx::VAR_FULL && o.rescue_from > 0 && o.max_iters > o.rescue_from;
     if (rescue) {
         WsView wv;

@@ -66,38 +66,45 @@ constexpr bool ipm_tab_ok()
 static_assert(ipm_tab_ok(), "coop_ipm builds dS entry-wise: every off-diagonal entry belongs to at most one of the 15 triples");
 __device__ const IpmTab kIpmTab = make_ipm_tab();
 
-// Cholesky of the n x n matrix at A (row stride ld, lower triangle, in place) by n lanes, one row each (`mine`; several groups
-// of lanes may factor different matrices side by side); `col` is n doubles of scratch per group.  Every lane of the wavefront must
-// call (wave-uniform syncs).  Returns false in the lanes of a group whose matrix is not positive definite (the factor is then
-// garbage).  (A variant with the rows in registers and one published column per step was slower: it spilled.)
+// Cholesky with the rows in registers: lane i < N holds row i in a[] (entries 0..i; the rest is ignored and comes back as
+// garbage), lanes >= N hold zeros.  Left-looking, fully unrolled; the finished entries of row j reach the other lanes through lane
+// reads -- no LDS, no barrier (a version with the matrix in LDS cost ~1 200 cycles per column in dependent round trips: 12 of the 39 us of an
+// interior-point iteration went into the 21 x 21 factor).  Returns false (wave-uniform) if the matrix is not positive definite.
 template <int N>
-__device__ __forceinline__ bool coop_chol(double *A, int ld, double *col, int row, bool mine)
+__device__ __forceinline__ bool chol_rows(double (&a)[N])
 {
-    constexpr int n = N;
     bool ok = true;
-    for (int j = 0; j < n; ++j) {
-        if (mine && row >= j) {
-            // fixed trip count with a select instead of `k < j` as the loop bound: all 2 N loads are in flight together (with the
-            // bound in the loop every multiply-add waited for its own pair of loads: 26 000 cycles for N = 21)
-            double s0 = A[row * ld + j], s1 = 0.0;
 #pragma unroll
-            for (int k = 0; k + 1 < N; k += 2) {
-                const double p0 = A[row * ld + k] * A[j * ld + k], p1 = A[row * ld + k + 1] * A[j * ld + k + 1];
-                s0 -= k < j ? p0 : 0.0;
-                s1 -= k + 1 < j ? p1 : 0.0;
-            }
-            if (N & 1) { const double p0 = A[row * ld + N - 1] * A[j * ld + N - 1]; s0 -= N - 1 < j ? p0 : 0.0; }
-            col[row] = s0 + s1;
-        }
-        CVXW_SYNC();
-        const double d = mine ? col[j] : 1.0;
+    for (int j = 0; j < N; ++j) {
+        double s = a[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s -= a[k] * wave_lane(a[k], j);
+        const double d = wave_lane(s, j);
         ok = ok && (d > 0.0);
-        const double il = cvx::rsqrt_(d > 0.0 ? d : 1.0);
-        CVXW_SYNC();
-        if (mine && row >= j) A[row * ld + j] = col[row] * il; // (row == j: d / sqrt(d) = sqrt(d))
-        CVXW_SYNC();
+        a[j] = s * cvx::rsqrt_(d > 0.0 ? d : 1.0); // (row == j: d / sqrt(d) = sqrt(d))
     }
-    CVXW_SYNC();
+    return ok;
+}
+// The same for several matrices side by side, one per group of N consecutive lanes starting at lane `base` (`mine`: this lane
+// belongs to a group).  Right-looking, so that a column needs ONE exchange: the pivot and the column's entries, all read from
+// the lanes that own them with ds_bpermute in one batch.  Returns false in the lanes of a group whose matrix is not positive definite.
+template <int N>
+__device__ __forceinline__ bool chol_rows_grouped(double (&a)[N], int base, bool mine)
+{
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const double d = __shfl(a[j], base + j);
+        double c[N];
+#pragma unroll
+        for (int k = j + 1; k < N; ++k) c[k] = __shfl(a[j], base + k);
+        ok = ok && (!mine || d > 0.0);
+        const double il = cvx::rsqrt_(d > 0.0 ? d : 1.0);
+        const double f = a[j] * il * il; // a_ik -= l_ij l_kj = (a_ij / d) a_kj
+#pragma unroll
+        for (int k = j + 1; k < N; ++k) a[k] -= f * c[k];
+        a[j] *= il;
+    }
     return ok;
 }
 
@@ -126,12 +133,10 @@ __device__ __forceinline__ void coop_steps(double *L, const double *Z, const dou
     const bool isz = g < 3;
     const double cand = (isz ? scale_z : scale_s) * f;
     const double *X = isz ? Z : S, *dX = isz ? dZ : dS;
-    double *T = L + I_TEST + (mine ? g : 0) * 100;
-    if (mine) {
-        for (int j = 0; j <= r; ++j) T[r * 10 + j] = X[r * 10 + j] + cand * dX[r * 10 + j];
-    }
-    CVXW_SYNC();
-    const bool ok = coop_chol<10>(T, 10, L + I_COL + (mine ? g : 0) * 10, r, mine);
+    double a[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) a[j] = (mine && j <= r) ? X[r * 10 + j] + cand * dX[r * 10 + j] : (j == r ? 1.0 : 0.0);
+    const bool ok = chol_rows_grouped<10>(a, mine ? g * 10 : 60, mine);
     const unsigned long long m = __ballot(mine && ok && r == 0);
     ap = ((m >> 0) & 1ull) ? scale_z : (((m >> 10) & 1ull) ? 0.7 * scale_z : (((m >> 20) & 1ull) ? 0.45 * scale_z : 0.0));
     ad = ((m >> 30) & 1ull) ? scale_s : (((m >> 40) & 1ull) ? 0.7 * scale_s : (((m >> 50) & 1ull) ? 0.45 * scale_s : 0.0));
@@ -192,10 +197,16 @@ __device__ __noinline__ int coop_ipm(double *L, int lane, double qe, int ei, int
         if (gap < tol) break;
         const double mu = gap * 0.1;
         // ---- Si = S^-1: Cholesky in T1 (lanes 0..9 own a row), then one column of the inverse per lane
-        for (int e = lane; e < 100; e += 64) T1[e] = S[e];
-        CVXW_SYNC();
-        const bool oks = coop_chol<10>(T1, 10, L + I_COL, lane, lane < 10);
-        if (!__all(lane >= 10 || oks)) break;
+        {
+            double a[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) a[k] = (lane < 10 && k <= lane) ? S[lane * 10 + k] : 0.0;
+            if (!chol_rows<10>(a)) break;
+#pragma unroll
+            for (int k = 0; k < 10; ++k)
+                if (lane < 10 && k <= lane) T1[lane * 10 + k] = a[k];
+            CVXW_SYNC();
+        }
         IPM_CLK(0);
         if (lane < 10) {
             double x[10];
@@ -245,20 +256,26 @@ __device__ __noinline__ int coop_ipm(double *L, int lane, double qe, int ei, int
         }
         CVXW_SYNC();
         IPM_CLK(2);
-        const bool okm = coop_chol<21>(M, 21, L + I_COL, lane, lane < 21);
-        if (!__all(lane >= 21 || okm)) break;
+        const int li = lane < 21 ? lane : 0;
+        double Lr[21];
+#pragma unroll
+        for (int k = 0; k < 21; ++k) Lr[k] = (lane < 21 && k <= lane) ? M[li * 21 + k] : 0.0;
+        if (!chol_rows<21>(Lr)) break;
+#pragma unroll
+        for (int k = 0; k < 21; ++k)
+            if (lane < 21 && k <= lane) M[li * 21 + k] = Lr[k]; // (the columns are read back from here)
+        CVXW_SYNC();
         IPM_CLK(3);
         // the factor into registers for the two solves of this iteration: lane i keeps row i (left of the diagonal) and column i
         // (below it), zero elsewhere, and 1 / L_ii -- a substitution step is then two lane reads and one multiply-add, not two
         // round trips through LDS
-        double Lr[21], Lc[21];
-        const int li = lane < 21 ? lane : 0;
+        double Lc[21];
+        const double dinv = 1.0 / M[li * 21 + li];
 #pragma unroll
         for (int k = 0; k < 21; ++k) {
-            Lr[k] = (lane < 21 && k < lane) ? M[li * 21 + k] : 0.0;
+            Lr[k] = (lane < 21 && k < lane) ? Lr[k] : 0.0;
             Lc[k] = (lane < 21 && k > lane) ? M[k * 21 + li] : 0.0;
         }
-        const double dinv = 1.0 / M[li * 21 + li];
         IPM_CLK(4);
         // ---- predictor (sigma = 0), then corrector
         double sig_mu = 0.0, ap = 0.0, ad = 0.0;

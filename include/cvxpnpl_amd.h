@@ -85,11 +85,11 @@ typedef struct {
                             is not tight and the first-order iteration would crawl to max_iters (the reference's solve does) */
     double stall_lam, stall_res, stall_drop;
     int32_t rescue_from; /* a problem still open after this many first-order iterations is finished by the interior-point path
-                            (0 never; -1, the default: 48 for problems with at most 6 correspondences, where slow convergence is
+                            (0 never; -1, the default: 32 for problems with at most 6 correspondences, where slow convergence is
                             common, 96 otherwise; full variant only): ~12 second-order iterations whatever the conditioning, then
                             the first-order iteration goes on from the interior-point solution -- same rounding, polish, certificate
                             and recovery -- so that a launch no longer waits for a 1 000-iteration straggler (minimal and
-                            near-ambiguous configurations; measured on 50 k four-point RANSAC hypotheses: 7.1 -> 3.2 ms).
+                            near-ambiguous configurations; measured on 50 k four-point RANSAC hypotheses: 7.1 -> 2.9 ms).
                             Costs one more (mostly idle) kernel launch per solve in the wave and lane layouts. */
 } cvxpnpl_opts_t;
 

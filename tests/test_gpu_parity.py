@@ -472,9 +472,9 @@ def test_interior_point_rescue_matches_first_order_solve(gpu):
                 assert (r["status"] == 0).sum() >= (ref["status"] == 0).sum()
                 assert r["iters"].max() <= rf + 120, r["iters"].max()
                 assert (r["iters"] > rf).sum() > 20  # the path was taken
-    # the default options have it on (-1: 48 iterations for problems with at most 6 correspondences, 96 otherwise)
+    # the default options have it on (-1: 32 iterations for problems with at most 6 correspondences, 96 otherwise)
     r = _solve(gpu, d, 4, 0, max_iters=2500)
-    assert r["iters"].max() <= 48 + 120 and (r["iters"] > 48).sum() > 20 and (r["status"] == 0).sum() >= (ref["status"] == 0).sum()
+    assert r["iters"].max() <= 32 + 120 and (r["iters"] > 32).sum() > 20 and (r["status"] == 0).sum() >= (ref["status"] == 0).sum()
     with pytest.raises(RuntimeError, match="bad options"):
         _solve(gpu, d, 4, 0, rescue_from=-2)
     # lines, points + lines, and the cost seam (cvxpnpl_solve_cost_batch: the problem is re-assembled from Q45 / B27 on the way)

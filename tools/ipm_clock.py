@@ -14,7 +14,12 @@ sys.path.insert(0, root)
 import cvxpnpl_amd as ca  # noqa: E402
 from cvxpnpl_amd import synth  # noqa: E402
 
-d = synth.make_pnp(10_000, 4, 2.0, seed=3)
+if len(sys.argv) > 1 and sys.argv[1] == "planar":
+    d = synth.make_pnp(10000, 10, 0.0, seed=1)
+    d["pts_3d"][:, :, 2] = 0.0
+    d["pts_2d"] = synth.project(d["pts_3d"], d["K"], d["R_gt"], d["t_gt"])
+else:
+    d = synth.make_pnp(10_000, 4, 2.0, seed=3)
 p2, p3, K = (torch.as_tensor(d[k], device="cuda") for k in ("pts_2d", "pts_3d", "K"))
 for R in (40, 120):
     res = ca.pnp_batch(p2, p3, K, max_iters=2500, rescue_from=R)
