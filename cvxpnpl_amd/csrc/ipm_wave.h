@@ -1,14 +1,16 @@
 // ipm_wave.h -- the interior-point solve of ipm_core.h with the 64 lanes of one wavefront working on ONE problem.
 //
-// cvxw::solve_one_wave calls this once for a problem that is still open after opts.rescue_from first-order iterations
-// (minimal and near-ambiguous configurations need hundreds to thousands of them, and a launch lasts as long as its slowest
-// problem): ~12 second-order iterations of ~20 us each whatever the conditioning, then the Douglas-Rachford iteration goes on
-// from W = Z - S / rho -- whose positive part is Z and whose dual hint rho (W+ - W) is S -- so that the usual attempt
-// (rounding, Newton polish, dual certificate, twin logic for rank 2, the reference's recovery) finishes the problem one
-// iteration later.  Same mathematics as cvx::ipm_solve (HKM direction, Mehrotra predictor-corrector, feasible start);
-// what is different is the step length: six candidate steps are Cholesky-tested side by side (one ten-lane group each).
-// All matrices are full 10 x 10 (row-major) / 21 x 21 in LDS; nothing of the first-order solver's LDS state survives
-// except the translation map and the canonical frame, which lie outside [0, 684) u [908, LDSW).
+// cvxw::solve_one_wave<.., IPM = true> (cvxw::rescue_wave_kernel only) calls this once for a problem that is still open after
+// opts.rescue_from first-order iterations (minimal and near-ambiguous configurations need hundreds to thousands of them, and a
+// launch lasts as long as its slowest problem): ~13 second-order iterations of ~26 us each whatever the conditioning, then
+// the Douglas-Rachford iteration goes on from W = Z - S / rho -- whose positive part is Z and whose dual hint rho (W+ - W) is
+// S -- so that the usual attempt (rounding, Newton polish, dual certificate, twin logic for rank 2, the reference's recovery)
+// finishes the problem one iteration later.  Same mathematics as cvx::ipm_solve (HKM direction, Mehrotra predictor-corrector,
+// feasible start); what is different is the step length: three candidate steps each for Z and for S are Cholesky-tested
+// side by side (one ten-lane group each) instead of backtracking.  Z, S, their directions and the 21 x 21 Schur matrix are
+// full matrices in LDS; the Cholesky factors are computed with one row per lane in registers (chol_rows*).  Nothing of the
+// first-order solver's LDS state survives the solve except the translation map and the canonical frame, which lie outside
+// [0, 684) u [908, LDSW_IPM); the caller assembles the problem again.
 #pragma once
 #include <hip/hip_runtime.h>
 
