@@ -165,6 +165,14 @@ __device__ __noinline__ int coop_ipm(double *L, int lane, double qe, int ei, int
     auto pack_term = [&](int i, int k) { return (int)kIpmTab.r[i][k] | ((int)kIpmTab.c[i][k] << 4) | (((int)kIpmTab.s[i][k] + 1) << 8); };
     int *TI = reinterpret_cast<int *>(L + I_TAB);
     if (lane < 63) TI[lane] = pack_term(lane / 3, lane % 3);
+    int sch_i[4], sch_j[4]; // Schur entries e = lane + 64 r (lower triangle, 231 of them): row and column
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int e = lane + 64 * r;
+        int i = 0, acc = 0;
+        while (acc + i + 1 <= e) { acc += i + 1; ++i; } // row i starts at i (i + 1) / 2
+        sch_i[r] = i < 21 ? i : 0; sch_j[r] = i < 21 ? e - acc : 0;
+    }
     int rhs_t[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) rhs_t[k] = lane < 21 ? pack_term(lane, k) : 0x100;
@@ -234,11 +242,11 @@ __device__ __noinline__ int coop_ipm(double *L, int lane, double qe, int ei, int
         CVXW_SYNC();
         IPM_CLK(1);
         // ---- Schur matrix M_ij = <A_i, Z A_j Si>, lower triangle: 231 entries dealt to the lanes
-#pragma unroll 1
-        for (int e = lane; e < 231; e += 64) {
-            int i = 0, acc = 0;
-            while (acc + i + 1 <= e) { acc += i + 1; ++i; } // row i starts at i (i + 1) / 2
-            const int j = e - acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = lane + 64 * r;
+            if (e >= 231) break;
+            const int i = sch_i[r], j = sch_j[r];
             int wi[3], wj[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) { wi[k] = TI[i * 3 + k]; wj[k] = TI[j * 3 + k]; }
