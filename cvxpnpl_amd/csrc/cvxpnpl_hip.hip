@@ -295,12 +295,18 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     // wave: -12 % at 2 k).
     if (o.first_check <= 0) o.first_check = layout == CVXPNPL_LAYOUT_LANE ? 6 : 5;
     // interior-point path for the problems still open after rescue_from iterations (ipm_wave.h): its queue lives in the workspace
-    // -1 (default): by problem size.  Slow convergence is a property of minimal and near-minimal configurations; with ten
-    // correspondences a problem that is still open after 32 or 48 iterations usually finishes within the next ~15, and the ~0.35 ms of
-    // the interior-point path would then end the launch later (profiles/r02/rescue_sweep.jsonl, launch time with 32 / 48 / 96:
-    // 1.81 / 1.84 / 2.36 ms for 10 k problems with N = 4, 1.09 / 1.26 / 1.58 for N = 5, 0.83 / 0.91 / 1.05 for N = 6, but
-    // 4.79 / 4.80 / 4.46 ms for 1 M with N = 10).
-    if (o.rescue_from < 0) o.rescue_from = (!a.Q45 && a.n_p + a.n_l <= 6) ? 32 : 96;
+    // -1 (default): by problem size.  Slow convergence is a property of minimal and near-minimal configurations
+    // (profiles/r02/remaining_iters.jsonl, 100 k problems each, first-order iterations only: with N = 4 / 5 / 6 / 7 correspondences
+    // 21 % / 3.8 % / 0.7 % / 0.14 % of the problems are still open after 32 iterations and 27 % / 17 % / 12 % / 6 % of those need more
+    // than the ~75 iterations an interior-point solve costs, slowest 1 455 / 1 037 / 581 / 227; with N = 8 the slowest takes 99, with
+    // N = 10 (1 M problems) 61, and a problem that is open after 48 finishes within the next 3-25).  A threshold below the natural tail
+    // of a workload sends problems through a 0.3 ms solve they did not need and ends the launch later: 100 k problems with N = 8
+    // 1.05 ms without the path, 1.35 ms with 96; 1 M with N = 10 4.46 / 4.75 ms with 96 / 32; against that 10 k problems with N = 4
+    // 4.77 / 1.78 ms, N = 6 (100 k) 3.42 / 1.91 ms without / with 32, N = 7 (100 k) 1.71 / 1.49 ms without / with 64.
+    if (o.rescue_from < 0) {
+        const int n = a.Q45 ? 8 : a.n_p + a.n_l;
+        o.rescue_from = n <= 6 ? 32 : (n == 7 ? 64 : 128);
+    }
     const bool rescue = o.variant == cvx::VAR_FULL && o.rescue_from > 0 && o.max_iters > o.rescue_from;
     if (rescue) {
         WsView wv;

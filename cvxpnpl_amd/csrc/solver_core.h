@@ -90,7 +90,7 @@ CVX_HD Opts default_opts()
     o.eps = 1e-9; o.max_iters = 2500; o.rho = 0.1; o.alpha = 1.4;
     o.first_check = 5; o.check_every = 2; o.res_tol = 1e-5; o.jacobi_sweeps = 12; o.jacobi_tol = 6e-2; o.warm_start = 1; o.rho_tail = 0.05; o.tail_from = 3; o.variant = VAR_FULL;
     o.adapt_every = 10; o.adapt_from = 40; o.adapt_mu = 2.0; o.adapt_tau = 2.0; o.stall_from = 300; o.stall_lam = 0.05; o.stall_res = 1e-3; o.stall_drop = 0.003;
-    o.rescue_from = -1; // (by problem size, cvxpnpl_hip.hip: 32 for minimal problems, 96 otherwise)
+    o.rescue_from = -1; // (by problem size, cvxpnpl_hip.hip: 32 for at most 6 correspondences, 64 for 7, 128 otherwise)
     return o;
 }
 

@@ -86,7 +86,7 @@ typedef struct {
     double stall_lam, stall_res, stall_drop;
     int32_t rescue_from; /* a problem still open after this many first-order iterations is finished by the interior-point path
                             (0 never; -1, the default: 32 for problems with at most 6 correspondences, where slow convergence is
-                            common, 96 otherwise; full variant only): ~12 second-order iterations whatever the conditioning, then
+                            common, 64 for 7, 128 otherwise; full variant only): ~12 second-order iterations whatever the conditioning, then
                             the first-order iteration goes on from the interior-point solution -- same rounding, polish, certificate
                             and recovery -- so that a launch no longer waits for a 1 000-iteration straggler (minimal and
                             near-ambiguous configurations; measured on 50 k four-point RANSAC hypotheses: 7.1 -> 2.9 ms).

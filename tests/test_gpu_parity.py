@@ -472,7 +472,7 @@ def test_interior_point_rescue_matches_first_order_solve(gpu):
                 assert (r["status"] == 0).sum() >= (ref["status"] == 0).sum()
                 assert r["iters"].max() <= rf + 120, r["iters"].max()
                 assert (r["iters"] > rf).sum() > 20  # the path was taken
-    # the default options have it on (-1: 32 iterations for problems with at most 6 correspondences, 96 otherwise)
+    # the default options have it on (-1: 32 iterations for problems with at most 6 correspondences, 64 for 7, 128 otherwise)
     r = _solve(gpu, d, 4, 0, max_iters=2500)
     assert r["iters"].max() <= 32 + 120 and (r["iters"] > 32).sum() > 20 and (r["status"] == 0).sum() >= (ref["status"] == 0).sum()
     with pytest.raises(RuntimeError, match="bad options"):
