@@ -16,7 +16,7 @@ _ip = C.POINTER(C.c_int32)
 
 # every symbol include/cvxpnpl_amd.h declares
 EXPORTS = (
-    "cvxpnpl_default_opts", "cvxpnpl_solve_batch", "cvxpnpl_solve_cost_batch", "cvxpnpl_recover_multi", "cvxpnpl_recover_multi_batch", "cvxpnpl_recover_multi_device", "cvxpnpl_assemble_batch",
+    "cvxpnpl_default_opts", "cvxpnpl_opts_size", "cvxpnpl_solve_batch", "cvxpnpl_solve_cost_batch", "cvxpnpl_recover_multi", "cvxpnpl_recover_multi_batch", "cvxpnpl_recover_multi_device", "cvxpnpl_assemble_batch",
     "cvxpnpl_assemble_large_batch", "cvxpnpl_assemble_large_scratch_bytes",
     "cvxpnpl_score_hypotheses", "cvxpnpl_pack_results", "cvxpnpl_synth_batch", "cvxpnpl_pose_errors", "cvxpnpl_disambiguate",
     "cvxpnpl_workspace_bytes", "cvxpnpl_set_workspace", "cvxpnpl_release_workspace", "cvxpnpl_calibration_copy",
@@ -31,11 +31,12 @@ STATUS_NAMES = {0: "certified", 1: "rank>1", 2: "uncertified", 3: "nonfinite", 4
 class Opts(C.Structure):
     """cvxpnpl_opts_t"""
     _fields_ = [
-        ("eps", C.c_double), ("max_iters", C.c_int32), ("rho", C.c_double), ("alpha", C.c_double),
+        ("struct_size", C.c_uint32), ("eps", C.c_double), ("max_iters", C.c_int32), ("rho", C.c_double), ("alpha", C.c_double),
         ("first_check", C.c_int32), ("check_every", C.c_int32), ("res_tol", C.c_double),
         ("jacobi_sweeps", C.c_int32), ("jacobi_tol", C.c_double), ("warm_start", C.c_int32), ("rho_tail", C.c_double), ("tail_from", C.c_int32), ("lane_iters", C.c_int32), ("layout", C.c_int32),
         ("variant", C.c_int32), ("adapt_every", C.c_int32), ("adapt_from", C.c_int32), ("adapt_mu", C.c_double), ("adapt_tau", C.c_double),
         ("stall_from", C.c_int32), ("stall_lam", C.c_double), ("stall_res", C.c_double), ("stall_drop", C.c_double), ("rescue_from", C.c_int32),
+        ("f32_sweeps_until", C.c_int32),
     ]
 
 
@@ -59,6 +60,10 @@ def lib():
     L = C.CDLL(LIB_PATH)
     L.cvxpnpl_default_opts.argtypes = [C.POINTER(Opts)]
     L.cvxpnpl_default_opts.restype = None
+    L.cvxpnpl_opts_size.argtypes = []
+    L.cvxpnpl_opts_size.restype = C.c_size_t
+    if L.cvxpnpl_opts_size() != C.sizeof(Opts):  # the hand-written mirror above and the header must move in lock-step
+        raise ImportError(f"cvxpnpl_amd._lib.Opts has {C.sizeof(Opts)} bytes, {LIB_PATH} expects {L.cvxpnpl_opts_size()} (include/cvxpnpl_amd.h)")
     L.cvxpnpl_solve_batch.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_int32, C.POINTER(Opts), C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -95,21 +95,21 @@ def pnpl_batch(pts_2d, line_2d, pts_3d, line_3d, K, eps: float = 1e-9, max_iters
     n_l = l3.shape[-3] if l3 is not None and l3.dim() >= 4 else 0
     if n_p == 0 and n_l == 0:
         raise ValueError("need at least one point or line correspondence ([B,n,3] points / [B,n,2,3] lines)")
-    if n_p + 2 * n_l >= LARGE_N and (p3 if n_p else l3).shape[0] > 0:
-        # the scalability regime (benchmarks/scalability/pnp.py:37-40: up to 10^4 points per problem): bandwidth-shaped
-        # blocked assembly, then the solve at the cost seam -- instead of one wavefront streaming the problem
-        Bt, Qt = assemble_batch(pts_2d, line_2d, p3 if n_p else None, l3 if n_l else None, K, device=device, blocked=True)
-        return solve_cost_batch(Qt, Bt, eps=eps, max_iters=max_iters, want_Z=want_Z, device=device, **solver_opts)
     batch = (p3 if n_p else l3).shape[0]
-    p2, l2 = _pair_2d(pts_2d, line_2d, device, batch, n_p, n_l)
-    p3 = p3.reshape(batch, n_p, 3) if n_p else None
-    l3 = l3.reshape(batch, n_l, 2, 3) if n_l else None
     if n_p and n_l and l3.shape[0] != batch:
         raise ValueError(f"points and lines describe different batches ({batch} vs {l3.shape[0]})")
     Kd = _as_dev(K, device, (3, 3))
     per = int(Kd.dim() == 3)
-    if per and Kd.shape[0] != batch:
+    if Kd.dim() not in (2, 3) or (per and Kd.shape[0] != batch):
         raise ValueError("K must be [3,3] or [batch,3,3]")
+    if n_p + 2 * n_l >= LARGE_N and batch > 0:
+        # the scalability regime (benchmarks/scalability/pnp.py:37-40: up to 10^4 points per problem): bandwidth-shaped
+        # blocked assembly, then the solve at the cost seam -- instead of one wavefront streaming the problem
+        Bt, Qt = assemble_batch(pts_2d, line_2d, p3 if n_p else None, l3 if n_l else None, Kd, device=device, blocked=True)
+        return solve_cost_batch(Qt, Bt, eps=eps, max_iters=max_iters, want_Z=want_Z, device=device, **solver_opts)
+    p2, l2 = _pair_2d(pts_2d, line_2d, device, batch, n_p, n_l)
+    p3 = p3.reshape(batch, n_p, 3) if n_p else None
+    l3 = l3.reshape(batch, n_l, 2, 3) if n_l else None
     opts = _lib.default_opts(eps=float(eps), max_iters=int(max_iters), **solver_opts)
     with torch.cuda.device(device):
         R, t, status, iters, cost, work, Z = _alloc_outputs(batch, device, want_Z)
@@ -289,8 +289,12 @@ def _single(pts_2d, line_2d, pts_3d, line_3d, K, eps, max_iters, verbose) -> Lis
     p2, p3 = b(pts_2d, (2,)), b(pts_3d, (3,))
     l2, l3 = b(line_2d, (2, 2)), b(line_3d, (2, 3))
     Kn = np.asarray(K, dtype=np.float64)
-    # res_tol = 0: an uncertifiable problem runs to max_iters like the reference's solve (the batch entry points
-    # stop such problems at the fixed-point residual opts.res_tol instead)
+    # res_tol = 0: the fixed-point-residual exit of the batch entry points is off.  This is NOT "to max_iters like the reference"
+    # for every problem (the advisor's finding): a problem still open after opts.rescue_from first-order iterations (32 / 64 /
+    # 128 by size) gets its iterate from the interior-point solve of the same SDP -- the SDP optimum to a gap of 1e-10, where the
+    # reference + SCS would hand back whatever 2 500 first-order iterations reached -- and a Z that has settled at rank > 1
+    # (opts.stall_from = 300) stops as rank > 1.  Certified poses are unaffected; for non-tight problems the poses recovered
+    # from Z (recover_multi) are those of the converged Z, not of SCS's iterate.  INTEGRATION.md section 3 says the same.
     res = pnpl_batch(p2, l2, p3, l3, Kn, eps=eps, max_iters=max_iters, want_Z=True, res_tol=0.0)
     Bt = Qt = None
     if int(res.status[0]) == 1:
@@ -337,6 +341,10 @@ def assemble_batch(pts_2d, line_2d, pts_3d, line_3d, K, device=None, blocked=Non
     p2, l2 = _pair_2d(pts_2d, line_2d, dev, batch, n_p, n_l)
     Kd = _as_dev(K, dev, (3, 3))
     per = int(Kd.dim() == 3)
+    if Kd.dim() not in (2, 3) or (per and Kd.shape[0] != batch):  # (a short [m,3,3] would be read out of bounds by the kernels)
+        raise ValueError("K must be [3,3] or [batch,3,3]")
+    if n_p and n_l and l3.shape[0] != batch:
+        raise ValueError(f"points and lines describe different batches ({batch} vs {l3.shape[0]})")
     if blocked is None:
         blocked = n_p + 2 * n_l >= LARGE_N
     p3 = p3.reshape(batch, n_p, 3) if n_p else None

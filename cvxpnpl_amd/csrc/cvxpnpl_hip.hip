@@ -5,7 +5,9 @@
 #include <string.h>
 
 #include <map>
+#include <memory>
 #include <mutex>
+#include <vector>
 #include <utility>
 
 #include "../../include/cvxpnpl_amd.h"
@@ -35,6 +37,7 @@ struct BatchArgs {
 // Hybrid schedule: a lane that is not finished by then parks its iterate in ws[b] and queues b for
 // resume_wave_kernel, so that one slow problem cannot hold the other 63 lanes (and the whole launch)
 // for hundreds of lane-serial iterations.
+template <bool DBL>
 __global__ void __launch_bounds__(64) solve_lane_kernel(BatchArgs a, cvx::Opts o, int handoff_at, int32_t *qcount, int32_t *qentries, double *ws)
 {
     __shared__ double lds_const[72 * 64];
@@ -46,7 +49,8 @@ __global__ void __launch_bounds__(64) solve_lane_kernel(BatchArgs a, cvx::Opts o
     double Z[55];
     // TWIN = false: the hand-off comes before iteration 6, where the twin-candidate logic would start.
     // The cost matrix and the translation map (72 doubles) live in this lane's LDS column, not in registers.
-    cvx::solve_problem<false, cvx::LdsStore>(pv, o, sol, a.Z ? Z : nullptr, handoff_at, ws + b * 56, cvx::LdsStore{lds_const + threadIdx.x});
+    // DBL: the eigen-solve on float64 columns (opts.f32_sweeps_until below the length of this phase; the default is packed single precision)
+    cvx::solve_problem<false, cvx::LdsStore, cvx::VAR_FULL, DBL>(pv, o, sol, a.Z ? Z : nullptr, handoff_at, ws + b * 56, cvx::LdsStore{lds_const + threadIdx.x});
     if (sol.status == -1) {
         const int q = atomicAdd(qcount, 1);
         qentries[q] = (int32_t)b;
@@ -101,6 +105,22 @@ struct Workspace { void *ptr = nullptr; size_t bytes = 0; int64_t cap = 0; size_
 std::mutex g_ws_mutex;
 std::map<std::pair<int, void *>, Workspace> g_ws;
 thread_local char g_err[512] = "";
+
+// One solve is two or three dependent launches that share the queue and the parked-iterate buffer of their (device, stream):
+// host threads calling on the SAME stream (ctypes drops the GIL; torch's default stream is shared by every thread) must not
+// interleave them (A.first, B.first, A.resume: B would overwrite A's parked slots and A's resume kernel would drain B's queue
+// entries with A's pointers), and the workspace must not be freed / regrown between a thread's pointer fetch and its launches.
+// So the launches of a solve, from get_workspace to the last kernel, run under the mutex of their (device, stream); threads on
+// different streams do not contend.  (Round 2 had dropped the global launch mutex of round 1: the advisor's finding.)
+std::mutex g_lm_mutex;
+std::map<std::pair<int, void *>, std::unique_ptr<std::mutex>> g_launch_mutexes; // never erased: a mutex may be held while its workspace goes
+std::mutex &launch_mutex(int dev, void *stream)
+{
+    std::lock_guard<std::mutex> lock(g_lm_mutex);
+    std::unique_ptr<std::mutex> &p = g_launch_mutexes[std::make_pair(dev, stream)];
+    if (!p) p.reset(new std::mutex);
+    return *p;
+}
 
 size_t queue_entries_bytes(int64_t cap) { return ((size_t)(cap + cvxw::RESUME_GRID_MAX) * sizeof(int32_t) + 255) & ~(size_t)255; }
 size_t hybrid_queue_bytes(int64_t cap) { return 256 + 2 * queue_entries_bytes(cap); }
@@ -200,7 +220,9 @@ cvx::Opts to_core(const cvxpnpl_opts_t *opts)
         o.adapt_every = opts->adapt_every; o.adapt_from = opts->adapt_from; o.adapt_mu = opts->adapt_mu; o.adapt_tau = opts->adapt_tau;
         o.stall_from = opts->stall_from; o.stall_lam = opts->stall_lam; o.stall_res = opts->stall_res; o.stall_drop = opts->stall_drop;
         o.rescue_from = opts->rescue_from;
+        o.f32_sweeps_until = opts->f32_sweeps_until;
     }
+    if (o.f32_sweeps_until < 0) o.f32_sweeps_until = cvx::F32_SWEEPS_DEFAULT;
     return o;
 }
 
@@ -232,7 +254,11 @@ void cvxpnpl_default_opts(cvxpnpl_opts_t *opts)
     opts->adapt_every = o.adapt_every; opts->adapt_from = o.adapt_from; opts->adapt_mu = o.adapt_mu; opts->adapt_tau = o.adapt_tau;
     opts->stall_from = o.stall_from; opts->stall_lam = o.stall_lam; opts->stall_res = o.stall_res; opts->stall_drop = o.stall_drop;
     opts->rescue_from = o.rescue_from;
+    opts->f32_sweeps_until = -1;
+    opts->struct_size = (uint32_t)sizeof(cvxpnpl_opts_t);
 }
+
+size_t cvxpnpl_opts_size(void) { return sizeof(cvxpnpl_opts_t); }
 
 static int check_args(int64_t batch, int32_t n_p, const double *p2, const double *p3, int32_t n_l, const double *l2,
                       const double *l3, const double *K)
@@ -249,7 +275,13 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
 {
     const int64_t batch = a.batch;
     if (!a.R || !a.t || !a.status) { snprintf(g_err, sizeof(g_err), "cvxpnpl: R, t and status outputs are required"); return -1; }
-    if (opts && (opts->max_iters < 1 || !(opts->rho > 0) || !(opts->eps > 0) || opts->check_every < 1 || opts->first_check < 0 ||
+    if (opts && opts->struct_size != (uint32_t)sizeof(cvxpnpl_opts_t)) {
+        // a caller built against another revision of cvxpnpl_opts_t: refuse rather than read fields that are not there
+        snprintf(g_err, sizeof(g_err), "cvxpnpl: options block of %u bytes, this library's cvxpnpl_opts_t has %zu (cvxpnpl_default_opts / cvxpnpl_opts_size)",
+                 opts->struct_size, sizeof(cvxpnpl_opts_t));
+        return -1;
+    }
+    if (opts && (opts->max_iters < 1 || opts->f32_sweeps_until < -1 || !(opts->rho > 0) || !(opts->eps > 0) || opts->check_every < 1 || opts->first_check < 0 ||
                  (opts->variant != CVXPNPL_VARIANT_FULL && opts->variant != CVXPNPL_VARIANT_RC) || opts->adapt_every < 0 ||
                  (opts->adapt_every > 0 && !(opts->adapt_mu >= 1.0 && opts->adapt_tau > 1.0)) || opts->rescue_from < -1)) {
         snprintf(g_err, sizeof(g_err), "cvxpnpl: bad options");
@@ -257,6 +289,9 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     }
     cvx::Opts o = to_core(opts);
     if (!opts) o.first_check = 0; // (by layout, below)
+    int cur_dev = 0;
+    if (hipGetDevice(&cur_dev) != hipSuccess) { snprintf(g_err, sizeof(g_err), "cvxpnpl: hipGetDevice failed"); return -2; }
+    std::lock_guard<std::mutex> launch_lock(launch_mutex(cur_dev, stream)); // (see launch_mutex)
     hipStream_t s = (hipStream_t)stream;
     const int block = 64;
     int64_t grid = (batch + block - 1) / block;
@@ -285,7 +320,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     int quad_iters = opts ? opts->lane_iters : -1;
     if (quad_iters <= 0) quad_iters = 7; // measured (4 problem sets at 10 k, same box): 5: 0.242 ms, 7: 0.233, 8: 0.235, 10: 0.240; 24 k: 7 = 10 (round 1, second phase as a call: 8-12)
     if (quad_iters > 16) quad_iters = 16; // the quad phase runs its eigen-solve sweeps in single precision: fine for the first iterations, not for a slow tail (quad_kernel.h)
-    const bool penta = layout == CVXPNPL_LAYOUT_PENTA;
+    const bool penta = layout == CVXPNPL_LAYOUT_PENTA && !(o.f32_sweeps_until < quad_iters); // (float64 sweeps: built for the sixteen-lane geometry only)
     if (layout == 9 || penta) layout = CVXPNPL_LAYOUT_QUAD; // experiment (tools/README.md): quad iterations only, 3 waves/SIMD: quad iterations only (solve_quad_kernel<1>)
     if (layout == CVXPNPL_LAYOUT_QUAD && !(quad_iters >= 1 && o.max_iters > quad_iters)) layout = CVXPNPL_LAYOUT_WAVE;
     // First certificate attempt (0 = by layout): after 5 iterations 94 % of N = 10 problems certify, after 6 99 %.  In the lane-hybrid
@@ -328,6 +363,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
         qa.a = w; qa.o = o; qa.handoff_at = quad_iters; qa.qcount = count; qa.qentries = entries; qa.ws = ws;
         if (opts && opts->layout == 9) hipLaunchKernelGGL((cvxq::solve_quad_kernel<1, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // experiment
         else if (penta) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 12>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
+        else if (o.f32_sweeps_until < quad_iters) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 16, true>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // float64 sweeps (A/B mode)
         else hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         const int64_t rgrid = batch < cvxw::RESUME_GRID_MAX ? batch : cvxw::RESUME_GRID_MAX;
         if (rescue) launch_rescue(batch, s, w, o, count, entries, ws); // (both queues in one launch)
@@ -351,7 +387,8 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
             if (!get_workspace(batch, cvxw::RS_LANE, stream, wv)) return -2;
             int32_t *count = wv.count, *entries = wv.entries;
             double *ws = wv.parked;
-            hipLaunchKernelGGL(solve_lane_kernel, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws);
+            if (o.f32_sweeps_until < lane_iters) hipLaunchKernelGGL(solve_lane_kernel<true>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws); // float64 sweeps (A/B mode)
+            else hipLaunchKernelGGL(solve_lane_kernel<false>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws);
             const int64_t rgrid = batch < cvxw::RESUME_GRID_MAX ? batch : cvxw::RESUME_GRID_MAX;
             launch_resume(rgrid, s, w, o, count, entries, ws, false);
         } else {
@@ -534,6 +571,7 @@ int cvxpnpl_set_workspace(void *d_workspace, size_t bytes, void *stream)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { snprintf(g_err, sizeof(g_err), "cvxpnpl: hipGetDevice failed"); return -2; }
+    std::lock_guard<std::mutex> launch_lock(launch_mutex(dev, stream)); // no solve of this stream is between its launches
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     Workspace &w = g_ws[std::make_pair(dev, stream)];
     if (w.ptr && w.owned) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(w.ptr); }
@@ -550,12 +588,19 @@ int cvxpnpl_release_workspace(void *stream, int32_t all_streams)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { snprintf(g_err, sizeof(g_err), "cvxpnpl: hipGetDevice failed"); return -2; }
-    std::lock_guard<std::mutex> lock(g_ws_mutex);
-    for (auto it = g_ws.begin(); it != g_ws.end();) {
-        if (it->first.first == dev && (all_streams || it->first.second == stream)) {
-            if (it->second.ptr && it->second.owned) { (void)hipStreamSynchronize((hipStream_t)it->first.second); (void)hipFree(it->second.ptr); }
-            it = g_ws.erase(it);
-        } else ++it;
+    std::vector<void *> streams;
+    {
+        std::lock_guard<std::mutex> lock(g_ws_mutex);
+        for (auto &kv : g_ws)
+            if (kv.first.first == dev && (all_streams || kv.first.second == stream)) streams.push_back(kv.first.second);
+    }
+    for (void *st : streams) { // lock order as in a solve: the stream's launch mutex, then the workspace table
+        std::lock_guard<std::mutex> launch_lock(launch_mutex(dev, st));
+        std::lock_guard<std::mutex> lock(g_ws_mutex);
+        auto it = g_ws.find(std::make_pair(dev, st));
+        if (it == g_ws.end()) continue;
+        if (it->second.ptr && it->second.owned) { (void)hipStreamSynchronize((hipStream_t)st); (void)hipFree(it->second.ptr); }
+        g_ws.erase(it);
     }
     return 0;
 }

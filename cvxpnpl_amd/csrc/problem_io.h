@@ -54,7 +54,7 @@ CVX_HD bool assemble(const ProblemView &v, double *B, double *Q9)
     return ok && (det == det) && det != 0.0;
 }
 
-template <bool TWIN = true, class ST = RegStore, int VAR = VAR_FULL>
+template <bool TWIN = true, class ST = RegStore, int VAR = VAR_FULL, bool DBL = TWIN>
 CVX_HD void solve_problem(const ProblemView &v, const Opts &o, Solution &sol, double *Zout, int handoff_at = 0,
                           double *handoff = nullptr, ST st = ST())
 {
@@ -70,7 +70,7 @@ CVX_HD void solve_problem(const ProblemView &v, const Opts &o, Solution &sol, do
         CVX_UNROLL for (int i = 0; i < 45; ++i) Q9[i] = NAN;
         CVX_UNROLL for (int i = 0; i < 27; ++i) B[i] = NAN;
     }
-    solve_sdp<TWIN, ST, VAR>(Q9, B, o, sol, Zout, handoff_at, handoff, st);
+    solve_sdp<TWIN, ST, VAR, DBL>(Q9, B, o, sol, Zout, handoff_at, handoff, st);
     if (!ok) { CVX_UNROLL for (int i = 0; i < 3; ++i) sol.t[i] = NAN; }
 }
 

@@ -229,6 +229,21 @@ __device__ __forceinline__ void pair_cs(float d, float gam, bool rot, bool tie_n
     s = t * c;
 }
 
+// The same in float64 throughout (F64SW instantiation: Opts::f32_sweeps_until below the length of this phase -- the A/B mode
+// of the single-precision sweeps; seeds v_rsq_f64 / v_rcp_f64 + two Newton steps, <= 2 ulp)
+__device__ __forceinline__ void pair_cs_f64(double d, double gam, bool rot, bool tie_neg, double &c, double &s, double &t)
+{
+    const double g2 = 2.0 * gam;
+    const double h2 = d * d + g2 * g2 + 1e-290;
+    const double h = h2 * cvx::rsqrt_(h2);
+    double tf = g2 * cvx::rcp(fabs(d) + h);
+    const bool neg = d < 0.0 || (d == 0.0 && tie_neg);
+    tf = neg ? -tf : tf;
+    t = rot ? tf : 0.0;
+    c = cvx::rsqrt_(1.0 + t * t);
+    s = t * c;
+}
+
 // In-place LDL^T of the symmetric matrix held 3-4 entries per lane, pivot rows broadcast through LDS;
 // returns the smallest pivot (cvx::ldl_min_pivot).
 template <class OWN>
@@ -304,7 +319,8 @@ __device__ __forceinline__ void finish_own(QuadArgsPtr kp, unsigned parked, doub
 // MODE 0: the schedule described above.  MODE 1 (experiment, tools/phase_a_time.sh): the iterations only -- no
 // certificate code is compiled in, every problem is parked after handoff_at iterations -- to measure what the
 // iteration phase costs at the occupancy it gets without the certificate's registers.
-template <int MODE, int OCC = 2, int LPP = 16>
+// F64SW: the Jacobi sweeps, G = (W + sigma I) V and the warm-start eigenvectors in float64 (see pair_cs_f64)
+template <int MODE, int OCC = 2, int LPP = 16, bool F64SW = false>
 __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
 {
     typedef Geo<LPP> G_;
@@ -535,6 +551,10 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
     f2 v[5]; // unit eigenvector owned by this lane (warm start of the next eigen-solve), rows 2i and 2i + 1, single precision
 #pragma unroll
     for (int i = 0; i < 5; ++i) { v[i].x = (gl == 2 * i) ? 1.0f : 0.0f; v[i].y = (gl == 2 * i + 1) ? 1.0f : 0.0f; }
+    double vd[10]; // (F64SW) the same in float64
+#pragma unroll
+    for (int i = 0; i < 10; ++i) vd[i] = (gl == i) ? 1.0 : 0.0;
+    auto vrow = [&](int i) -> double { if constexpr (F64SW) return vd[i]; else return (double)((i & 1) ? v[i >> 1].y : v[i >> 1].x); };
     int it = 0, total_sweeps = 0, next_check = o.first_check;
     bool have_prev = false;
     int reused = 0; // consecutive checks that took over the previous check's pose (cvx::REUSE_MAX, see cvx::solve_sdp)
@@ -589,6 +609,67 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
 #pragma unroll
             for (int m = 0; m < EPL; ++m) fro += w.wgt(m) * W[m] * W[m];
             sigma = 1.5 * cvx::sqrt_fast(grp_sum<LPP>(L, gl, fro)) + 1e-300;
+            int sweeps = 0;
+            double g[10];
+            float alf = 0.0f; // (single-precision path: squared norm of this lane's column)
+            f2 q[5];
+            if constexpr (F64SW) {
+                // float64 throughout: W to LDS as the full symmetric matrix (row stride 10), g = (W + sigma I) v, 22 ds_bpermute per step
+#pragma unroll
+                for (int m = 0; m < EPL; ++m)
+                    if (w.ok(m)) { L[Q_WF + w.ei(m) * 10 + w.ej(m)] = W[m]; L[Q_WF + w.ej(m) * 10 + w.ei(m)] = W[m]; }
+                CVXW_SYNC();
+                double qd[10];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) {
+                    const double2 *row = L2 + (Q_WF + i * 10) / 2;
+                    double a = 0.0;
+#pragma unroll
+                    for (int kk = 0; kk < 5; ++kk) { const double2 r = row[kk]; a = fma(r.x, vd[2 * kk], a); a = fma(r.y, vd[2 * kk + 1], a); }
+                    qd[i] = fma(sigma, vd[i], a);
+                }
+                double alq = 0.0;
+#pragma unroll
+                for (int i = 0; i < 10; ++i) alq = fma(qd[i], qd[i], alq);
+CVXQ_PH(0);
+                bool active = !done; // row-uniform
+                do {
+                    bool coarse = false;
+#pragma unroll
+                    for (int st = 0; st < 9; ++st) {
+                        const int partner = (int)((ptab >> (4 * st)) & 15);
+                        const int addr = lane_base4 + (partner << 2);
+                        double oq[10];
+#pragma unroll
+                        for (int i = 0; i < 10; ++i) oq[i] = bperm(addr, qd[i]);
+                        const double be = bperm(addr, alq);
+                        double gam = 0.0;
+#pragma unroll
+                        for (int i = 0; i < 10; ++i) gam = fma(qd[i], oq[i], gam);
+                        const double g2 = gam * gam, ab = alq * be;
+                        coarse |= (partner != gl) && g2 > tol2 * ab;
+                        double c, sn, t;
+                        pair_cs_f64(be - alq, gam, active && (partner != gl) && g2 > 1e-30 * ab, gl > partner, c, sn, t);
+#pragma unroll
+                        for (int i = 0; i < 10; ++i) qd[i] = c * qd[i] - sn * oq[i];
+                        alq -= t * gam;
+                    }
+                    alq = 0.0; // exact norms once per sweep (the incremental update drifts)
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) alq = fma(qd[i], qd[i], alq);
+                    const bool grp_more = grp_bits<LPP>(__ballot(coarse && active), grp) != 0;
+                    if (active) ++sweeps;
+                    active = active && grp_more && sweeps < o.jacobi_sweeps;
+                } while (__any(active));
+#pragma unroll
+                for (int i = 0; i < 10; ++i) g[i] = qd[i];
+                al = alq;
+                {
+                    const double il = gl < 10 ? cvx::rsqrt_(alq) : 0.0;
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) vd[i] = qd[i] * il;
+                }
+            } else {
             // g = (W + sigma I) v in single precision like the sweeps that follow (see there): W goes to LDS as floats, rows
             // padded to 12 (three b128 reads per row instead of five), two rows of v per packed FMA
             float *Lf = reinterpret_cast<float *>(L + Q_WF);
@@ -597,7 +678,6 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
                 if (w.ok(m)) { const float wf = (float)W[m]; Lf[w.ei(m) * 12 + w.ej(m)] = wf; Lf[w.ej(m) * 12 + w.ei(m)] = wf; }
             CVXW_SYNC();
             const float sigf = (float)sigma;
-            f2 q[5];
 #pragma unroll
             for (int i = 0; i < 10; ++i) {
                 const float4 *row = reinterpret_cast<const float4 *>(Lf + i * 12);
@@ -612,7 +692,6 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
                 const float gi = fmaf(sigf, vi, a.x + a.y);
                 if (i & 1) q[i >> 1].y = gi; else q[i >> 1].x = gi;
             }
-            float alf;
             {
                 f2 a = q[0] * q[0];
 #pragma unroll
@@ -627,7 +706,6 @@ CVXQ_PH(0); /* fro, LDS copy of W, g = (W + sigma I) v */
             // the first 7-16 iterations are concerned (single precision throughout only hurts tails of > 100 iterations,
             // which are the wave-per-problem kernel's).  Half the exchange (11 ds_bpermute per step), half the arithmetic.
             const float tol2f = (float)tol2;
-            int sweeps = 0;
             bool active = !done; // row-uniform
             do {
                 bool coarse = false;
@@ -662,13 +740,13 @@ CVXQ_PH(0); /* fro, LDS copy of W, g = (W + sigma I) v */
                 if (active) ++sweeps;
                 active = active && grp_more && sweeps < o.jacobi_sweeps;
             } while (__any(active));
-            double g[10];
 #pragma unroll
             for (int i = 0; i < 5; ++i) { g[2 * i] = (double)q[i].x; g[2 * i + 1] = (double)q[i].y; }
             al = 0.0;
 #pragma unroll
             for (int i = 0; i < 10; ++i) al += g[i] * g[i];
 CVXQ_PH(1); /* jacobi */
+            }
             total_sweeps += sweeps;
             // ---- Wp = sum_{lam > 0} lam u u^T from (g, w g), w = lam / |g|^2
             const double lp = cvx::sqrt_fast(al), lam = lp - sigma;
@@ -679,7 +757,7 @@ CVXQ_PH(1); /* jacobi */
                 for (int i = 0; i < 5; ++i) L2[(Q_Y + gl * 10) / 2 + i] = make_double2(g[2 * i], g[2 * i + 1]);
                 L[Q_Y + 100 + gl] = wpos;
             }
-            {
+            if constexpr (!F64SW) {
                 const float ilf = col ? __builtin_amdgcn_rsqf(alf) : 0.0f;
                 const f2 il2 = {ilf, ilf};
 #pragma unroll
@@ -713,7 +791,7 @@ CVXQ_PH(2); /* Wp */
             CVXW_SYNC(); // (the Wp gathers above are done with Q_Y)
             if (gl == jmax) {
 #pragma unroll
-                for (int i = 0; i < 5; ++i) { L[Q_M + 22 + 2 * i] = (double)v[i].x; L[Q_M + 22 + 2 * i + 1] = (double)v[i].y; }
+                for (int i = 0; i < 10; ++i) L[Q_M + 22 + i] = vrow(i);
             }
             CVXW_SYNC();
             double vloc[10];
@@ -997,7 +1075,7 @@ CVXQ_PH(7); /* projection + update */
                     if (gl + LPP * m < 27) park(slot + cvxw::RS_B + gl + LPP * m, L[Q_B + gl + LPP * m]);
                 if (gl < 10) {
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) { park(slot + cvxw::RS_V + gl * 10 + 2 * i, (double)v[i].x); park(slot + cvxw::RS_V + gl * 10 + 2 * i + 1, (double)v[i].y); }
+                    for (int i = 0; i < 10; ++i) park(slot + cvxw::RS_V + gl * 10 + i, vrow(i));
                 }
                 if (gl == 0) { park(slot + cvxw::RS_IT, (double)it); park(slot + cvxw::RS_NC, (double)next_check); }
                 parked = true;

@@ -75,7 +75,10 @@ struct Opts {
     double stall_drop; // ... (relative decrease of the second eigenvalue between two attempts that still counts as settled)
     int variant;       // VAR_FULL: the 22 equalities of cvxpnpl.py:387-451; VAR_RC: the 16 of benchmarks/toolkit/methods/rc.py:9-64
     int rescue_from;   // kernels: a solve still open after this many iterations goes to the interior-point path (ipm_core.h); 0: never, < 0: by problem size
+    int f32_sweeps_until; // kernels: the Jacobi sweeps of the PSD projection run on single-precision columns during the first this many
+                          // iterations of a solve (< 0: default, F32_SWEEPS_DEFAULT); 0: every sweep in float64, rotation angles included
 };
+constexpr int F32_SWEEPS_DEFAULT = 64;
 
 // Constraint sets.  VAR_RC is the reference's ablation "rc" (benchmarks/toolkit/methods/rc.py:16-35): the six row
 // orthonormality rows (kron(I3, E_ij), cvxpnpl.py:404-418) are left out -- in the closed forms below that means the
@@ -91,6 +94,7 @@ CVX_HD Opts default_opts()
     o.first_check = 5; o.check_every = 2; o.res_tol = 1e-5; o.jacobi_sweeps = 12; o.jacobi_tol = 6e-2; o.warm_start = 1; o.rho_tail = 0.05; o.tail_from = 3; o.variant = VAR_FULL;
     o.adapt_every = 10; o.adapt_from = 40; o.adapt_mu = 2.0; o.adapt_tau = 2.0; o.stall_from = 300; o.stall_lam = 0.05; o.stall_res = 1e-3; o.stall_drop = 0.003;
     o.rescue_from = -1; // (by problem size, cvxpnpl_hip.hip: 32 for at most 6 correspondences, 64 for 7, 128 otherwise)
+    o.f32_sweeps_until = -1;
     return o;
 }
 
@@ -377,6 +381,7 @@ struct Eig {
     double G[10][10]; // G[j][i]: column j, row i
     double n2[10];    // squared column norms = lam'_j^2
     double sigma;
+    bool exact = false; // device build: rotation angles in float64 as well (Opts::f32_sweeps_until == 0); the host build always is
 };
 
 CVX_HD void eig_load(Eig &e, const double *W)
@@ -427,10 +432,20 @@ CVX_HD void eig_norms(Eig &e)
 // The rotation is exactly orthogonal (c^2 + s^2 = 1 to rounding) for ANY t, so t may be
 // approximate; c is refined to full double precision.  Device build: v_rsq_f64 /
 // v_rcp_f64 seeds + Newton steps instead of the IEEE sqrt / divide expansions.
-CVX_HD void jacobi_cs(double al, double be, double gam, bool rot, double &c, double &s, double &t)
+CVX_HD void jacobi_cs(double al, double be, double gam, bool rot, double &c, double &s, double &t, bool exact = false)
 {
     const double d = be - al, g2 = 2.0 * gam;
 #if defined(__HIP_DEVICE_COMPILE__)
+    if (exact) { // (uniform) everything in float64: Opts::f32_sweeps_until == 0, the A/B mode of the single-precision sweeps
+        const double h2 = d * d + g2 * g2 + 1e-290;
+        const double h = h2 * rsqrt_(h2);
+        double tt = g2 * rcp(fabs(d) + h);
+        tt = d < 0 ? -tt : tt;
+        t = rot ? tt : 0.0;
+        c = rsqrt_(1.0 + t * t);
+        s = t * c;
+        return;
+    }
     // tan(theta) in single precision (one v_rsq_f32 + one v_rcp_f32): an angle that is right to
     // ~1e-7 still annihilates g_p . g_q to 1e-7 of its size per rotation, far below the
     // sweep tolerance.  cos(theta) then comes from a float seed refined by one double Newton
@@ -487,7 +502,7 @@ CVX_HD double eig_step5(Eig &e)
     CVX_UNROLL for (int k = 0; k < 5; ++k) {
         const double al = e.n2[P[k]], be = e.n2[Q[k]];
         const double g2 = gam[k] * gam[k], ab = al * be;
-        jacobi_cs(al, be, gam[k], g2 > 1e-30 * ab, c[k], s[k], t[k]);
+        jacobi_cs(al, be, gam[k], g2 > 1e-30 * ab, c[k], s[k], t[k], e.exact);
         const double r = g2 / ab;
         worst = r > worst ? r : worst;
         e.n2[P[k]] = al - t[k] * gam[k];
@@ -554,6 +569,8 @@ struct EigF {
     double sigma;
 };
 CVX_HD double eig_g(const Eig &e, int j, int i) { return e.G[j][i]; }
+CVX_HD void set_exact(Eig &e, bool x) { e.exact = x; }
+CVX_HD void set_exact(EigF &, bool) {}
 CVX_HD double eig_g(const EigF &e, int j, int i) { return (double)((i & 1) ? e.G[j][i >> 1].y : e.G[j][i >> 1].x); }
 CVX_HD void eig_unit(Eig &e)
 {
@@ -1342,7 +1359,9 @@ CVX_HD void fallback_pose(QV Qs, double tr, const double *v, const double *v2, i
 template <bool TWIN> struct EigOf { typedef Eig type; };
 template <> struct EigOf<false> { typedef EigF type; };
 
-template <bool TWIN = true, class ST = RegStore, int VAR = VAR_FULL>
+// DBL: the eigen-solve on float64 columns (Eig) instead of packed single precision (EigF); the lane phase (TWIN = false) runs
+// single precision unless Opts::f32_sweeps_until asks for less than its length (cvxpnpl_hip.hip)
+template <bool TWIN = true, class ST = RegStore, int VAR = VAR_FULL, bool DBL = TWIN>
 CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution &sol, double *Zout, int handoff_at = 0,
                       double *handoff = nullptr, ST st = ST())
 {
@@ -1389,7 +1408,8 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
     double W[55], Wp[55];
     CVX_UNROLL for (int i = 0; i < 55; ++i) W[i] = 0;
     W[sidx(9, 9)] = 1.0;
-    typename EigOf<TWIN>::type e; // (TWIN = false: the lane phase, at most 5 iterations: single-precision sweeps)
+    typename EigOf<DBL>::type e; // (TWIN = false: the lane phase, at most 6 iterations: single-precision sweeps by default)
+    set_exact(e, o.f32_sweeps_until == 0);
     Cert c;
     c.ok = false;
     int it = 0, next_check = o.first_check;

@@ -495,7 +495,7 @@ struct WaveArgs {
 // the translation map and the unit eigenvectors of the last iterate -- so that the wavefront that takes the problem over
 // neither re-reads and re-assembles the correspondences nor starts its first eigen-solve cold (2-3 iteration-equivalents
 // off the tail of every launch: the slowest problems are exactly the handed-over ones).
-constexpr int F32_SWEEPS_UNTIL = 64; // eigen-solve sweeps in single precision during the first iterations (solve_one_wave)
+constexpr int F32_SWEEPS_UNTIL = cvx::F32_SWEEPS_DEFAULT; // eigen-solve sweeps in single precision during the first iterations of a solve; Opts::f32_sweeps_until overrides (0: never)
 constexpr int RS_W = 0, RS_IT = 55, RS_LANE = 56;           // lane schedule: 56 doubles per problem
 constexpr int RS_Q = 56, RS_B = 112, RS_NC = 139, RS_V = 140, RS_FULL = 240; // quad schedule: + Q (55, vech order, 0 outside the 9x9 block), B (27), the iteration of the next certificate attempt, V (100: [column][row])
 
@@ -830,8 +830,8 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
         int sweeps = 0;
         bool more;
         CVXW_PH(PH_EIG_SETUP);
-        if (it < F32_SWEEPS_UNTIL) {
-            // The sweeps of the first F32_SWEEPS_UNTIL iterations run in single precision (columns as floats in LDS, two rows per
+        if (it < (o.f32_sweeps_until < 0 ? F32_SWEEPS_UNTIL : o.f32_sweeps_until)) {
+            // The sweeps of the first F32_SWEEPS_UNTIL iterations (Opts::f32_sweeps_until) run in single precision (columns as floats in LDS, two rows per
             // packed FMA, rotation parameters without the double refinements): the columns only have to become orthogonal
             // to the sweep tolerance, the iterate is a dual hint whose certificate is verified in double.  Host experiment
             // (10 k problems each of PnP N=10 / N=6 sigma 5 / N=4, PnPL 5+5): iteration histograms identical to double
@@ -891,7 +891,7 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
                     const double g2 = gam * gam, ab = al * be;
                     coarse |= g2 > tol2 * ab;
                     double c, s, t;
-                    cvx::jacobi_cs(al, be, gam, g2 > 1e-30 * ab, c, s, t);
+                    cvx::jacobi_cs(al, be, gam, g2 > 1e-30 * ab, c, s, t, o.f32_sweeps_until == 0);
                     L[CA + jl] = c * ca - s * cb;
                     L[CB + jl] = s * ca + c * cb;
                     if (ji == 0) { L[NA + jk] = al - t * gam; L[NB + jk] = be + t * gam; }

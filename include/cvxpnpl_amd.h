@@ -57,6 +57,10 @@ enum {
 };
 
 typedef struct {
+    uint32_t struct_size; /* sizeof(cvxpnpl_opts_t) of the header the CALLER was built against: cvxpnpl_default_opts fills it in, every
+                             entry point that takes options rejects a block whose size is not this library's (return -1,
+                             cvxpnpl_last_error names both sizes) instead of reading fields that are not there.  cvxpnpl_opts_size()
+                             returns the library's value for bindings that mirror the struct by hand (ctypes, cgo, JNI). */
     double eps;        /* absolute duality-gap tolerance; reference `eps` (cvxpnpl.py:527), default 1e-9 */
     int32_t max_iters; /* iteration cap; reference `max_iters` (cvxpnpl.py:528), default 2500 */
     double rho;        /* ADMM penalty on the trace-normalised cost, default 0.1 */
@@ -91,9 +95,19 @@ typedef struct {
                             and recovery -- so that a launch no longer waits for a 1 000-iteration straggler (minimal and
                             near-ambiguous configurations; measured on 50 k four-point RANSAC hypotheses: 7.1 -> 2.9 ms).
                             Costs one more (mostly idle) kernel launch per solve in the wave and lane layouts. */
+    int32_t f32_sweeps_until; /* The reference computes in float64 throughout (numpy defaults, cvxpnpl.py:475-513).  So does this library
+                            -- inputs, Gram sums, iterate, polish, dual certificate, outputs -- with ONE exception: during the first
+                            iterations of a solve the Jacobi sweeps of the PSD projection (and the product (W + sigma I) V that starts them)
+                            run on single-precision columns; a pose is only ever reported CERTIFIED after the float64 chain polish -> dual ->
+                            LDL^T -> gap has succeeded on it.  This field bounds the exception: sweeps are single precision while the
+                            iteration count of the solve is below it.  -1 (default): 64.  0: never -- every sweep, rotation angles
+                            included, in float64 (the A/B mode: `value_all_f64` of bench.py, tests/test_precision_modes.py).  The quad
+                            and lane phases (at most 16 / 6 iterations) run entirely in one precision: single only if the whole phase lies
+                            below the bound, float64 otherwise. */
 } cvxpnpl_opts_t;
 
 void cvxpnpl_default_opts(cvxpnpl_opts_t *opts);
+size_t cvxpnpl_opts_size(void); /* sizeof(cvxpnpl_opts_t) in this build of the library (see struct_size) */
 
 /*
  * Solve `batch` independent problems, each with n_p point and n_l line correspondences

@@ -37,6 +37,53 @@ def test_default_opts_match_reference_defaults(L):
         _lib.default_opts(nonsense=1)
 
 
+def test_opts_struct_is_size_guarded(L):
+    """cvxpnpl_opts_t carries its own size: a caller built against another revision of the struct (e.g. round 1's,
+    shorter) is refused with a launch-level error instead of having fields read from beyond its buffer."""
+    from cvxpnpl_amd import _lib
+
+    assert L.cvxpnpl_opts_size() == C.sizeof(_lib.Opts)
+    o = _lib.default_opts()
+    assert o.struct_size == C.sizeof(_lib.Opts) and o.f32_sweeps_until == -1
+    dummy = (C.c_double * 64)()  # never dereferenced: the size check comes before any launch
+    p = C.cast(dummy, C.c_void_p)
+
+    def call(opts_ptr):
+        return L.cvxpnpl_solve_batch(1, 4, p, p, 0, None, None, p, 0, opts_ptr, p, p, p, None, None, None, None, None)
+
+    class OldOpts(C.Structure):  # the struct as round 2 shipped it: no struct_size, no f32_sweeps_until -- a short buffer
+        _fields_ = [f for f in _lib.Opts._fields_ if f[0] not in ("struct_size", "f32_sweeps_until")]
+
+    old = OldOpts()
+    C.memmove(C.byref(old), C.byref(o, 8), C.sizeof(old))
+    assert call(C.cast(C.pointer(old), C.POINTER(_lib.Opts))) == -1
+    assert b"options block" in L.cvxpnpl_last_error() and str(C.sizeof(_lib.Opts)).encode() in L.cvxpnpl_last_error()
+    o.struct_size = C.sizeof(_lib.Opts) - 8
+    assert call(C.byref(o)) == -1 and b"options block" in L.cvxpnpl_last_error()
+    o.struct_size = 0
+    assert call(C.byref(o)) == -1
+    rc = L.cvxpnpl_solve_cost_batch(1, p, p, C.byref(o), p, p, p, None, None, None, None, None)
+    assert rc == -1 and b"options block" in L.cvxpnpl_last_error()
+
+
+def test_integration_doc_mirrors_the_opts_struct():
+    """INTEGRATION.md's ctypes block is generated from _lib.Opts (tools/gen_integration_opts.py): field names, order, types"""
+    from cvxpnpl_amd import _lib
+
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blk = doc[doc.index("<!-- opts:begin -->"):doc.index("<!-- opts:end -->")]
+    fields = re.findall(r'\("([a-z_0-9]+)", C\.(c_[a-z0-9]+)\)', blk)
+    assert fields == [(n, t.__name__) for n, t in _lib.Opts._fields_], "run python tools/gen_integration_opts.py"
+    hdr = open(os.path.join(ROOT, "include", "cvxpnpl_amd.h")).read()
+    body = hdr[hdr.index("typedef struct {"):hdr.index("} cvxpnpl_opts_t;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for typ, decl in re.findall(r"\b(uint32_t|int32_t|double)\s+([a-z_0-9, ]+);", body):
+        names += [(d.strip(), typ) for d in decl.split(",")]
+    ct = {"uint32_t": "c_uint", "int32_t": "c_int", "double": "c_double"}  # (ctypes aliases c_uint32 -> c_uint, c_int32 -> c_int)
+    assert [(n, ct[t]) for n, t in names] == [(n, t.__name__) for n, t in _lib.Opts._fields_]
+
+
 def test_bad_arguments_are_rejected_without_gpu(L):
     from cvxpnpl_amd import _lib
 

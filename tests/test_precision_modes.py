@@ -1,0 +1,105 @@
+"""opts.f32_sweeps_until: the ONE place the float64 path uses single precision -- the Jacobi sweeps of the PSD projection
+during the first iterations of a solve -- can be switched off (0 = every sweep, rotation angles included, in float64; the
+reference is float64 throughout, cvxpnpl.py:475-513).  These tests make the claim "the single-precision sweeps change no
+result" checkable from outside: both modes through the C ABI on the same inputs, all four layouts.
+
+Bounds (stated, asserted):
+  * statuses identical;
+  * certified poses (status 0) equal to 1e-12 rad / 1e-12 relative translation -- a certified pose is the Newton-polished
+    stationary point of r^T Q r on SO(3), found in float64 in both modes; the iterate is only its starting point;
+  * uncertified exits (forced by max_iters = 2...12): the returned Z of the two modes within 2e-4 in Frobenius norm (|Z| = 4:
+    a young iterate that carries the ~1e-7 single-precision noise of each of its sweeps, amplified by a not-yet-contracting
+    iteration; measured worst 1.6e-5), same rank decision except where an eigenvalue sits within that distance of the 1e-3
+    threshold of cvxpnpl.py:502."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_parity import CASES, LAYOUTS, _solve, geodesic_np, gpu  # noqa: E402,F401
+
+
+@pytest.mark.parametrize("layout", sorted(LAYOUTS))
+@pytest.mark.parametrize("n_p,n_l,sigma,batch", CASES)
+def test_f32_and_f64_sweeps_agree(gpu, n_p, n_l, sigma, batch, layout):  # noqa: F811
+    from cvxpnpl_amd import synth
+
+    d = synth.make_pnpl(batch, n_p, n_l, sigma, seed=200 + n_p + 7 * n_l)
+    a = _solve(gpu, d, n_p, n_l, layout=LAYOUTS[layout], want_Z=True)                      # default: single-precision sweeps while young
+    b = _solve(gpu, d, n_p, n_l, layout=LAYOUTS[layout], want_Z=True, f32_sweeps_until=0)  # float64 throughout
+    # minimal problems run long: an iteration count may differ by a certificate attempt between the modes, the outcome may not
+    assert (a["status"] == b["status"]).all(), np.flatnonzero(a["status"] != b["status"])
+    cert = a["status"] == 0
+    assert cert.sum() >= batch - 2
+    worst_r = max(geodesic_np(a["R"][i], b["R"][i]) for i in np.flatnonzero(cert))
+    tn = np.maximum(1.0, np.linalg.norm(b["t"][cert], axis=1))
+    worst_t = (np.linalg.norm(a["t"][cert] - b["t"][cert], axis=1) / tn).max()
+    assert worst_r <= 1e-12 and worst_t <= 1e-12, (worst_r, worst_t)
+    # the certificate itself is a float64 statement in both modes
+    for r in (a, b):
+        gap = r["cost"][cert, 0] - r["cost"][cert, 1]
+        assert (gap >= -1e-15).all() and (gap <= 1.0001e-9 + 1e-12 * np.abs(r["cost"][cert, 0])).all()
+    if n_p + n_l >= 8:  # well-posed problems take the same number of iterations in both modes
+        assert (a["iters"] == b["iters"]).mean() >= 0.98, (a["iters"] != b["iters"]).sum()
+
+
+@pytest.mark.parametrize("layout", sorted(LAYOUTS))
+@pytest.mark.parametrize("max_iters", [2, 3, 5, 8, 12])
+def test_uncertified_exits_of_both_modes(gpu, layout, max_iters):  # noqa: F811
+    """solves cut short: the pose comes from the iterate, whose eigenvectors were single precision in one mode"""
+    from cvxpnpl_amd import synth
+
+    worst = 0.0
+    for n_p, n_l, sigma in [(10, 0, 2.0), (5, 5, 1.0), (4, 0, 1.0)]:
+        d = synth.make_pnpl(96, n_p, n_l, sigma, seed=31 + n_p + max_iters)
+        a = _solve(gpu, d, n_p, n_l, layout=LAYOUTS[layout], want_Z=True, max_iters=max_iters)
+        b = _solve(gpu, d, n_p, n_l, layout=LAYOUTS[layout], want_Z=True, max_iters=max_iters, f32_sweeps_until=0)
+        open_ = (a["status"] != 0) & (b["status"] != 0)
+        assert ((a["status"] == 0) == (b["status"] == 0)).all()  # what certifies, certifies in both modes
+        if not open_.any():
+            continue
+        dz = np.linalg.norm((a["Z"][open_] - b["Z"][open_]) * _VECH_W, axis=1)
+        worst = max(worst, float(dz.max()))
+        same = a["status"][open_] == b["status"][open_]
+        if not same.all():  # only where an eigenvalue of Z sits at the rank threshold (cvxpnpl.py:502)
+            for i in np.flatnonzero(open_)[~same]:
+                lam = np.linalg.eigvalsh(_unvech(b["Z"][i]))
+                assert np.abs(lam - 1e-3).min() < 2e-4, (i, lam)
+    assert worst <= 2e-4, worst
+
+
+def test_f64_mode_against_the_oracle(gpu, orc):  # noqa: F811
+    """the float64 mode is a full citizen: same oracle parity as the default (<= 1e-6 rad, north-star tolerance)"""
+    from cvxpnpl_amd import synth
+
+    d = synth.make_pnp(64, 10, sigma=2.0, seed=77)
+    o = orc.pnpl_batch(d["pts_2d"], None, d["pts_3d"], None, d["K"], eps=1e-11, max_iters=200000)
+    for layout in sorted(LAYOUTS):
+        r = _solve(gpu, d, 10, 0, layout=LAYOUTS[layout], f32_sweeps_until=0)
+        ok = (r["status"] == 0) & (o["n_poses"] == 1)
+        assert ok.sum() >= 63
+        g = synth.geodesic(r["R"][ok], o["R"][ok, 0])
+        assert g.max() < 1e-6 and np.abs(r["t"][ok] - o["t"][ok, 0]).max() < 1e-6
+
+
+def test_f32_sweeps_until_is_validated(gpu):  # noqa: F811
+    from cvxpnpl_amd import synth
+
+    d = synth.make_pnp(8, 10, sigma=1.0, seed=1)
+    with pytest.raises(RuntimeError, match="bad options"):
+        _solve(gpu, d, 10, 0, f32_sweeps_until=-2)
+    r = _solve(gpu, d, 10, 0, f32_sweeps_until=3)  # in between: phases shorter than the bound stay single, the others float64
+    assert (r["status"] == 0).all()
+
+
+def _unvech(z):
+    M = np.zeros((10, 10))
+    k = 0
+    for i in range(10):
+        for j in range(i, 10):
+            M[i, j] = M[j, i] = z[k]
+            k += 1
+    return M
+
+
+_VECH_W = np.array([1.0 if i == j else np.sqrt(2.0) for i in range(10) for j in range(i, 10)])

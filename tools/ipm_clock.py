@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["CVXPNPL_AMD_LIB"] = os.path.join(root, "cvxpnpl_amd", "libcvxpnpl_ipmclock.so")
+os.environ["CVXPNPL_AMD_LIB"] = os.path.join(root, "tools", "diag", "libcvxpnpl_ipmclock.so")
 sys.path.insert(0, root)
 import cvxpnpl_amd as ca  # noqa: E402
 from cvxpnpl_amd import synth  # noqa: E402

@@ -37,6 +37,6 @@ python tools/planar_timing.py > $out/planar_timing.jsonl 2>/dev/null
 python tools/iters_hist.py config5 2500 > $out/iters_config5.json 2>/dev/null
 tools/layout_sweep.sh > $out/layout_sweep.txt 2>/dev/null
 python tools/rescue_sweep.py 0 32 48 64 96 128 192 > $out/rescue_sweep.jsonl 2>/dev/null
-CVXPNPL_AMD_LIB=$root/cvxpnpl_amd/libcvxpnpl_ipmclock.so python tools/ipm_clock.py > $out/ipm_clock.jsonl 2>/dev/null
-CVXPNPL_AMD_LIB=$root/cvxpnpl_amd/libcvxpnpl_timeline.so python tools/timeline.py 10000 > $out/timeline_10k.json 2>/dev/null
+CVXPNPL_AMD_LIB=$root/tools/diag/libcvxpnpl_ipmclock.so python tools/ipm_clock.py > $out/ipm_clock.jsonl 2>/dev/null
+CVXPNPL_AMD_LIB=$root/tools/diag/libcvxpnpl_timeline.so python tools/timeline.py 10000 > $out/timeline_10k.json 2>/dev/null
 ls $out

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Shader cycles per phase of the quad kernel (diagnostics; GPU box):
-    hipcc ... -DCVXQ_PHASES -o cvxpnpl_amd/libcvxpnpl_phases.so ; CVXPNPL_AMD_LIB=.../libcvxpnpl_phases.so python tools/quad_phases.py [batch]
+    hipcc ... -DCVXQ_PHASES -o tools/diag/libcvxpnpl_phases.so ; CVXPNPL_AMD_LIB=tools/diag/libcvxpnpl_phases.so python tools/quad_phases.py [batch]
 batch = 4 is ONE wavefront alone on the chip: the latency regime of the stragglers that end every launch."""
 import json
 import os

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Wavefront timeline of the quad kernel (diagnostics; GPU box):
-    hipcc ... -DCVXQ_TIMELINE -o cvxpnpl_amd/libcvxpnpl_timeline.so ;  CVXPNPL_AMD_LIB=.../libcvxpnpl_timeline.so python tools/timeline.py [batch]
+    hipcc ... -DCVXQ_TIMELINE -o tools/diag/libcvxpnpl_timeline.so ;  CVXPNPL_AMD_LIB=tools/diag/libcvxpnpl_timeline.so python tools/timeline.py [batch]
 Every wavefront stamps the shader clock at its start, after the assembly, at the end of the quad loop and at its end;
 prints when waves start and end relative to the first start, their durations, and how busy the chip is over time."""
 import json
