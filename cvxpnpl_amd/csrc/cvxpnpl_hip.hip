@@ -13,6 +13,7 @@
 #include "../../include/cvxpnpl_amd.h"
 #include "problem_io.h"
 #include "solver_core.h"
+#include "lane_core.h"
 #include "wave_kernel.h"
 #include "quad_kernel.h"
 #include "score_kernel.h"
@@ -68,6 +69,35 @@ __global__ void __launch_bounds__(64) solve_lane_kernel(BatchArgs a, cvx::Opts o
 #pragma unroll
         for (int i = 0; i < 55; ++i) a.Z[b * 55 + i] = Z[i];
     }
+}
+
+// The same phase from the register-budgeted restatement of the scalar core (lane_core.h): the schedule the launch policy
+// actually uses -- handoff_at iterations, one certificate attempt after the last, single-precision sweeps -- written straight
+// line with streamed projections.  512 registers (256 + 256), ~20 spilled, 60 B of scratch per lane; the general core above needs
+// 2 640 B per lane (1 006 spilled registers, 1.1 GB of HBM traffic per 125 k launch) and stays for every other combination of
+// options (float64 sweeps, hand-off point != first attempt).
+__global__ void __launch_bounds__(64) solve_lane2_kernel(BatchArgs a, cvx::Opts o, int handoff_at, int32_t *qcount, int32_t *qentries, double *ws)
+{
+    __shared__ double lds_const[72 * 64];
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.batch) return;
+    cvx::ProblemView pv = cvx::make_view(b, a.n_p, a.p2, a.p3, a.n_l, a.l2, a.l3, a.K, a.K_per_problem);
+    if (a.Q45) { pv.Q45 = a.Q45 + b * 45; pv.B27 = a.B27 + b * 27; }
+    cvx::Solution sol;
+    cvxl::lane_phase(pv, o, sol, a.Z ? a.Z + b * 55 : nullptr, handoff_at, ws + b * 56, cvx::LdsStore{lds_const + threadIdx.x});
+    if (sol.status == -1) {
+        const int q = atomicAdd(qcount, 1);
+        qentries[q] = (int32_t)b;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a.R[b * 9 + i] = sol.R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a.t[b * 3 + i] = sol.t[i];
+    a.status[b] = sol.status;
+    if (a.iters) a.iters[b] = sol.iters;
+    if (a.cost) { a.cost[2 * b] = sol.cost; a.cost[2 * b + 1] = sol.dobj; }
+    if (a.work) { a.work[2 * b] = sol.rank; a.work[2 * b + 1] = sol.sweeps; }
 }
 
 // results of one shard as the 13-doubles-per-pose records the multi-GPU gather exchanges: R (9, row-major), t (3), status
@@ -320,6 +350,8 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     int quad_iters = opts ? opts->lane_iters : -1;
     if (quad_iters <= 0) quad_iters = 7; // measured (4 problem sets at 10 k, same box): 5: 0.242 ms, 7: 0.233, 8: 0.235, 10: 0.240; 24 k: 7 = 10 (round 1, second phase as a call: 8-12)
     if (quad_iters > 16) quad_iters = 16; // the quad phase runs its eigen-solve sweeps in single precision: fine for the first iterations, not for a slow tail (quad_kernel.h)
+    const bool lane_general = layout == 10; // experiment / A-B (tools/README.md): the lane schedule with the general scalar core (solve_lane_kernel)
+    if (lane_general) layout = CVXPNPL_LAYOUT_LANE;
     const bool penta = layout == CVXPNPL_LAYOUT_PENTA && !(o.f32_sweeps_until < quad_iters); // (float64 sweeps: built for the sixteen-lane geometry only)
     if (layout == 9 || penta) layout = CVXPNPL_LAYOUT_QUAD; // experiment (tools/README.md): quad iterations only, 3 waves/SIMD: quad iterations only (solve_quad_kernel<1>)
     if (layout == CVXPNPL_LAYOUT_QUAD && !(quad_iters >= 1 && o.max_iters > quad_iters)) layout = CVXPNPL_LAYOUT_WAVE;
@@ -387,7 +419,10 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
             if (!get_workspace(batch, cvxw::RS_LANE, stream, wv)) return -2;
             int32_t *count = wv.count, *entries = wv.entries;
             double *ws = wv.parked;
-            if (o.f32_sweeps_until < lane_iters) hipLaunchKernelGGL(solve_lane_kernel<true>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws); // float64 sweeps (A/B mode)
+            // the register-budgeted kernel covers the schedule of the defaults (one attempt, right at the hand-off point, single-precision sweeps)
+            const bool budgeted = !lane_general && o.f32_sweeps_until >= lane_iters && o.first_check == lane_iters && lane_iters >= 2 && o.warm_start != 0;
+            if (budgeted) hipLaunchKernelGGL(solve_lane2_kernel, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws);
+            else if (o.f32_sweeps_until < lane_iters) hipLaunchKernelGGL(solve_lane_kernel<true>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws); // float64 sweeps (A/B mode)
             else hipLaunchKernelGGL(solve_lane_kernel<false>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws);
             const int64_t rgrid = batch < cvxw::RESUME_GRID_MAX ? batch : cvxw::RESUME_GRID_MAX;
             launch_resume(rgrid, s, w, o, count, entries, ws, false);

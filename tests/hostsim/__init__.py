@@ -22,7 +22,8 @@ class Opts(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, "hostsim.cpp"), os.path.join(_CSRC, "solver_core.h"), os.path.join(_CSRC, "problem_io.h"), os.path.join(_CSRC, "ipm_core.h")]
+    srcs = [os.path.join(_HERE, "hostsim.cpp"), os.path.join(_CSRC, "solver_core.h"), os.path.join(_CSRC, "problem_io.h"), os.path.join(_CSRC, "ipm_core.h"),
+            os.path.join(_CSRC, "lane_core.h")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off",
                                "-o", _SO, srcs[0]])
@@ -148,3 +149,21 @@ def proj_affine_rc(E55, homog):
     E = np.ascontiguousarray(E55, dtype=np.float64).copy()
     lib().hs_proj_affine_rc(_p(E), int(homog))
     return E
+
+
+def lane_phase(pts_2d, pts_3d, line_2d, line_3d, K, iters, impl, opts=None, dbl=False):
+    """First phase of the lane-hybrid schedule on the host (hs_lane_phase): impl 0 = the general scalar core
+    (cvx::solve_problem<TWIN = false>), impl 1 = the register-budgeted restatement (cvxl::lane_phase).  status -1 = parked,
+    handoff [B,56] = W (55) + iteration count."""
+    a = [np.ascontiguousarray(v, dtype=np.float64) if v is not None else None for v in (pts_2d, pts_3d, line_2d, line_3d)]
+    K = np.ascontiguousarray(K, dtype=np.float64)
+    Bn = len(a[1]) if a[1] is not None else len(a[3])
+    n_p = a[1].shape[1] if a[1] is not None else 0
+    n_l = a[3].shape[1] if a[3] is not None else 0
+    o = opts or default_opts()
+    R, t = np.zeros((Bn, 3, 3)), np.zeros((Bn, 3))
+    st, it, sw = (np.zeros(Bn, np.int32) for _ in range(3))
+    cost, ho, Z = np.zeros((Bn, 2)), np.zeros((Bn, 56)), np.full((Bn, 55), np.nan)
+    lib().hs_lane_phase(Bn, n_p, _p(a[0]), _p(a[1]), n_l, _p(a[2]), _p(a[3]), _p(K), int(K.ndim == 3), C.byref(o), int(iters), int(impl), int(dbl),
+                        _p(R), _p(t), st.ctypes.data_as(_ip), it.ctypes.data_as(_ip), _p(cost), sw.ctypes.data_as(_ip), _p(ho), _p(Z))
+    return {"R": R, "t": t, "status": st, "iters": it, "cost": cost, "sweeps": sw, "handoff": ho, "Z": Z}

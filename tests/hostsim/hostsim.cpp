@@ -4,6 +4,7 @@
 #include "../../cvxpnpl_amd/csrc/solver_core.h"
 #include "../../cvxpnpl_amd/csrc/problem_io.h"
 #include "../../cvxpnpl_amd/csrc/ipm_core.h"
+#include "../../cvxpnpl_amd/csrc/lane_core.h"
 
 extern "C" {
 
@@ -108,3 +109,34 @@ extern "C" int hs_solve_cost_batch(int batch, const double *Q45, const double *B
 }
 
 extern "C" void hs_proj_affine_rc(double *E, int homog) { cvx::proj_affine<cvx::VAR_RC>(E, homog != 0); }
+
+// the first phase of the lane-hybrid schedule on the host: the general scalar core (impl 0: cvx::solve_problem<TWIN = false>, what
+// solve_lane_kernel<DBL> instantiates; dbl != 0: float64 eigen-solve) or the register-budgeted restatement (impl 1: cvxl::lane_phase,
+// what solve_lane2_kernel instantiates).  status -1 = parked: handoff[b][0..54] = W, [55] = iteration count.
+extern "C" int hs_lane_phase(int batch, int n_p, const double *pts_2d, const double *pts_3d, int n_l, const double *line_2d, const double *line_3d,
+                             const double *K, int K_per_problem, const cvx::Opts *opts, int iters, int impl, int dbl, double *R_out, double *t_out,
+                             int *status, int *its, double *cost, int *sweeps, double *handoff, double *Z_out)
+{
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int b = 0; b < batch; ++b) {
+        cvx::ProblemView pv = cvx::make_view(b, n_p, pts_2d, pts_3d, n_l, line_2d, line_3d, K, K_per_problem);
+        cvx::Solution sol;
+        sol.status = -7; sol.cost = NAN; sol.dobj = NAN;
+        for (int i = 0; i < 9; ++i) sol.R[i] = NAN;
+        for (int i = 0; i < 3; ++i) sol.t[i] = NAN;
+        double Z[55];
+        double *ho = handoff + (size_t)b * 56;
+        for (int i = 0; i < 56; ++i) ho[i] = NAN;
+        if (impl == 1) cvxl::lane_phase(pv, *opts, sol, Z_out ? Z : nullptr, iters, ho, cvx::RegStore());
+        else if (dbl) cvx::solve_problem<false, cvx::RegStore, cvx::VAR_FULL, true>(pv, *opts, sol, Z_out ? Z : nullptr, iters, ho);
+        else cvx::solve_problem<false, cvx::RegStore, cvx::VAR_FULL, false>(pv, *opts, sol, Z_out ? Z : nullptr, iters, ho);
+        for (int i = 0; i < 9; ++i) R_out[(size_t)b * 9 + i] = sol.R[i];
+        for (int i = 0; i < 3; ++i) t_out[(size_t)b * 3 + i] = sol.t[i];
+        status[b] = sol.status;
+        its[b] = sol.iters;
+        cost[2 * (size_t)b] = sol.cost; cost[2 * (size_t)b + 1] = sol.dobj;
+        sweeps[b] = sol.sweeps;
+        if (Z_out && sol.status >= 0) for (int i = 0; i < 55; ++i) Z_out[(size_t)b * 55 + i] = Z[i];
+    }
+    return 0;
+}
