@@ -56,8 +56,8 @@ def _kernel_name(layout, batch, blocked=False):
     if blocked:
         return "assemble_large_kernel (dominant: timed on its own) + assemble_finish_kernel + solve_wave_kernel"
     if layout == 0:
-        layout = 2 if batch < 2560 else (3 if batch < 24576 else 1)
-    return {1: "solve_lane_kernel + resume_wave_kernel (+ rescue_wave_kernel: problems beyond opts.rescue_from iterations)",
+        layout = 2 if batch < 2560 else (3 if batch < 20000 else 1)
+    return {1: "solve_lane2_kernel + resume_wave_kernel (+ rescue_wave_kernel: problems beyond opts.rescue_from iterations)",
             2: "solve_wave_kernel (+ rescue_wave_kernel: problems beyond opts.rescue_from iterations)",
             3: "solve_quad_kernel (+ rescue_wave_kernel: planar scenes and problems beyond opts.rescue_from iterations)",
             4: "solve_quad_kernel<12 lanes per problem> (+ rescue_wave_kernel: planar scenes and problems beyond opts.rescue_from iterations)"}.get(layout, f"experimental layout {layout}")
@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--workload", default="pnp_n10_10k", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override problems per GPU per step")
     ap.add_argument("--n", type=int, default=0, help="points per problem of --workload pnp_scal")
+    ap.add_argument("--blocked", default="auto", choices=("auto", "0", "1"), help="assembly path: 1 = cvxpnpl_assemble_large_batch + cost-seam solve, "
+                    "0 = in-kernel assembly, auto = the product's rule (cvxpnpl_amd.api.LARGE_N = 768 correspondence records)")
     ap.add_argument("--no-f64-ab", action="store_true", help="skip the extra all-float64 measurement (value_all_f64)")
     ap.add_argument("--sigma", type=float, default=None, help="pixel noise of the synthetic problems")
     ap.add_argument("--seed", type=int, default=42, help="seed of the synthetic problems (diagnostics: the default is the judged workload)")
@@ -167,7 +169,7 @@ def main():
     pending = []  # (work, packed) of the gather in flight: overlapped with the next batch's solve
     side = torch.cuda.Stream(dev) if gather else None   # pack + all_gather of the finished step, off the solve stream
     packed_done = [None] * nsets                         # event: the records of this output set have been packed (it may be overwritten)
-    blocked = n_p + 2 * n_l >= 192  # cvxpnpl_amd.api.LARGE_N: blocked assembly + cost-seam solve
+    blocked = (n_p + 2 * n_l >= 768) if args.blocked == "auto" else args.blocked == "1"  # cvxpnpl_amd.api.LARGE_N: blocked assembly + cost-seam solve
     if blocked:
         nb = L.cvxpnpl_assemble_large_scratch_bytes(batch, n_p, n_l)
         asm_scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
@@ -570,6 +572,8 @@ def _measure_pmc(args):
         child += ["--batch", str(args.batch)]
     if args.n:
         child += ["--n", str(args.n)]
+    if args.blocked != "auto":
+        child += ["--blocked", args.blocked]
     if args.sigma is not None:
         child += ["--sigma", str(args.sigma)]
     for kv in args.opt:

@@ -321,7 +321,12 @@ def solve_relaxation_rc(A: np.ndarray, B: np.ndarray, eps: float = 1e-9, max_ite
     return solve_relaxation(A, B, eps=eps, max_iters=max_iters, verbose=verbose, variant=_lib.VARIANT_RC)
 
 
-LARGE_N = 192  # correspondence records (points + 2 x lines) from which pnpl_batch assembles with the blocked kernel
+# Correspondence records (points + 2 x lines) from which pnpl_batch assembles with the blocked kernel.  Measured, wall clock of pnpl_batch,
+# blocked / in-kernel (profiles/r03/large_n_crossover.jsonl): 384 records 1.4-1.5 (1-1000 problems), 1.0 (4 k-16 k), 1.5 (50 k); 768: 1.17 / 1.14 /
+# 0.97 / 0.72 / 0.73 / 1.0 (1 / 256 / 1 k / 4 k / 16 k / 50 k problems); 1536: 0.84-0.88 / 0.72 / 0.5.  In-kernel assembly costs one memory
+# round trip and is parallel over problems only; the blocked kernel is parallel over correspondences and pays two more launches.
+# (Round 2 had 192, from launch-time measurements of 1 000-problem batches with the general lane core.)
+LARGE_N = 768
 
 
 def assemble_batch(pts_2d, line_2d, pts_3d, line_3d, K, device=None, blocked=None):

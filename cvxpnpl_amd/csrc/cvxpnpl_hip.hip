@@ -327,18 +327,18 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     int64_t grid = (batch + block - 1) / block;
     if (grid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl: batch too large for one launch"); return -1; }
     int layout = opts ? opts->layout : CVXPNPL_LAYOUT_AUTO;
-    // AUTO, by launch size (measured on one MI355X, M poses/s for wave / quad / lane-hybrid, PnP N = 10,
-    // profiles/r02/layout_sweep.txt; quad and lane phases with single-precision eigen-solve sweeps):
-    //   2 k: 16.8 / 16.0 / 7.3    5 k: 23.9 / 31.3 / 17.3   10 k: 28.1 / 46.3 / 31.5    16 k: 31.8 / 64.4 / 46.6
-    //   24 k: 33.0 / 67.9 / 67.4  32 k: 33.6 / 69.0 / 83.9  50 k: 38.0 / 84.9 / 113.2   125 k: 40.1 / 103.8 / 147.5
-    // * below 2560 problems a wavefront per problem: every SIMD gets work and a finished problem frees
-    //   its slot at once (3 problem sets per size: 2048: 16.8 wave / 15.5 quad, 2560: 17.1 / 19.6, 3072: 17.1 / 21.4);
+    // AUTO, by launch size (measured on one MI355X, M poses/s, PnP N = 10, one launch stream; wave / quad: profiles/r02/layout_sweep.txt,
+    // quad / lane-hybrid with the register-budgeted first phase: profiles/r03/layout_sweep2.txt, two problem sets per size):
+    //   wave / quad      2 k: 19.7 / 17.3    5 k: 27.9 / 34.1    10 k: 33.8 / 51.7
+    //   quad / lane     10 k: 51.6, 49.1 / 36.7, 41.0    16 k: 52.0, 73.5 / 48.7, 63.3    20 k: 74.5, 72.8 / 79.6, 73.4
+    //                   24 k: 74.5, 75.6 / 95.4, 86.8    32 k: 87.2, 87.7 / 115.0, 124.8   125 k: 113 / 247
+    // * below 2560 problems a wavefront per problem: every SIMD gets work and a finished problem frees its slot at once;
     // * from there four problems per wavefront (one per DPP row): 2.5x fewer instructions per problem;
-    // * from 24576 the lane-hybrid schedule (64 problems per wavefront for the first lane_iters iterations; 20 k: 69.6 quad / 56.0 lane, 24 k: 71.2 / 72.4, 28 k: 75.2 / 79.7; before the wave kernel went to single-precision sweeps: 24 k: 67.9 quad /
-    //   67.4 lane, 28 k: 75.0 / 78.0): fewest instructions, but it needs tens of thousands of problems to fill the chip.
-    // The problems the quad phase leaves open are finished by the same wavefront, those of the lane phase
-    // by a second kernel, one per wavefront in both cases.
-    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 2560 ? CVXPNPL_LAYOUT_WAVE : (batch < 24576 ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
+    // * from 20 000 the lane-hybrid schedule (64 problems per wavefront for the first lane_iters iterations): fewest instructions
+    //   per problem, but it needs ~20 k problems to give every SIMD a wavefront (round 2, general scalar core: crossover 24 576).
+    // The problems the quad phase leaves open are finished by the same wavefront, those of the lane phase by a second kernel,
+    // one per wavefront in both cases.
+    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 2560 ? CVXPNPL_LAYOUT_WAVE : (batch < 20000 ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
     // the 16-equality variant (benchmarks/toolkit/methods/rc.py) is built for the wave-per-problem layout only
     if (o.variant == cvx::VAR_RC) layout = CVXPNPL_LAYOUT_WAVE;
     cvxw::WaveArgs w;

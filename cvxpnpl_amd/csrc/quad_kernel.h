@@ -38,7 +38,10 @@ constexpr int Q_Y = 200;   // 124  eigen columns g [column][row] + weights (100.
 constexpr int Q_X = Q_Y + 40; // 56 entry scratch of the affine projection (over C_YV.. : never live together)
 constexpr int Q_B = 324;   // 28   translation map B (27)
 constexpr int Q_M = 352;   // 36   0.. R out, 12.. previous polished R, 22.. candidate eigenvector
-constexpr int QLDS = 388;
+#ifndef CVXQ_SLICE
+#define CVXQ_SLICE 388
+#endif
+constexpr int QLDS = CVXQ_SLICE; // (A/B knob: slice stride in doubles; 400 puts the two slices of a 32-lane half 32 banks apart)
 constexpr int C_RED = 388;  // 12   (twelve-lane groups only) partial values of a reduction over the group
 constexpr int QLDS12 = 404; // slice of a twelve-lane group: 404 * 2 dwords = 40 mod 64 banks, the six slices of a wave start 0, 40, 16, 56, 32, 8 banks in
 // Lanes per problem: 16 (a DPP row; four problems per wavefront) or 12 (five problems per wavefront + four dummy lanes that own a
