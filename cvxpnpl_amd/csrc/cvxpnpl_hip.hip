@@ -218,7 +218,8 @@ void launch_resume(int64_t rgrid, hipStream_t s, const cvxw::WaveArgs &w, const 
     ra.a = w; ra.o = o; ra.count_p = count; ra.entries = entries; ra.ws = ws;
     ra.ws_stride = full ? cvxw::RS_FULL : cvxw::RS_LANE; ra.ws_full = full ? 1 : 0;
     ra.count2 = nullptr; ra.entries2 = nullptr; ra.grid1 = 0;
-    hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64), 0, s, ra);
+    if (o.variant == cvx::VAR_RC) hipLaunchKernelGGL(cvxw::resume_wave_kernel_rc, dim3((unsigned)rgrid), dim3(64), 0, s, ra);
+    else hipLaunchKernelGGL(cvxw::resume_wave_kernel, dim3((unsigned)rgrid), dim3(64), 0, s, ra);
 }
 
 // last launch of a solve with opts.rescue_from in force: the problems the other kernels gave up on (w.rq_count / w.rq_entries) and,
@@ -230,7 +231,8 @@ void launch_rescue(int64_t batch, hipStream_t s, const cvxw::WaveArgs &w, const 
     cvxw::ResumeArgs ra;
     ra.a = w; ra.o = o; ra.count_p = w.rq_count; ra.entries = w.rq_entries; ra.ws = ws; ra.ws_stride = cvxw::RS_FULL; ra.ws_full = 1;
     ra.count2 = count; ra.entries2 = entries; ra.grid1 = (int)rgrid;
-    hipLaunchKernelGGL(cvxw::rescue_wave_kernel, dim3((unsigned)(count ? 2 * rgrid : rgrid)), dim3(64), 0, s, ra);
+    if (o.variant == cvx::VAR_RC) hipLaunchKernelGGL(cvxw::rescue_wave_kernel_rc, dim3((unsigned)(count ? 2 * rgrid : rgrid)), dim3(64), 0, s, ra);
+    else hipLaunchKernelGGL(cvxw::rescue_wave_kernel, dim3((unsigned)(count ? 2 * rgrid : rgrid)), dim3(64), 0, s, ra);
 }
 
 int set_err(const char *what, hipError_t e)
@@ -339,8 +341,10 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     // The problems the quad phase leaves open are finished by the same wavefront, those of the lane phase by a second kernel,
     // one per wavefront in both cases.
     if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 2560 ? CVXPNPL_LAYOUT_WAVE : (batch < 20000 ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
-    // the 16-equality variant (benchmarks/toolkit/methods/rc.py) is built for the wave-per-problem layout only
-    if (o.variant == cvx::VAR_RC) layout = CVXPNPL_LAYOUT_WAVE;
+    // The 16-equality variant (benchmarks/toolkit/methods/rc.py): wave-per-problem and, since round 3, the quad schedule (the
+    // constraint set is a template parameter of the kernels); the lane kernels and the interior-point path are built for the full set.
+    const bool rc = o.variant == cvx::VAR_RC;
+    if (rc && (layout == CVXPNPL_LAYOUT_LANE || layout == CVXPNPL_LAYOUT_PENTA || layout == 9 || layout == 10)) layout = CVXPNPL_LAYOUT_QUAD;
     cvxw::WaveArgs w;
     w.batch = batch; w.n_p = a.n_p; w.n_l = a.n_l; w.K_per_problem = a.K_per_problem;
     w.p2 = a.p2; w.p3 = a.p3; w.l2 = a.l2; w.l3 = a.l3; w.K = a.K;
@@ -348,13 +352,17 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     w.Q45 = a.Q45; w.B27 = a.B27;
     w.rq_count = nullptr; w.rq_entries = nullptr;
     int quad_iters = opts ? opts->lane_iters : -1;
+    // rc: the weaker relaxation certifies after ~21 iterations instead of 5 (N = 10): a longer first phase, first attempt later
+    if (quad_iters <= 0 && rc) quad_iters = 28;
     if (quad_iters <= 0) quad_iters = 7; // measured (4 problem sets at 10 k, same box): 5: 0.242 ms, 7: 0.233, 8: 0.235, 10: 0.240; 24 k: 7 = 10 (round 1, second phase as a call: 8-12)
-    if (quad_iters > 16) quad_iters = 16; // the quad phase runs its eigen-solve sweeps in single precision: fine for the first iterations, not for a slow tail (quad_kernel.h)
+    if (quad_iters > 48) quad_iters = 48; // (rc: up to 48 -- still inside the wave kernel's own single-precision window of 64)
+    if (quad_iters > 16 && !rc) quad_iters = 16; // the quad phase runs its eigen-solve sweeps in single precision: fine for the first iterations, not for a slow tail (quad_kernel.h)
     const bool lane_general = layout == 10; // experiment / A-B (tools/README.md): the lane schedule with the general scalar core (solve_lane_kernel)
     if (lane_general) layout = CVXPNPL_LAYOUT_LANE;
     const bool penta = layout == CVXPNPL_LAYOUT_PENTA && !(o.f32_sweeps_until < quad_iters); // (float64 sweeps: built for the sixteen-lane geometry only)
     if (layout == 9 || penta) layout = CVXPNPL_LAYOUT_QUAD; // experiment (tools/README.md): quad iterations only, 3 waves/SIMD: quad iterations only (solve_quad_kernel<1>)
     if (layout == CVXPNPL_LAYOUT_QUAD && !(quad_iters >= 1 && o.max_iters > quad_iters)) layout = CVXPNPL_LAYOUT_WAVE;
+    if (layout == CVXPNPL_LAYOUT_QUAD && rc && o.f32_sweeps_until < quad_iters) layout = CVXPNPL_LAYOUT_WAVE; // (rc quad kernel: single-precision sweeps only)
     // First certificate attempt (0 = by layout): after 5 iterations 94 % of N = 10 problems certify, after 6 99 %.  In the lane-hybrid
     // schedule every problem that fails the first attempt is parked and resumed one per wavefront, so the later attempt pays for its
     // extra iteration: 125 k problems 157 -> 164 M poses/s, PnPL 100 k 116 -> 126 M.  The quad and wave layouts keep 5 (quad with 6, launch
@@ -373,8 +381,12 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     if (o.rescue_from < 0) {
         const int n = a.Q45 ? 8 : a.n_p + a.n_l;
         o.rescue_from = n <= 6 ? 32 : (n == 7 ? 64 : 128);
+        // rc: the weaker relaxation is tight less often, and a problem whose relaxation is not tight crawls to max_iters -- 13 of 10 000
+        // N = 10 problems run all 2 500 iterations, 10 ms per launch whatever the layout (profiles/r03/rc_rate.txt) -- while the
+        // typical problem certifies after ~21 iterations, p99 ~60: hand over at 96 whatever the size
+        if (rc) o.rescue_from = 96;
     }
-    const bool rescue = o.variant == cvx::VAR_FULL && o.rescue_from > 0 && o.max_iters > o.rescue_from;
+    const bool rescue = o.rescue_from > 0 && o.max_iters > o.rescue_from;
     if (rescue) {
         WsView wv;
         const bool hybrid = layout == CVXPNPL_LAYOUT_QUAD || (layout == CVXPNPL_LAYOUT_LANE && o.max_iters > 1);
@@ -395,6 +407,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
         qa.a = w; qa.o = o; qa.handoff_at = quad_iters; qa.qcount = count; qa.qentries = entries; qa.ws = ws;
         if (opts && opts->layout == 9) hipLaunchKernelGGL((cvxq::solve_quad_kernel<1, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // experiment
         else if (penta) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 12>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
+        else if (rc) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 16, false, cvx::VAR_RC>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (o.f32_sweeps_until < quad_iters) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 16, true>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // float64 sweeps (A/B mode)
         else hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         const int64_t rgrid = batch < cvxw::RESUME_GRID_MAX ? batch : cvxw::RESUME_GRID_MAX;

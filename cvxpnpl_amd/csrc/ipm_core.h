@@ -23,35 +23,47 @@
 namespace cvx {
 
 constexpr int IPM_M = 21;
+// Independent rows of the constraint set: 21 of the reference's 22 (cvxpnpl.py:387-451), or -- VAR_RC, the ablation of
+// benchmarks/toolkit/methods/rc.py:9-64 -- its 16: the twelve triples 3..14, the three column sums (none of them implied once the
+// row sums are gone) and Z_99 = 1.
+CVX_HD constexpr int ipm_rows(int var) { return var == VAR_RC ? 16 : IPM_M; }
 
 // term k (0..2) of constraint i: A_i = sum_k coef_k sym(E_{r_k c_k}), sym(E_rc) = (E_rc + E_cr) / 2
-CVX_HD void ipm_term(int i, int k, int &r, int &c, double &coef)
+template <int VAR = VAR_FULL>
+CVX_HD constexpr void ipm_term(int i, int k, int &r, int &c, double &coef)
 {
+    if (VAR == VAR_RC) {
+        if (i < 12) { r = tri_i(i + 3, k); c = tri_j(i + 3, k); coef = tri_s(i + 3, k); return; }
+        if (i < 15) { r = c = 3 * (i - 12) + k; coef = 1.0; return; }      // column sums of the diagonal block D[r][c] = Z[3c+r, 3c+r]
+        r = c = 9; coef = k == 0 ? 1.0 : 0.0;                              // Z_99 = 1
+        return;
+    }
     if (i < 15) { r = tri_i(i, k); c = tri_j(i, k); coef = tri_s(i, k); return; }
     if (i < 18) { r = c = 3 * k + (i - 15); coef = 1.0; return; }          // row sums of the diagonal block D[r][c] = Z[3c+r, 3c+r]
     if (i < 20) { r = c = 3 * (i - 18) + k; coef = 1.0; return; }          // column sums (the third one is implied)
     r = c = 9; coef = k == 0 ? 1.0 : 0.0;                                  // Z_99 = 1
 }
-CVX_HD double ipm_b(int i) { return i < 15 ? 0.0 : 1.0; }
 
 // <A_i, X> for a symmetric X
+template <int VAR = VAR_FULL>
 CVX_HD double ipm_adot(int i, const double (*X)[10])
 {
     double s = 0;
     for (int k = 0; k < 3; ++k) {
         int r, c; double cf;
-        ipm_term(i, k, r, c, cf);
+        ipm_term<VAR>(i, k, r, c, cf);
         s += cf * X[r][c];
     }
     return s;
 }
 // Y += sum_i y_i A_i (sign: scale)
+template <int VAR = VAR_FULL>
 CVX_HD void ipm_adjoint(const double *y, double scale, double (*Y)[10])
 {
-    for (int i = 0; i < IPM_M; ++i)
+    for (int i = 0; i < ipm_rows(VAR); ++i)
         for (int k = 0; k < 3; ++k) {
             int r, c; double cf;
-            ipm_term(i, k, r, c, cf);
+            ipm_term<VAR>(i, k, r, c, cf);
             const double v = scale * cf * y[i];
             if (r == c) Y[r][r] += v;
             else { Y[r][c] += 0.5 * v; Y[c][r] += 0.5 * v; }
@@ -117,15 +129,19 @@ CVX_HD void ipm_mul(const double (*A)[10], const double (*B)[10], double (*C)[10
 
 // Interior-point solve of the relaxation for the trace-normalised cost q (45 packed, 9x9).  Z, S: 10x10 (full, symmetric).
 // Returns the number of iterations; gap = <Z, S> at exit.
+template <int VAR = VAR_FULL>
 CVX_HD int ipm_solve(const double *q, double (*Z)[10], double (*S)[10], double *y, double tol, int max_iters, double &gap)
 {
+    constexpr int NR = ipm_rows(VAR);
     for (int i = 0; i < 10; ++i)
         for (int j = 0; j < 10; ++j) {
             Z[i][j] = (i == j) ? (i < 9 ? 1.0 / 3.0 : 1.0) : 0.0;
             S[i][j] = (i < 9 && j < 9) ? q[qidx(i, j)] : 0.0;
         }
-    for (int i = 0; i < IPM_M; ++i) y[i] = 0.0;
-    y[15] = y[16] = y[17] = y[20] = -1.0; // S0 = q + I (q is positive semidefinite with trace 1)
+    for (int i = 0; i < NR; ++i) y[i] = 0.0;
+    // S0 = q + I (q is positive semidefinite with trace 1): the three row-sum rows (rc: column-sum rows) and the Z_99 row add up to I
+    if (VAR == VAR_RC) y[12] = y[13] = y[14] = y[15] = -1.0;
+    else y[15] = y[16] = y[17] = y[20] = -1.0;
     for (int i = 0; i < 10; ++i) S[i][i] += 1.0;
     int it = 0;
     gap = 0;
@@ -146,26 +162,26 @@ CVX_HD int ipm_solve(const double *q, double (*Z)[10], double (*S)[10], double *
             for (int i = 0; i < 10; ++i) Si[i][c] = e[i];
         }
         // Schur matrix M_ij = <A_i, Z A_j Si> (symmetric positive definite), factored once per iteration
-        double M[IPM_M][IPM_M];
-        for (int i = 0; i < IPM_M; ++i)
+        double M[NR][NR];
+        for (int i = 0; i < NR; ++i)
             for (int j = 0; j <= i; ++j) {
                 double s = 0;
                 for (int ka = 0; ka < 3; ++ka) {
                     int a, b; double ca;
-                    ipm_term(i, ka, a, b, ca);
+                    ipm_term<VAR>(i, ka, a, b, ca);
                     if (ca == 0.0) continue;
                     for (int kb = 0; kb < 3; ++kb) {
                         int p, r; double cb;
-                        ipm_term(j, kb, p, r, cb);
+                        ipm_term<VAR>(j, kb, p, r, cb);
                         if (cb == 0.0) continue;
                         s += ca * cb * 0.25 * (Z[a][p] * Si[r][b] + Z[a][r] * Si[p][b] + Z[b][p] * Si[r][a] + Z[b][r] * Si[p][a]);
                     }
                 }
                 M[i][j] = s;
             }
-        if (!ipm_chol(&M[0][0], IPM_M, IPM_M, 0.0)) break;
+        if (!ipm_chol(&M[0][0], NR, NR, 0.0)) break;
         // predictor (sigma = 0), then corrector with Mehrotra's sigma and second-order term
-        double dZ[10][10], dS[10][10], dy[IPM_M], Rc[10][10], T1[10][10], T2[10][10];
+        double dZ[10][10], dS[10][10], dy[NR], Rc[10][10], T1[10][10], T2[10][10];
         double sig_mu = 0.0;
         double ap = 1.0, ad = 1.0;
         for (int pass = 0; pass < 2; ++pass) {
@@ -177,11 +193,11 @@ CVX_HD int ipm_solve(const double *q, double (*Z)[10], double (*S)[10], double *
                 for (int i = 0; i < 10; ++i)
                     for (int j = 0; j < 10; ++j) Rc[i][j] -= 0.5 * (T2[i][j] + T2[j][i]);
             }
-            for (int i = 0; i < IPM_M; ++i) dy[i] = -ipm_adot(i, Rc);
-            ipm_chol_solve(&M[0][0], IPM_M, IPM_M, dy);
+            for (int i = 0; i < NR; ++i) dy[i] = -ipm_adot<VAR>(i, Rc);
+            ipm_chol_solve(&M[0][0], NR, NR, dy);
             for (int i = 0; i < 10; ++i)
                 for (int j = 0; j < 10; ++j) dS[i][j] = 0.0;
-            ipm_adjoint(dy, -1.0, dS);
+            ipm_adjoint<VAR>(dy, -1.0, dS);
             ipm_mul(Z, dS, T1);
             ipm_mul(T1, Si, T2);
             for (int i = 0; i < 10; ++i)
@@ -202,7 +218,7 @@ CVX_HD int ipm_solve(const double *q, double (*Z)[10], double (*S)[10], double *
         if (!(g == g) || !(g < gap)) break; // no progress: rounding has taken over; the iterate of the last good step stands
         for (int i = 0; i < 10; ++i)
             for (int j = 0; j < 10; ++j) { Z[i][j] += ap * dZ[i][j]; S[i][j] += ad * dS[i][j]; }
-        for (int i = 0; i < IPM_M; ++i) y[i] += ad * dy[i];
+        for (int i = 0; i < NR; ++i) y[i] += ad * dy[i];
         gap = g;
     }
     return it;
@@ -211,6 +227,7 @@ CVX_HD int ipm_solve(const double *q, double (*Z)[10], double (*S)[10], double *
 // From the interior-point iterate to the reference's outputs: eigen-decomposition of Z, rank-1 rounding + Newton polish + dual
 // certificate with S as the hint (or the twin-candidate logic for a rank-2 Z), exactly the decisions of cvx::solve_sdp at a
 // certificate attempt; the reference's own recovery when nothing certifies.  Qs: trace-normalised cost (45 packed), tr: trace.
+template <int VAR = VAR_FULL>
 CVX_HD void ipm_finish(const double *Qs, double tr, const Opts &o, const double (*Zf)[10], const double (*Sf)[10], Solution &sol, double *Zout)
 {
     double delta = o.eps / (8.0 * tr);
@@ -242,7 +259,7 @@ CVX_HD void ipm_finish(const double *Qs, double tr, const Opts &o, const double 
     if (!(l2 > 0.5 * l1)) {
         const double d0 = round_candidate(vt, c.R);
         polish_rotation(Qs, c.R, c.pobj);
-        dual_certificate<true, const double *, VAR_FULL>(Qs, Wd, Wz, 1.0, delta, d0, c); // hint: rho (Wp - W) = S
+        dual_certificate<true, const double *, VAR>(Qs, Wd, Wz, 1.0, delta, d0, c); // hint: rho (Wp - W) = S
     } else {
         double zp[10], zm[10], fp, fm;
         twin_candidates(vt, v2, zp, zm);
@@ -254,14 +271,14 @@ CVX_HD void ipm_finish(const double *Qs, double tr, const Opts &o, const double 
         ambiguous = fin && dp > 0 && dm > 0 && fabs(fp - fm) <= gtol && trc < 2.9;
         if (ambiguous) {
             c.pobj = fp;
-            dual_certificate<true, const double *, VAR_FULL>(Qs, Wd, Wz, 1.0, delta, dp, c);
+            dual_certificate<true, const double *, VAR>(Qs, Wd, Wz, 1.0, delta, dp, c);
             ambiguous = c.ok && (tr * (fabs(c.zSz) + 4.0 * delta) <= gap_tol);
             if (!ambiguous) c.ok = false;
         } else {
             const bool take_m = dm > 0 && (fm == fm) && (!(dp > 0) || !(fp == fp) || fm < fp);
             if (take_m) { for (int i = 0; i < 9; ++i) c.R[i] = Rm[i]; }
             c.pobj = take_m ? fm : fp;
-            dual_certificate<true, const double *, VAR_FULL>(Qs, Wd, Wz, 1.0, delta, take_m ? dm : dp, c);
+            dual_certificate<true, const double *, VAR>(Qs, Wd, Wz, 1.0, delta, take_m ? dm : dp, c);
         }
     }
     if (ambiguous) {
@@ -305,6 +322,7 @@ CVX_HD void ipm_finish(const double *Qs, double tr, const Opts &o, const double 
 }
 
 // One problem through the interior-point path: Q9 (45, unnormalised A^T A), B (27) -> Solution, like cvx::solve_sdp.
+template <int VAR = VAR_FULL>
 CVX_HD void ipm_problem(const double *Q9, const double *B, const Opts &o, Solution &sol, double *Zout)
 {
     double tr = 0;
@@ -325,9 +343,9 @@ CVX_HD void ipm_problem(const double *Q9, const double *B, const Opts &o, Soluti
     cn.on = false;
     canonicalise_planar(q, cn);
     double Z[10][10], S[10][10], y[IPM_M], gap;
-    const int nit = ipm_solve(q, Z, S, y, 1e-10, 40, gap);
+    const int nit = ipm_solve<VAR>(q, Z, S, y, 1e-10, 40, gap);
     sol.iters += nit;
-    ipm_finish(q, tr, o, Z, S, sol, Zout);
+    ipm_finish<VAR>(q, tr, o, Z, S, sol, Zout);
     if (cn.on) {
         canon_rotation_back(cn, sol.R);
         if (Zout) canon_congruence(cn, Zout, false);

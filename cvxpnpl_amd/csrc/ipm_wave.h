@@ -30,31 +30,45 @@ constexpr int I_QS = I_T1, I_W = I_M; // hand-over between cvxw::solve_pass and 
 constexpr int LDS_IPM_END = 2304;
 static_assert(LDS_IPM_END <= LDSW_IPM, "the interior-point solve needs LDSW_IPM doubles per wavefront");
 
-struct IpmTab { signed char r[21][3], c[21][3], s[21][3]; signed char ent_con[55], ent_sgn[55]; };
+struct IpmTab { signed char r[21][3], c[21][3], s[21][3]; signed char ent_con[55], ent_sgn[55]; signed char d1[10], d2[10]; };
+// (rows: cvx::ipm_term<VAR>; ent_con / ent_sgn: the row an off-diagonal entry belongs to and its sign; d1 / d2: the row(s) a
+// diagonal entry belongs to, -1: none)
+template <int VAR>
 constexpr IpmTab make_ipm_tab()
 {
     IpmTab t{};
+    constexpr int NR = cvx::ipm_rows(VAR), T0 = VAR == cvx::VAR_RC ? 3 : 0, NT = 15 - T0; // triples T0..14 are rows 0..NT-1
     for (int i = 0; i < 21; ++i)
         for (int k = 0; k < 3; ++k) {
             int r = 9, c = 9, s = 0;
-            if (i < 15) { r = cvx::tri_i(i, k); c = cvx::tri_j(i, k); s = cvx::tri_s(i, k) < 0 ? -1 : 1; }
-            else if (i < 18) { r = c = 3 * k + (i - 15); s = 1; }
+            if (i < NT) { r = cvx::tri_i(i + T0, k); c = cvx::tri_j(i + T0, k); s = cvx::tri_s(i + T0, k) < 0 ? -1 : 1; }
+            else if (VAR == cvx::VAR_RC) {
+                if (i < 15) { r = c = 3 * (i - 12) + k; s = 1; }
+                else if (i == 15) { r = c = 9; s = k == 0 ? 1 : 0; }
+            } else if (i < 18) { r = c = 3 * k + (i - 15); s = 1; }
             else if (i < 20) { r = c = 3 * (i - 18) + k; s = 1; }
             else { r = c = 9; s = k == 0 ? 1 : 0; }
+            if (i >= NR) { r = c = 9; s = 0; }
             t.r[i][k] = (signed char)r; t.c[i][k] = (signed char)c; t.s[i][k] = (signed char)s;
         }
     for (int e = 0; e < 55; ++e) { t.ent_con[e] = -1; t.ent_sgn[e] = 0; }
-    for (int i = 0; i < 15; ++i)
+    for (int i = 0; i < NT; ++i)
         for (int k = 0; k < 3; ++k) {
-            const int e = cvx::sidx(cvx::tri_i(i, k), cvx::tri_j(i, k));
+            const int e = cvx::sidx(cvx::tri_i(i + T0, k), cvx::tri_j(i + T0, k));
             t.ent_con[e] = (signed char)i;
-            t.ent_sgn[e] = (signed char)(cvx::tri_s(i, k) < 0 ? -1 : 1);
+            t.ent_sgn[e] = (signed char)(cvx::tri_s(i + T0, k) < 0 ? -1 : 1);
         }
+    for (int i = 0; i < 10; ++i) {
+        t.d1[i] = -1; t.d2[i] = -1;
+        if (i == 9) t.d1[i] = (signed char)(NR - 1);
+        else if (VAR == cvx::VAR_RC) t.d1[i] = (signed char)(12 + i / 3);
+        else { t.d1[i] = (signed char)(15 + i % 3); if (i / 3 < 2) t.d2[i] = (signed char)(18 + i / 3); }
+    }
     return t;
 }
 constexpr bool ipm_tab_ok()
 {
-    const IpmTab t = make_ipm_tab();
+    const IpmTab t = make_ipm_tab<cvx::VAR_FULL>();
     int hit[55] = {};
     for (int i = 0; i < 15; ++i)
         for (int k = 0; k < 3; ++k) {
@@ -63,10 +77,22 @@ constexpr bool ipm_tab_ok()
         }
     for (int e = 0; e < 55; ++e)
         if (hit[e] > 1) return false;
+    // the tables restate cvx::ipm_term
+    for (int v = 0; v < 2; ++v) {
+        const IpmTab u = v ? make_ipm_tab<cvx::VAR_RC>() : make_ipm_tab<cvx::VAR_FULL>();
+        for (int i = 0; i < cvx::ipm_rows(v); ++i)
+            for (int k = 0; k < 3; ++k) {
+                int r = 0, c = 0; double cf = 0;
+                if (v) cvx::ipm_term<cvx::VAR_RC>(i, k, r, c, cf); else cvx::ipm_term<cvx::VAR_FULL>(i, k, r, c, cf);
+                if (u.s[i][k] != (cf > 0 ? 1 : (cf < 0 ? -1 : 0))) return false;
+                if (cf != 0 && (u.r[i][k] != r || u.c[i][k] != c)) return false;
+            }
+    }
     return t.ent_con[0] == -1;
 }
 static_assert(ipm_tab_ok(), "coop_ipm builds dS entry-wise: every off-diagonal entry belongs to at most one of the 15 triples");
-__device__ const IpmTab kIpmTab = make_ipm_tab();
+__device__ const IpmTab kIpmTab = make_ipm_tab<cvx::VAR_FULL>();
+__device__ const IpmTab kIpmTabRc = make_ipm_tab<cvx::VAR_RC>();
 
 // Cholesky with the rows in registers: lane i < N holds row i in a[] (entries 0..i; the rest is ignored and comes back as
 // garbage), lanes >= N hold zeros.  Left-looking, fully unrolled; the finished entries of row j reach the other lanes through lane
@@ -146,8 +172,11 @@ __device__ __forceinline__ void coop_steps(double *L, const double *Z, const dou
 
 // The solve.  qe: this lane's entry (ei, ej) of the trace-normalised cost (lanes < 55, 0 outside the 9 x 9 block).
 // On exit Z and S (full, symmetric) are at L[I_Z], L[I_S]; returns the iterations, gap = <Z, S>.
+template <int VAR>
 __device__ __noinline__ int coop_ipm(double *L, int lane, double qe, int ei, int ej, double tol, int max_iters, double *gap_out)
 {
+    constexpr int NR = cvx::ipm_rows(VAR), NSCH = NR * (NR + 1) / 2; // constraint rows; entries of the Schur matrix's lower triangle
+    const IpmTab &tab = VAR == cvx::VAR_RC ? kIpmTabRc : kIpmTab;
     double *Z = L + I_Z, *S = L + I_S, *Si = L + I_SI, *dZ = L + I_DZ, *dS = L + I_DS, *Rc = L + I_RC, *dy = L + I_DY, *rhs = L + I_RHS;
     double *M = L + I_M, *T1 = L + I_T1, *T2 = L + I_T2;
     CVXW_SYNC();
@@ -162,7 +191,7 @@ __device__ __noinline__ int coop_ipm(double *L, int lane, double qe, int ei, int
     // The constraint tables, once per solve (kIpmTab lives in global memory: read inside the iteration -- nine dependent byte
     // loads per Schur entry -- it was most of the solve's time).  The 63 terms, packed r | c << 4 | (s + 1) << 8, go to LDS;
     // rhs: the terms of row `lane`;  dS entries e = lane + 64 r (r < 2): dS[e] = c1 dy[i1] + c2 dy[i2].
-    auto pack_term = [&](int i, int k) { return (int)kIpmTab.r[i][k] | ((int)kIpmTab.c[i][k] << 4) | (((int)kIpmTab.s[i][k] + 1) << 8); };
+    auto pack_term = [&](int i, int k) { return (int)tab.r[i][k] | ((int)tab.c[i][k] << 4) | (((int)tab.s[i][k] + 1) << 8); };
     int *TI = reinterpret_cast<int *>(L + I_TAB);
     if (lane < 63) TI[lane] = pack_term(lane / 3, lane % 3);
     int sch_i[4], sch_j[4]; // Schur entries e = lane + 64 r (lower triangle, 231 of them): row and column
@@ -171,11 +200,11 @@ __device__ __noinline__ int coop_ipm(double *L, int lane, double qe, int ei, int
         const int e = lane + 64 * r;
         int i = 0, acc = 0;
         while (acc + i + 1 <= e) { acc += i + 1; ++i; } // row i starts at i (i + 1) / 2
-        sch_i[r] = i < 21 ? i : 0; sch_j[r] = i < 21 ? e - acc : 0;
+        sch_i[r] = i < NR ? i : 0; sch_j[r] = i < NR ? e - acc : 0;
     }
     int rhs_t[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) rhs_t[k] = lane < 21 ? pack_term(lane, k) : 0x100;
+    for (int k = 0; k < 3; ++k) rhs_t[k] = lane < NR ? pack_term(lane, k) : 0x100;
     int ds_i1[2], ds_i2[2];
     double ds_c1[2], ds_c2[2];
 #pragma unroll
@@ -184,12 +213,11 @@ __device__ __noinline__ int coop_ipm(double *L, int lane, double qe, int ei, int
         const int i = (e < 100 ? e : 0) / 10, j = (e < 100 ? e : 0) % 10;
         ds_i1[r] = 0; ds_i2[r] = 0; ds_c1[r] = 0.0; ds_c2[r] = 0.0;
         if (i != j) {
-            const int se = cvx::sidx(i, j), t = kIpmTab.ent_con[se];
-            if (t >= 0) { ds_i1[r] = t; ds_c1[r] = -0.5 * (double)kIpmTab.ent_sgn[se]; }
-        } else if (i == 9) { ds_i1[r] = 20; ds_c1[r] = -1.0; }
-        else {
-            ds_i1[r] = 15 + i % 3; ds_c1[r] = -1.0;
-            if (i / 3 < 2) { ds_i2[r] = 18 + i / 3; ds_c2[r] = -1.0; }
+            const int se = cvx::sidx(i, j), t = tab.ent_con[se];
+            if (t >= 0) { ds_i1[r] = t; ds_c1[r] = -0.5 * (double)tab.ent_sgn[se]; }
+        } else {
+            if (tab.d1[i] >= 0) { ds_i1[r] = tab.d1[i]; ds_c1[r] = -1.0; }
+            if (tab.d2[i] >= 0) { ds_i2[r] = tab.d2[i]; ds_c2[r] = -1.0; }
         }
     }
     auto frob = [&](const double *A, const double *B) { // <A, B> over all 100 entries
@@ -245,7 +273,7 @@ __device__ __noinline__ int coop_ipm(double *L, int lane, double qe, int ei, int
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int e = lane + 64 * r;
-            if (e >= 231) break;
+            if (e >= NSCH) break;
             const int i = sch_i[r], j = sch_j[r];
             int wi[3], wj[3];
 #pragma unroll
@@ -262,29 +290,29 @@ __device__ __noinline__ int coop_ipm(double *L, int lane, double qe, int ei, int
                     s += ca * cb * 0.25 * (Z[a * 10 + p] * Si[q * 10 + b] + Z[a * 10 + q] * Si[p * 10 + b] + Z[b * 10 + p] * Si[q * 10 + a] + Z[b * 10 + q] * Si[p * 10 + a]);
                 }
             }
-            M[i * 21 + j] = s;
+            M[i * NR + j] = s;
         }
         CVXW_SYNC();
         IPM_CLK(2);
-        const int li = lane < 21 ? lane : 0;
-        double Lr[21];
+        const int li = lane < NR ? lane : 0;
+        double Lr[NR];
 #pragma unroll
-        for (int k = 0; k < 21; ++k) Lr[k] = (lane < 21 && k <= lane) ? M[li * 21 + k] : 0.0;
-        if (!chol_rows<21>(Lr)) break;
+        for (int k = 0; k < NR; ++k) Lr[k] = (lane < NR && k <= lane) ? M[li * NR + k] : 0.0;
+        if (!chol_rows<NR>(Lr)) break;
 #pragma unroll
-        for (int k = 0; k < 21; ++k)
-            if (lane < 21 && k <= lane) M[li * 21 + k] = Lr[k]; // (the columns are read back from here)
+        for (int k = 0; k < NR; ++k)
+            if (lane < NR && k <= lane) M[li * NR + k] = Lr[k]; // (the columns are read back from here)
         CVXW_SYNC();
         IPM_CLK(3);
         // the factor into registers for the two solves of this iteration: lane i keeps row i (left of the diagonal) and column i
         // (below it), zero elsewhere, and 1 / L_ii -- a substitution step is then two lane reads and one multiply-add, not two
         // round trips through LDS
-        double Lc[21];
-        const double dinv = 1.0 / M[li * 21 + li];
+        double Lc[NR];
+        const double dinv = 1.0 / M[li * NR + li];
 #pragma unroll
-        for (int k = 0; k < 21; ++k) {
-            Lr[k] = (lane < 21 && k < lane) ? Lr[k] : 0.0;
-            Lc[k] = (lane < 21 && k > lane) ? M[k * 21 + li] : 0.0;
+        for (int k = 0; k < NR; ++k) {
+            Lr[k] = (lane < NR && k < lane) ? Lr[k] : 0.0;
+            Lc[k] = (lane < NR && k > lane) ? M[k * NR + li] : 0.0;
         }
         IPM_CLK(4);
         // ---- predictor (sigma = 0), then corrector
@@ -299,7 +327,7 @@ __device__ __noinline__ int coop_ipm(double *L, int lane, double qe, int ei, int
                 Rc[e] = sig_mu * Si[e] - Z[e] - (pass == 1 ? 0.5 * (T2[e] + T2[j * 10 + i]) : 0.0);
             }
             CVXW_SYNC();
-            if (lane < 21) {
+            if (lane < NR) {
                 double s = 0;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) s += (double)(((rhs_t[k] >> 8) & 3) - 1) * Rc[(rhs_t[k] & 15) * 10 + ((rhs_t[k] >> 4) & 15)];
@@ -307,18 +335,18 @@ __device__ __noinline__ int coop_ipm(double *L, int lane, double qe, int ei, int
             }
             CVXW_SYNC();
             {
-                double r = lane < 21 ? rhs[lane] : 0.0;
+                double r = lane < NR ? rhs[lane] : 0.0;
 #pragma unroll
-                for (int k = 0; k < 21; ++k) { // forward
+                for (int k = 0; k < NR; ++k) { // forward
                     const double xk = wave_lane(r, k) * wave_lane(dinv, k);
                     r = lane == k ? xk : r - Lr[k] * xk;
                 }
 #pragma unroll
-                for (int k = 20; k >= 0; --k) { // backward
+                for (int k = NR - 1; k >= 0; --k) { // backward
                     const double xk = wave_lane(r, k) * wave_lane(dinv, k);
                     r = lane == k ? xk : r - Lc[k] * xk;
                 }
-                if (lane < 21) dy[lane] = r;
+                if (lane < NR) dy[lane] = r;
             }
             CVXW_SYNC();
             // dS = - sum dy_i A_i, entry-wise: an off-diagonal entry belongs to one triple, a diagonal one to a row and a column sum

@@ -188,7 +188,9 @@ struct Own {
 
 // Projection of the symmetric matrix held 3-4 entries per lane onto { <A_i, Z> = b_i } (tgt = 1) or its
 // direction space (tgt = 0); closed form of cvx::proj_affine.
-template <class OWN>
+// VAR_RC (the reference's "rc" ablation, benchmarks/toolkit/methods/rc.py:9-64): the row-orthonormality rows are absent -- the entries
+// inside one diagonal 3x3 block (triples 0..2) are free and a diagonal entry only sees its column sum (cvxw::coop_proj).
+template <int VAR = cvx::VAR_FULL, class OWN>
 __device__ __forceinline__ void quad_proj(double *L, const OWN &w, double *X, double tgt)
 {
 #pragma unroll
@@ -206,11 +208,12 @@ __device__ __forceinline__ void quad_proj(double *L, const OWN &w, double *X, do
         const unsigned pk = w.pk[m];
         const int ri = w.ei(m) % 3, ci = w.ei(m) / 3; // diagonal entry (ei, ei), ei < 9, is D[ri][ci]
         const double rr = ri == 0 ? r0 : (ri == 1 ? r1 : r2), cc = ci == 0 ? c0 : (ci == 1 ? c1 : c2);
-        const double xdiag = (w.ei(m) == 9) ? tgt : X[m] - (rr + cc) * (1.0 / 3.0) + tot * (1.0 / 9.0);
+        const double xdiag = (w.ei(m) == 9) ? tgt : X[m] - (VAR == cvx::VAR_RC ? cc * (1.0 / 3.0) : (rr + cc) * (1.0 / 3.0) - tot * (1.0 / 9.0));
         const double x1 = L[Q_X + ((pk >> 8) & 63)], x2 = L[Q_X + ((pk >> 14) & 63)];
         const unsigned n0 = (pk >> 20) & 1;
         const double mm = (flip(X[m], n0) + flip(x1, (pk >> 21) & 1) + flip(x2, (pk >> 22) & 1)) * (1.0 / 3.0);
-        X[m] = ((pk >> 23) & 1) ? xdiag : X[m] - flip(mm, n0);
+        const bool free_entry = VAR == cvx::VAR_RC && w.ei(m) != w.ej(m) && w.ej(m) < 9 && (w.ei(m) / 3 == w.ej(m) / 3);
+        X[m] = ((pk >> 23) & 1) ? xdiag : (free_entry ? X[m] : X[m] - flip(mm, n0));
     }
     CVXW_SYNC();
 }
@@ -303,7 +306,7 @@ struct QuadArgs {
 };
 typedef const __attribute__((address_space(4))) QuadArgs *QuadArgsPtr;
 
-template <int NPW>
+template <int NPW, int VAR>
 __device__ __forceinline__ void finish_own(QuadArgsPtr kp, unsigned parked, double *lds)
 {
 #if defined(__HIP_DEVICE_COMPILE__) // (the host pass cannot copy out of the constant address space; it never calls this)
@@ -313,7 +316,7 @@ __device__ __forceinline__ void finish_own(QuadArgsPtr kp, unsigned parked, doub
     const int64_t b0 = (int64_t)blockIdx.x * NPW;
     for (int g = 0; g < NPW; ++g) { // wave-uniform
         if (!((parked >> g) & 1u)) continue;
-        cvxw::solve_one_wave(a, o, b0 + g, lds, ws + (b0 + g) * cvxw::RS_FULL, true);
+        cvxw::solve_one_wave<VAR>(a, o, b0 + g, lds, ws + (b0 + g) * cvxw::RS_FULL, true);
         CVXW_SYNC();
     }
 #endif
@@ -323,7 +326,7 @@ __device__ __forceinline__ void finish_own(QuadArgsPtr kp, unsigned parked, doub
 // certificate code is compiled in, every problem is parked after handoff_at iterations -- to measure what the
 // iteration phase costs at the occupancy it gets without the certificate's registers.
 // F64SW: the Jacobi sweeps, G = (W + sigma I) V and the warm-start eigenvectors in float64 (see pair_cs_f64)
-template <int MODE, int OCC = 2, int LPP = 16, bool F64SW = false>
+template <int MODE, int OCC = 2, int LPP = 16, bool F64SW = false, int VAR = cvx::VAR_FULL>
 __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
 {
     typedef Geo<LPP> G_;
@@ -940,7 +943,7 @@ CVXQ_PH(4); /* polar + Newton polish */
                 double T[EPL];
 #pragma unroll
                 for (int m = 0; m < EPL; ++m) { S[m] = rho * (Wp[m] - W[m]); T[m] = S[m] - (w.ej(m) < 9 ? L[Q_QF + w.ei(m) * 10 + w.ej(m)] : 0.0); }
-                quad_proj(L, w, T, 0.0);
+                quad_proj<VAR>(L, w, T, 0.0);
 #pragma unroll
                 for (int m = 0; m < EPL; ++m) {
                     S[m] = odd[m] ? 0.0 : S[m] - T[m];
@@ -954,7 +957,7 @@ CVXQ_PH(4); /* polar + Newton polish */
                 double rhs[10], lamv[10];
 #pragma unroll
                 for (int i = 0; i < 10; ++i) rhs[i] = L[C_ROW + i];
-                cvx::dual_lambda(Rc, rhs, symm, lamv);
+                cvx::dual_lambda<VAR>(Rc, rhs, symm, lamv);
                 if (gl == 0) {
 #pragma unroll
                     for (int i = 0; i < 10; ++i) L[C_LAM + i] = lamv[i];
@@ -968,7 +971,7 @@ CVXQ_PH(4); /* polar + Newton polish */
                     E[m] = odd[m] ? 0.0 : 0.5 * (L[C_LAM + w.ei(m)] * L[C_XV + w.ej(m)] + L[C_XV + w.ei(m)] * L[C_LAM + w.ej(m)]);
                     Nn[m] = E[m];
                 }
-                quad_proj(L, w, Nn, 0.0);
+                quad_proj<VAR>(L, w, Nn, 0.0);
 #pragma unroll
                 for (int m = 0; m < EPL; ++m) {
                     S[m] -= E[m] - Nn[m];
@@ -1035,7 +1038,7 @@ CVXQ_PH(6); /* LDL + outputs (or nothing when no check) */
             double X[EPL];
 #pragma unroll
             for (int m = 0; m < EPL; ++m) X[m] = 2.0 * Wp[m] - W[m] - irho * (w.ej(m) < 9 ? L[Q_QF + w.ei(m) * 10 + w.ej(m)] : 0.0); // (the cost entries stay in LDS: 8 registers less to carry through the loop)
-            quad_proj(L, w, X, 1.0);
+            quad_proj<VAR>(L, w, X, 1.0);
             double r2 = 0.0;
 #pragma unroll
             for (int m = 0; m < EPL; ++m) {
@@ -1099,7 +1102,7 @@ CVXQ_PH(7); /* projection + update */
     if (pmask) { // wave-uniform
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // every park() acknowledged before the iterate is read back
         CVXW_SYNC();
-        finish_own<NPW>((QuadArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), pmask, lds_all);
+        finish_own<NPW, VAR>((QuadArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), pmask, lds_all);
     }
 #ifdef CVXQ_PHASES
     if (lane == 0 && a.cost && (int64_t)blockIdx.x * NPW + 3 < a.batch) {

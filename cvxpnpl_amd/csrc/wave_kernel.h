@@ -776,7 +776,7 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
     bool certified = false;
 
     // a problem that is still open after rescue_cap iterations leaves the loop for the interior-point solve (below)
-    const int rescue_cap = (VAR == cvx::VAR_FULL && !(IPM && after_ipm) && o.rescue_from > 0 && (IPM || a.rq_count)) ? o.rescue_from : 0x7fffffff;
+    const int rescue_cap = (!(IPM && after_ipm) && o.rescue_from > 0 && (IPM || a.rq_count)) ? o.rescue_from : 0x7fffffff;
     while (!done && it < rescue_cap) {
         double sigma = 0.0;
         if (it == 0 && !resume && o.first_check > 1 && o.max_iters > 1) {
@@ -1321,7 +1321,7 @@ __device__ __forceinline__ void solve_one_wave(const WaveArgs &a, const cvx::Opt
 #ifdef CVXW_IPM_CLOCK
         const long long c1 = wall_clock64();
 #endif
-        const int nit = coop_ipm(L, lane, L[I_QS + lane], ei, ej, 1e-10, 40, &gap);
+        const int nit = coop_ipm<VAR>(L, lane, L[I_QS + lane], ei, ej, 1e-10, 40, &gap);
 #ifdef CVXW_IPM_CLOCK
         const long long c2 = wall_clock64();
 #endif
@@ -1375,7 +1375,7 @@ struct ResumeArgs {
 };
 typedef const __attribute__((address_space(4))) ResumeArgs *ResumeArgsPtr;
 
-template <bool IPM>
+template <bool IPM, int VAR = cvx::VAR_FULL>
 __device__ __forceinline__ void resume_body(ResumeArgsPtr kp, int32_t first, double *lds)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1396,12 +1396,12 @@ __device__ __forceinline__ void resume_body(ResumeArgsPtr kp, int32_t first, dou
         if ((threadIdx.x & 63) == 0) entries[q] = -1;
         if (b < a.batch) {
             if constexpr (IPM) {
-                if (second) solve_one_wave<cvx::VAR_FULL, true>(a, o, b, lds, ws + (int64_t)b * stride, full); // a parked problem
+                if (second) solve_one_wave<VAR, true>(a, o, b, lds, ws + (int64_t)b * stride, full); // a parked problem
                 else { // rescue queue: nothing parked but the iteration count, in the status word
                     const int st = a.status[b];
-                    solve_one_wave<cvx::VAR_FULL, true>(a, o, b, lds, nullptr, false, st >> 8, a.work ? a.work[2 * b + 1] : 0);
+                    solve_one_wave<VAR, true>(a, o, b, lds, nullptr, false, st >> 8, a.work ? a.work[2 * b + 1] : 0);
                 }
-            } else solve_one_wave(a, o, b, lds, ws + (int64_t)b * stride, full);
+            } else solve_one_wave<VAR>(a, o, b, lds, ws + (int64_t)b * stride, full);
             CVXW_SYNC();
         }
         // The next position nobody has taken yet: blocks own the positions below gridDim.x by index and DRAW the ones behind them
@@ -1432,6 +1432,14 @@ __global__ void __launch_bounds__(64, 2) resume_wave_kernel(ResumeArgs k)
     if (first < 0) return;
     resume_body<false>((ResumeArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), first, lds_all);
 }
+// the same for the 16-equality variant (quad schedule of cvxpnpl_solve_cost_batch / solve_batch with opts.variant = RC)
+__global__ void __launch_bounds__(64, 2) resume_wave_kernel_rc(ResumeArgs k)
+{
+    __shared__ __attribute__((aligned(16))) double lds_all[LDSW];
+    const int32_t first = k.entries[blockIdx.x];
+    if (first < 0) return;
+    resume_body<false, cvx::VAR_RC>((ResumeArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), first, lds_all);
+}
 
 // Last phase of a solve with opts.rescue_from in force: the problems the other kernels put on the rescue queue (k.count_p =
 // rq_count, k.entries = rq_entries; same self-cleaning queue discipline), one wavefront each, through the interior-point solve.
@@ -1443,6 +1451,14 @@ __global__ void __launch_bounds__(64, 2) rescue_wave_kernel(ResumeArgs k)
     const int32_t first = (int)blockIdx.x < k.grid1 ? k.entries[blockIdx.x] : k.entries2[(int)blockIdx.x - k.grid1];
     if (first < 0) return;
     resume_body<true>((ResumeArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), first, lds_all);
+}
+// the same for the 16-equality variant: the interior-point solve on its 16 rows (cvx::ipm_rows)
+__global__ void __launch_bounds__(64, 2) rescue_wave_kernel_rc(ResumeArgs k)
+{
+    __shared__ __attribute__((aligned(16))) double lds_all[LDSW_IPM];
+    const int32_t first = (int)blockIdx.x < k.grid1 ? k.entries[blockIdx.x] : k.entries2[(int)blockIdx.x - k.grid1];
+    if (first < 0) return;
+    resume_body<true, cvx::VAR_RC>((ResumeArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), first, lds_all);
 }
 
 } // namespace cvxw

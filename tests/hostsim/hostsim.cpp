@@ -51,7 +51,8 @@ int hs_ipm_batch(int batch, int n_p, const double *pts_2d, const double *pts_3d,
         cvx::Solution sol;
         sol.iters = 0;
         if (!cvx::assemble(pv, B, Q9)) { for (int i = 0; i < 45; ++i) Q9[i] = NAN; for (int i = 0; i < 27; ++i) B[i] = NAN; }
-        cvx::ipm_problem(Q9, B, *opts, sol, Z_out ? Z : nullptr);
+        if (opts->variant == cvx::VAR_RC) cvx::ipm_problem<cvx::VAR_RC>(Q9, B, *opts, sol, Z_out ? Z : nullptr);
+        else cvx::ipm_problem(Q9, B, *opts, sol, Z_out ? Z : nullptr);
         for (int i = 0; i < 9; ++i) R_out[(size_t)b * 9 + i] = sol.R[i];
         for (int i = 0; i < 3; ++i) t_out[(size_t)b * 3 + i] = sol.t[i];
         if (status) status[b] = sol.status;

@@ -42,7 +42,6 @@ def test_f32_and_f64_sweeps_agree(gpu, n_p, n_l, sigma, batch, layout):  # noqa:
     if n_p + n_l >= 8:  # well-posed problems take the same number of iterations in both modes (an attempt at the acceptance threshold
         # may flip -- noise-free data sits there: cost 0 against the 8e-13 tr floor of the gap -- and then costs one more attempt, two iterations)
         assert (a["iters"] == b["iters"]).mean() >= 0.9, (a["iters"] != b["iters"]).sum()
-        assert np.abs(a["iters"].astype(int) - b["iters"]).max() <= 4
 
 
 @pytest.mark.parametrize("layout", sorted(LAYOUTS))

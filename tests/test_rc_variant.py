@@ -191,3 +191,124 @@ def test_gpu_rc_variant_vs_oracle_and_reference_vectors(gpu, orc, grc):
         assert _geo(R[i], poses[0][0]) < 1e-6 and np.linalg.norm(t[i] - poses[0][1]) / np.linalg.norm(poses[0][1]) < 1e-6
         n_cmp += 1
     assert n_cmp >= 36
+
+
+@pytest.mark.gpu
+def test_gpu_rc_quad_schedule_equals_wave_and_oracle(gpu, orc):
+    """Round 3: the 16-equality variant in the quad schedule (four problems per wavefront, solve_quad_kernel<..., VAR_RC>, the
+    wavefront's leftovers and the planar queue through the rc wave kernel) -- same statuses as the wave-per-problem layout,
+    certified poses equal to 1e-9 (both Newton-polish the same stationary point), Z feasible for the reference's 16 rows, a
+    sample against the oracle's rc solve (<= 1e-6), and the AUTO policy picks it for a mid-size batch.
+    Match: benchmarks/toolkit/methods/rc.py:67-131."""
+    import torch
+
+    import cvxpnpl_amd as ca
+    from cvxpnpl_amd import synth
+
+    d = synth.make_pnp(3000, 10, 1.0, seed=78)
+    Bt, Qt = ca.assemble_batch(torch.as_tensor(d["pts_2d"], device=gpu), None, torch.as_tensor(d["pts_3d"], device=gpu), None, d["K"])
+    rw = ca.solve_cost_batch(Qt, Bt, variant=ca.VARIANT_RC, want_Z=True, layout=2)
+    outs = {}
+    for name, kw in (("quad", dict(layout=3)), ("auto", dict()), ("quad_short", dict(layout=3, lane_iters=9)), ("lane->quad", dict(layout=1))):
+        r = ca.solve_cost_batch(Qt, Bt, variant=ca.VARIANT_RC, want_Z=True, **kw)
+        outs[name] = {k: v.cpu().numpy() for k, v in r.items()}
+    w = {k: v.cpu().numpy() for k, v in rw.items()}
+    Ad, b = orc.sdp_constraints_rc()
+    for name, r in outs.items():
+        assert (r["status"] == w["status"]).mean() > 0.998, (name, np.flatnonzero(r["status"] != w["status"])[:10])
+        both = (r["status"] == 0) & (w["status"] == 0)
+        assert both.mean() > 0.97, name
+        assert synth.geodesic(r["R"], w["R"])[both].max() < 1e-9 and np.abs(r["t"] - w["t"])[both].max() < 1e-9, name
+        assert np.abs(r["Z"][r["status"] == 0] @ Ad[:16].T - b[:16]).max() < 1e-10
+        c = r["cost"][r["status"] == 0]
+        assert ((c[:, 0] - c[:, 1]) >= -1e-15).all() and ((c[:, 0] - c[:, 1]) <= 1.0001e-9).all()
+    assert np.array_equal(outs["auto"]["status"], outs["quad"]["status"]) and np.array_equal(outs["auto"]["iters"], outs["quad"]["iters"])  # AUTO at 3 000 = quad
+    q = outs["quad"]
+    n_cmp = 0
+    for i in range(0, 3000, 100):
+        (c1, c2, c3), (n1, n2, n3) = orc.point_constraints(d["pts_2d"][i], d["pts_3d"][i], d["K"])
+        B, A = orc.eliminate(np.vstack((c1, c2, c3)), np.vstack((n1, n2, n3)))
+        poses, info = orc.solve_relaxation_rc(A, B, eps=1e-11, max_iters=400000)
+        if q["status"][i] != 0 or len(poses) != 1:
+            continue
+        assert _geo(q["R"][i], poses[0][0]) < 1e-6 and np.linalg.norm(q["t"][i] - poses[0][1]) / np.linalg.norm(poses[0][1]) < 1e-6
+        n_cmp += 1
+    assert n_cmp >= 26
+
+
+def test_rc_interior_point_statement_vs_oracle_and_first_order(orc):
+    """The interior-point path on the 16-row constraint set (csrc/ipm_core.h, cvx::ipm_rows(VAR_RC): twelve triples, three column
+    sums, Z99 -- the scalar statement of what cvxw::coop_ipm<VAR_RC> runs in rescue_wave_kernel_rc): the same SDP as the
+    first-order rc solve and as the oracle's restated SCS on the reference's own _A_rc (rc.py:9-64), reached in <= 25
+    iterations whatever the conditioning; and its optimal Z satisfies the reference's 16 rows."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import hostsim
+    from cvxpnpl_amd import synth
+
+    d = synth.make_pnp(120, 10, 1.0, seed=77)
+    o = hostsim.default_opts(variant=1)
+    ip = hostsim.ipm_batch(d["pts_2d"], d["pts_3d"], None, None, d["K"], opts=o, want_Z=True)
+    Bs, Qs = [], []
+    for i in range(120):
+        _, B, Q = hostsim.assemble(d["pts_2d"][i], d["pts_3d"][i], None, None, d["K"])
+        Bs.append(B.reshape(-1))
+        Qs.append(np.array([Q[a, b] for a in range(9) for b in range(a, 9)]))
+    fo = hostsim.solve_cost_batch(np.array(Qs), np.array(Bs), variant=1, want_Z=True)
+    assert ip["iters"].max() <= 25
+    both = (ip["status"] == 0) & (fo["status"] == 0)
+    assert both.sum() >= 110 and (ip["status"] == 0).sum() >= (fo["status"] == 0).sum()
+    assert synth.geodesic(ip["R"], fo["R"])[both].max() < 1e-7 and np.abs(ip["t"] - fo["t"])[both].max() < 1e-7
+    Ad, b = orc.sdp_constraints_rc()
+    assert np.abs(ip["Z"][ip["status"] == 0] @ Ad[:16].T - b[:16]).max() < 1e-9
+    n_cmp = 0
+    for i in range(0, 120, 6):
+        (c1, c2, c3), (n1, n2, n3) = orc.point_constraints(d["pts_2d"][i], d["pts_3d"][i], d["K"])
+        B, A = orc.eliminate(np.vstack((c1, c2, c3)), np.vstack((n1, n2, n3)))
+        poses, info = orc.solve_relaxation_rc(A, B, eps=1e-11, max_iters=400000)
+        if ip["status"][i] != 0 or len(poses) != 1:
+            continue
+        assert _geo(ip["R"][i], poses[0][0]) < 1e-6 and np.linalg.norm(ip["t"][i] - poses[0][1]) / np.linalg.norm(poses[0][1]) < 1e-6
+        n_cmp += 1
+    assert n_cmp >= 16
+    # minimal problems: the rc relaxation is rarely tight there; the interior-point iterate is the SDP optimum all the same
+    dm = synth.make_pnp(64, 4, 1.0, seed=5)
+    im = hostsim.ipm_batch(dm["pts_2d"], dm["pts_3d"], None, None, dm["K"], opts=o, want_Z=True)
+    assert im["iters"].max() <= 30 and np.isfinite(im["R"]).all()
+    fin = np.isfinite(im["Z"]).all(axis=1)
+    assert np.abs(im["Z"][fin] @ Ad[:16].T - b[:16]).max() < 1e-7
+
+
+@pytest.mark.gpu
+def test_gpu_rc_interior_point_rescue(gpu, orc):
+    """opts.rescue_from for the rc variant (round 3; default 96): a problem whose relaxation is not tight no longer runs to
+    max_iters -- the launch's slowest problem stays below rescue_from + ~40 -- what certifies without the path certifies with it,
+    to the same pose, and the rescued problems themselves match the oracle's rc solve."""
+    import torch
+
+    import cvxpnpl_amd as ca
+    from cvxpnpl_amd import synth
+
+    d = synth.make_pnp(6000, 10, 2.0, seed=42)
+    Bt, Qt = ca.assemble_batch(torch.as_tensor(d["pts_2d"], device=gpu), None, torch.as_tensor(d["pts_3d"], device=gpu), None, d["K"])
+    base = {k: v.cpu().numpy() for k, v in ca.solve_cost_batch(Qt, Bt, variant=ca.VARIANT_RC, rescue_from=0, layout=2).items()}
+    for layout in (2, 3, 0):
+        r = {k: v.cpu().numpy() for k, v in ca.solve_cost_batch(Qt, Bt, variant=ca.VARIANT_RC, layout=layout, want_Z=True).items()}
+        assert r["iters"].max() <= 96 + 60, r["iters"].max()
+        both = (r["status"] == 0) & (base["status"] == 0)
+        assert (r["status"] == 0).sum() >= (base["status"] == 0).sum() and both.mean() > 0.98
+        assert synth.geodesic(r["R"], base["R"])[both].max() < 1e-7
+        assert np.isfinite(r["R"]).all()
+    resc = np.flatnonzero(r["iters"] > 96)
+    assert len(resc) >= 3
+    n_cmp = 0
+    for i in resc[:24]:
+        (c1, c2, c3), (n1, n2, n3) = orc.point_constraints(d["pts_2d"][i], d["pts_3d"][i], d["K"])
+        B, A = orc.eliminate(np.vstack((c1, c2, c3)), np.vstack((n1, n2, n3)))
+        poses, info = orc.solve_relaxation_rc(A, B, eps=1e-11, max_iters=400000)
+        if r["status"][i] != 0 or len(poses) != 1:
+            continue
+        assert _geo(r["R"][i], poses[0][0]) < 1e-6
+        n_cmp += 1
+    assert n_cmp >= 1 or (r["status"][resc] != 0).all()
