@@ -353,7 +353,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     w.rq_count = nullptr; w.rq_entries = nullptr;
     int quad_iters = opts ? opts->lane_iters : -1;
     // rc: the weaker relaxation certifies after ~21 iterations instead of 5 (N = 10): a longer first phase, first attempt later
-    if (quad_iters <= 0 && rc) quad_iters = 28;
+    if (quad_iters <= 0 && rc) quad_iters = 36; // (profiles/r03/rc_tune.txt: 28 / 36 / 44 within 1 %)
     if (quad_iters <= 0) quad_iters = 7; // measured (4 problem sets at 10 k, same box): 5: 0.242 ms, 7: 0.233, 8: 0.235, 10: 0.240; 24 k: 7 = 10 (round 1, second phase as a call: 8-12)
     if (quad_iters > 48) quad_iters = 48; // (rc: up to 48 -- still inside the wave kernel's own single-precision window of 64)
     if (quad_iters > 16 && !rc) quad_iters = 16; // the quad phase runs its eigen-solve sweeps in single precision: fine for the first iterations, not for a slow tail (quad_kernel.h)
@@ -368,7 +368,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     // extra iteration: 125 k problems 157 -> 164 M poses/s, PnPL 100 k 116 -> 126 M.  The quad and wave layouts keep 5 (quad with 6, launch
     // time relative to 5 over 4 problem sets per size: 3 k 0.93, 5 k 1.07, 8 k 1.02, 10 k 0.98, 12 k 1.07, 16 k 1.03, 20 k 1.02, 24 k 0.97;
     // wave: -12 % at 2 k).
-    if (o.first_check <= 0) o.first_check = layout == CVXPNPL_LAYOUT_LANE ? 6 : 5;
+    if (o.first_check <= 0) o.first_check = rc ? 11 : (layout == CVXPNPL_LAYOUT_LANE ? 6 : 5); // (rc: nothing certifies before ~10 iterations; 5 ... 15 within 3 %)
     // interior-point path for the problems still open after rescue_from iterations (ipm_wave.h): its queue lives in the workspace
     // -1 (default): by problem size.  Slow convergence is a property of minimal and near-minimal configurations
     // (profiles/r02/remaining_iters.jsonl, 100 k problems each, first-order iterations only: with N = 4 / 5 / 6 / 7 correspondences
@@ -383,8 +383,8 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
         o.rescue_from = n <= 6 ? 32 : (n == 7 ? 64 : 128);
         // rc: the weaker relaxation is tight less often, and a problem whose relaxation is not tight crawls to max_iters -- 13 of 10 000
         // N = 10 problems run all 2 500 iterations, 10 ms per launch whatever the layout (profiles/r03/rc_rate.txt) -- while the
-        // typical problem certifies after ~21 iterations, p99 ~60: hand over at 96 whatever the size
-        if (rc) o.rescue_from = 96;
+        // typical problem certifies after ~19 iterations (median; p90 33): hand over at 48 whatever the size
+        if (rc) o.rescue_from = 48; // (profiles/r03/rc_tune.txt, 50 k problems: 48 / 64 / 80 / 96 -> 2.92 / 3.10 / 3.46 / 3.63 ms, same outcomes)
     }
     const bool rescue = o.rescue_from > 0 && o.max_iters > o.rescue_from;
     if (rescue) {

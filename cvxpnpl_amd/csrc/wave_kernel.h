@@ -777,6 +777,12 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
 
     // a problem that is still open after rescue_cap iterations leaves the loop for the interior-point solve (below)
     const int rescue_cap = (!(IPM && after_ipm) && o.rescue_from > 0 && (IPM || a.rq_count)) ? o.rescue_from : 0x7fffffff;
+    // After the hand-over the iterate IS the SDP optimum (gap 1e-10): a problem that has not certified within IPM_GRACE further
+    // first-order iterations has a relaxation that is not tight (or one whose interior-point solve stalled), and exits through the
+    // reference's recovery from the Z it has instead of crawling to the rank-stall rule (measured: one of 50 000 rc problems ran 1 625
+    // iterations that way and held the launch for 8 ms; the slowest problem that does certify after a hand-over takes 47).
+    constexpr int IPM_GRACE = 64;
+    const int ipm_deadline = (IPM && after_ipm) ? it_io + IPM_GRACE : 0x7fffffff;
     while (!done && it < rescue_cap) {
         double sigma = 0.0;
         if (it == 0 && !resume && o.first_check > 1 && o.max_iters > 1) {
@@ -949,7 +955,7 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
         ++it;
         CVXW_PH(PH_WP);
         const bool check = it >= next_check;
-        bool last = (it >= o.max_iters) || (fp_res < o.res_tol);
+        bool last = (it >= o.max_iters) || (fp_res < o.res_tol) || (it >= ipm_deadline);
         if (check || last) {
             // top eigenvector slot and the runner-up (wave-uniform)
             int smax = 0, s2nd = 0;

@@ -282,7 +282,7 @@ def test_rc_interior_point_statement_vs_oracle_and_first_order(orc):
 
 @pytest.mark.gpu
 def test_gpu_rc_interior_point_rescue(gpu, orc):
-    """opts.rescue_from for the rc variant (round 3; default 96): a problem whose relaxation is not tight no longer runs to
+    """opts.rescue_from for the rc variant (round 3; default 48): a problem whose relaxation is not tight no longer runs to
     max_iters -- the launch's slowest problem stays below rescue_from + ~40 -- what certifies without the path certifies with it,
     to the same pose, and the rescued problems themselves match the oracle's rc solve."""
     import torch
@@ -295,12 +295,12 @@ def test_gpu_rc_interior_point_rescue(gpu, orc):
     base = {k: v.cpu().numpy() for k, v in ca.solve_cost_batch(Qt, Bt, variant=ca.VARIANT_RC, rescue_from=0, layout=2).items()}
     for layout in (2, 3, 0):
         r = {k: v.cpu().numpy() for k, v in ca.solve_cost_batch(Qt, Bt, variant=ca.VARIANT_RC, layout=layout, want_Z=True).items()}
-        assert r["iters"].max() <= 96 + 60, r["iters"].max()
+        assert r["iters"].max() <= 48 + 16 + 64 + 4, r["iters"].max()  # hand-over at 48, <= ~16 second-order iterations, the 64-iteration grace
         both = (r["status"] == 0) & (base["status"] == 0)
         assert (r["status"] == 0).sum() >= (base["status"] == 0).sum() and both.mean() > 0.98
         assert synth.geodesic(r["R"], base["R"])[both].max() < 1e-7
         assert np.isfinite(r["R"]).all()
-    resc = np.flatnonzero(r["iters"] > 96)
+    resc = np.flatnonzero(r["iters"] > 48)
     assert len(resc) >= 3
     n_cmp = 0
     for i in resc[:24]:
