@@ -9,11 +9,12 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
-WORKLOAD_KEY = {"default": "pnp_n10_10k:10000", "quad_24k": "pnp_n10_10k:24000", "hybrid_125k": "pnp_n10_125k:125000", "large_n": "pnp_n10000_1k:1000"}
+WORKLOAD_KEY = {"default": "pnp_n10_10k:10000", "quad_24k": "pnp_n10_10k:24000", "quad_16k": "pnp_n10_10k:16000", "hybrid_125k": "pnp_n10_125k:125000",
+                "pnpl_100k": "pnpl_5p5l_100k:100000", "large_n": "pnp_n10000_1k:1000", "minimal_50k": "pnp_n4_50k:50000"}
 
 
 def counters(run):
@@ -42,7 +43,7 @@ import hashlib
 
 LIB_SHA = hashlib.sha256(open(os.path.join(ROOT, "cvxpnpl_amd", "libcvxpnpl_amd.so"), "rb").read()).hexdigest()[:16]
 traffic = {}
-for run in ("default", "quad_24k", "hybrid_125k", "large_n"):
+for run in WORKLOAD_KEY:
     if not os.path.isdir(os.path.join(src, run)):
         continue
     os.makedirs(os.path.join(dst, run), exist_ok=True)
@@ -66,7 +67,7 @@ for run in ("default", "quad_24k", "hybrid_125k", "large_n"):
         "lib_sha16": LIB_SHA,
         "source": f"profiles/{tag}/{run}/pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KB*1024 divided by what the "
                   "same passes report for a known 64 MiB copy, summed over the kernels of one step"}
-for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(src, "*.jsonl")) + glob.glob(os.path.join(src, "layout_sweep.txt")) + glob.glob(os.path.join(src, "planar_general.txt")) + glob.glob(os.path.join(src, "*.json")):
+for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(src, "*.jsonl")) + glob.glob(os.path.join(src, "*.txt")) + glob.glob(os.path.join(src, "*.json")):
     shutil.copy(f, dst)
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
