@@ -8,12 +8,13 @@
 // registers, one DPP + LDS reduction per workgroup at the end, partial sums to a scratch buffer, and a second, tiny
 // kernel adds them in a fixed order (deterministic results) and finishes B and Q.
 //
-// Conditioning: the sums are taken about the first 3D point c of the problem (P' = P - c).  The cost r^T Q r is
+// Conditioning: the sums are taken about a point c of the scene (cvx::shift_centre: per coordinate the median of the first three 3D records; P' = P - c).  The cost r^T Q r is
 // invariant under that shift (the translation absorbs R c) and t = -B' r - R c, i.e. B[i][3j+i] += c_j: exact, and the
 // Gram difference C^T C - (N^T C)^T B no longer cancels |c|^2 / spread^2 digits when the world origin is far away.
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "problem_io.h"
 #include "solver_core.h"
 
 namespace cvxa {
@@ -70,8 +71,9 @@ __global__ void __launch_bounds__(ASM_TPB) assemble_large_kernel(AsmArgs a)
     cvx::inv3(Kc, Ki, det);
     const double *p2 = a.n_p ? a.p2 + b * a.n_p * 2 : nullptr, *p3 = a.n_p ? a.p3 + b * a.n_p * 3 : nullptr;
     const double *l2 = a.n_l ? a.l2 + b * a.n_l * 4 : nullptr, *l3 = a.n_l ? a.l3 + b * a.n_l * 6 : nullptr;
-    const double *c0 = a.n_p ? p3 : l3; // the shift: first 3D point / first line end point
-    const double cx = c0[0], cy = c0[1], cz = c0[2];
+    double c_[3]; // the shift (cvx::shift_centre: the same point in every workgroup of the problem and in assemble_finish_kernel)
+    cvx::shift_centre(a.n_p, p3, a.n_l, l3, c_);
+    const double cx = c_[0], cy = c_[1], cz = c_[2];
     cvx::Gram g;
     cvx::gram_zero(g);
     const int stride = a.nblk * ASM_TPB;
@@ -152,8 +154,8 @@ __global__ void __launch_bounds__(64) assemble_finish_kernel(AsmArgs a, double *
         cvx::inv3(Kc, Ki, det);
         ok = ok && (det == det) && det != 0.0;
     }
-    const double *c0 = a.n_p ? a.p3 + b * a.n_p * 3 : a.l3 + b * a.n_l * 6;
-    const double c[3] = {c0[0], c0[1], c0[2]};
+    double c[3];
+    cvx::shift_centre(a.n_p, a.n_p ? a.p3 + b * a.n_p * 3 : nullptr, a.n_l, a.n_l ? a.l3 + b * a.n_l * 6 : nullptr, c);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll

@@ -29,6 +29,26 @@ CVX_HD ProblemView make_view(long b, int n_p, const double *pts_2d, const double
     return v;
 }
 
+// The point c the Gram sums are taken about (P' = P - c; exact for any c: the cost is invariant, t = -B' r - R c): per coordinate the
+// MEDIAN of the first three 3D records (points, then line end points), so that one far outlier among them -- a bad RANSAC sample, a
+// sentinel point in first position -- cannot drag the centre away from the scene and bring the |c|^2 / spread^2 cancellation back
+// (round-2 advisor finding; rounds 1-2 used the first record).  Fewer than three records: the first one.
+CVX_HD void shift_centre(int n_p, const double *p3, int n_l, const double *l3, double *c)
+{
+    const int nrec = n_p + 2 * n_l;
+    CVX_UNROLL for (int k = 0; k < 3; ++k) {
+        const double a = n_p > 0 ? p3[k] : l3[k];
+        double m = a;
+        if (nrec >= 3) {
+            const double b = n_p > 1 ? p3[3 + k] : l3[3 * (1 - n_p) + k];
+            const double d = n_p > 2 ? p3[6 + k] : l3[3 * (2 - n_p) + k];
+            const double lo = a < b ? a : b, hi = a < b ? b : a;
+            m = d < lo ? lo : (d > hi ? hi : d);
+        }
+        c[k] = m;
+    }
+}
+
 // cvxpnpl.py:523-627 up to the call of _solve_relaxation: B (3x9) and Q9 = A^T A (45 packed)
 CVX_HD bool assemble(const ProblemView &v, double *B, double *Q9)
 {
@@ -37,11 +57,11 @@ CVX_HD bool assemble(const ProblemView &v, double *B, double *Q9)
     inv3(Kc, Ki, det);
     Gram g;
     gram_zero(g);
-    // The sums are taken about the problem's first 3D point c (P' = P - c): the cost r^T Q r is invariant under that
+    // The sums are taken about a point c of the scene (shift_centre; P' = P - c): the cost r^T Q r is invariant under that
     // shift (the translation absorbs R c) and t = -B' r - R c, i.e. B[i][3j+i] += c_j.  Exact, and the Gram difference
     // C^T C - (N^T C)^T B no longer cancels |c|^2 / spread^2 digits when the world origin is far from the scene.
-    const double *c0 = v.n_p ? v.p3 : v.l3;
-    const double c[3] = {c0[0], c0[1], c0[2]};
+    double c[3];
+    shift_centre(v.n_p, v.p3, v.n_l, v.l3, c);
     for (int i = 0; i < v.n_p; ++i)
         gram_add_point(g, Ki, v.p2[2 * i], v.p2[2 * i + 1], v.p3[3 * i] - c[0], v.p3[3 * i + 1] - c[1], v.p3[3 * i + 2] - c[2]);
     for (int i = 0; i < v.n_l; ++i) {

@@ -402,9 +402,10 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
             rqa[m] = 6 + qa; rqb[m] = 6 + qb; rte[m] = te;
         }
         const int nrec = pv.n_p + 2 * pv.n_l;
-        // sums about the problem's first 3D point (cvx::assemble: exact, and well conditioned far from the world origin)
-        const double *c0p = pv.n_p ? pv.p3 : pv.l3;
-        const double cs0 = c0p[0], cs1 = c0p[1], cs2 = c0p[2];
+        // sums about a point of the scene (cvx::shift_centre: exact, and well conditioned far from the world origin)
+        double cs_[3];
+        cvx::shift_centre(pv.n_p, pv.p3, pv.n_l, pv.l3, cs_);
+        const double cs0 = cs_[0], cs1 = cs_[1], cs2 = cs_[2];
         for (int base = 0; base < nrec; base += LPP) {
             const int cnt = nrec - base < LPP ? nrec - base : LPP;
             if (gl < cnt) {

@@ -565,9 +565,10 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
             q[0] = l2[0]; q[1] = l2[1]; q[2] = l2[2]; q[3] = l2[3];
             q[4] = l3[0]; q[5] = l3[1]; q[6] = l3[2];
         };
-        // sums about the problem's first 3D point (cvx::assemble: exact, and well conditioned far from the world origin)
-        const double *c0p = pv.n_p ? pv.p3 : pv.l3;
-        const double cs0 = c0p[0], cs1 = c0p[1], cs2 = c0p[2];
+        // sums about a point of the scene (cvx::shift_centre: exact, and well conditioned far from the world origin)
+        double cs_[3];
+        cvx::shift_centre(pv.n_p, pv.p3, pv.n_l, pv.l3, cs_);
+        const double cs0 = cs_[0], cs1 = cs_[1], cs2 = cs_[2];
         double rawp[5] = {0, 0, 0, 0, 0}, rawl[7] = {0, 0, 0, 0, 0, 0, 0};
         {
             const int cnt0 = nrec < CHUNK ? nrec : CHUNK;
