@@ -253,6 +253,7 @@ cvx::Opts to_core(const cvxpnpl_opts_t *opts)
         o.stall_from = opts->stall_from; o.stall_lam = opts->stall_lam; o.stall_res = opts->stall_res; o.stall_drop = opts->stall_drop;
         o.rescue_from = opts->rescue_from;
         o.f32_sweeps_until = opts->f32_sweeps_until;
+        o.sweep_schedule = opts->sweep_schedule != 0;
     }
     if (o.f32_sweeps_until < 0) o.f32_sweeps_until = cvx::F32_SWEEPS_DEFAULT;
     return o;
@@ -287,6 +288,7 @@ void cvxpnpl_default_opts(cvxpnpl_opts_t *opts)
     opts->stall_from = o.stall_from; opts->stall_lam = o.stall_lam; opts->stall_res = o.stall_res; opts->stall_drop = o.stall_drop;
     opts->rescue_from = o.rescue_from;
     opts->f32_sweeps_until = -1;
+    opts->sweep_schedule = 1;
     opts->struct_size = (uint32_t)sizeof(cvxpnpl_opts_t);
 }
 

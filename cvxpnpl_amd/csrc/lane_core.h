@@ -197,7 +197,7 @@ CVX_HD void lane_phase(const ProblemView &pv, const Opts &o, Solution &sol, doub
     const double tol2 = o.jacobi_tol * o.jacobi_tol;
     for (; it < iters;) {
         eig_load_warm_f32(e, W);
-        sol.sweeps += eig_solve(e, o.jacobi_sweeps, tol2);
+        sol.sweeps += eig_solve(e, o.sweep_schedule ? sweep_cap(it + 1, true, o.jacobi_sweeps) : o.jacobi_sweeps, tol2); // (the wavefront pays the maximum over its 64 lanes: cvx::sweep_cap)
         eig_pospart(e, Wp);
         ++it;
         if (it == o.tail_from) { // smaller penalty from here on; the dual is kept: Wm scales by rho / rho_tail

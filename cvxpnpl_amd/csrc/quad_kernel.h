@@ -617,6 +617,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
             for (int m = 0; m < EPL; ++m) fro += w.wgt(m) * W[m] * W[m];
             sigma = 1.5 * cvx::sqrt_fast(grp_sum<LPP>(L, gl, fro)) + 1e-300;
             int sweeps = 0;
+            const int sw_cap = o.sweep_schedule ? cvx::sweep_cap(it + 1, false, o.jacobi_sweeps) : o.jacobi_sweeps; // (the wavefront pays the maximum over its problems)
             double g[10];
             float alf = 0.0f; // (single-precision path: squared norm of this lane's column)
             f2 q[5];
@@ -666,7 +667,7 @@ CVXQ_PH(0);
                     for (int i = 0; i < 10; ++i) alq = fma(qd[i], qd[i], alq);
                     const bool grp_more = grp_bits<LPP>(__ballot(coarse && active), grp) != 0;
                     if (active) ++sweeps;
-                    active = active && grp_more && sweeps < o.jacobi_sweeps;
+                    active = active && grp_more && sweeps < sw_cap;
                 } while (__any(active));
 #pragma unroll
                 for (int i = 0; i < 10; ++i) g[i] = qd[i];
@@ -745,7 +746,7 @@ CVXQ_PH(0); /* fro, LDS copy of W, g = (W + sigma I) v */
                 }
                 const bool grp_more = grp_bits<LPP>(__ballot(coarse && active), grp) != 0;
                 if (active) ++sweeps;
-                active = active && grp_more && sweeps < o.jacobi_sweeps;
+                active = active && grp_more && sweeps < sw_cap;
             } while (__any(active));
 #pragma unroll
             for (int i = 0; i < 5; ++i) { g[2 * i] = (double)q[i].x; g[2 * i + 1] = (double)q[i].y; }

@@ -77,8 +77,23 @@ struct Opts {
     int rescue_from;   // kernels: a solve still open after this many iterations goes to the interior-point path (ipm_core.h); 0: never, < 0: by problem size
     int f32_sweeps_until; // kernels: the Jacobi sweeps of the PSD projection run on single-precision columns during the first this many
                           // iterations of a solve (< 0: default, F32_SWEEPS_DEFAULT); 0: every sweep in float64, rotation angles included
+    int sweep_schedule;   // kernels: 1 (default) caps the sweeps of the YOUNG eigen-solves by iteration (sweep_cap below); 0: jacobi_sweeps only
 };
 constexpr int F32_SWEEPS_DEFAULT = 64;
+// Sweeps the eigen-solve of iteration `it` (2, 3, ...: iteration 1 needs none) may take in the first phases of the hybrid schedules,
+// where a wavefront runs the MAXIMUM over its problems (64 in the lane phase, 4 in the quad phase): the first eigen-solve of a solve
+// takes 3-4 sweeps, the later ones 1-2 on average but 2-3 at wavefront level (measured, 200 wavefronts of 64 N = 10 problems: mean per
+// eigen-solve 3.1 / 1.8 / 2.0 / 1.3 / 1.0, wavefront maximum 4.0 / 2.5 / 2.7 / 2.0 / 1.9 -- 13.1 sweeps paid for 9.2 needed).  A column pair
+// that misses its last sweep is orthogonal to ~0.1 instead of 6e-2 for ONE iteration; the next warm start absorbs it.  Host experiment
+// (tests/hostsim, 30 000 problems per workload, certified at the first attempt, uncapped -> capped): lane phase, attempt after 6
+// iterations, caps 3 2 2 1 1: N = 10 98.63 -> 98.61 %, PnPL 5+5 95.47 -> 95.35 %, N = 8 94.63 -> 94.62 %, N = 6 77.00 -> 76.90 %, PnL 8
+// 80.6 -> 80.1 %; quad phase, attempt after 5, caps 3 2 2 2 (the eigen-solve an attempt reads keeps 2: with 1 there 94.19 -> 93.81 %):
+// N = 10 94.19 -> 94.19 %, PnPL 88.62 -> 88.55 %, N = 8 86.49 -> 86.45 %.  Results are unaffected (what is not certified continues).
+CVX_HD constexpr int sweep_cap(int it, bool lane_phase, int cap)
+{
+    const int c = it <= 2 ? 3 : (it <= 4 ? 2 : (lane_phase ? 1 : 2));
+    return c < cap ? c : cap;
+}
 
 // Constraint sets.  VAR_RC is the reference's ablation "rc" (benchmarks/toolkit/methods/rc.py:16-35): the six row
 // orthonormality rows (kron(I3, E_ij), cvxpnpl.py:404-418) are left out -- in the closed forms below that means the
@@ -95,6 +110,7 @@ CVX_HD Opts default_opts()
     o.adapt_every = 10; o.adapt_from = 40; o.adapt_mu = 2.0; o.adapt_tau = 2.0; o.stall_from = 300; o.stall_lam = 0.05; o.stall_res = 1e-3; o.stall_drop = 0.003;
     o.rescue_from = -1; // (by problem size, cvxpnpl_hip.hip: 32 for at most 6 correspondences, 64 for 7, 128 otherwise)
     o.f32_sweeps_until = -1;
+    o.sweep_schedule = 1;
     return o;
 }
 
@@ -1435,7 +1451,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
         } else {
             if (o.warm_start && it > 0) eig_load_warm(e, W);
             else eig_load(e, W);
-            sol.sweeps += eig_solve(e, o.jacobi_sweeps, o.jacobi_tol * o.jacobi_tol);
+            sol.sweeps += eig_solve(e, (!TWIN && o.sweep_schedule) ? sweep_cap(it + 1, true, o.jacobi_sweeps) : o.jacobi_sweeps, o.jacobi_tol * o.jacobi_tol); // (lane phase: sweep_cap)
             eig_pospart(e, Wp);
         }
         ++it;

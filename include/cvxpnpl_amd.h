@@ -104,6 +104,12 @@ typedef struct {
                             included, in float64 (the A/B mode: `value_all_f64` of bench.py, tests/test_precision_modes.py).  The quad
                             and lane phases (at most 16 / 6 iterations) run entirely in one precision: single only if the whole phase lies
                             below the bound, float64 otherwise. */
+    int32_t sweep_schedule; /* 1 (default): in the first phases of the quad and lane schedules -- where a wavefront runs the maximum number of
+                            Jacobi sweeps over its 4 / 64 problems -- the sweeps of an eigen-solve are capped by iteration: 3 for the
+                            first one (iteration 2), then 2 (lane phase: 1 from iteration 5 on); jacobi_sweeps still bounds everything.
+                            A column pair that misses its last sweep is caught by the next iteration's warm start; what certifies is
+                            unchanged to ~0.1 % of the first attempts (cvx::sweep_cap has the measurements), results are not affected.
+                            0: only jacobi_sweeps. */
 } cvxpnpl_opts_t;
 
 void cvxpnpl_default_opts(cvxpnpl_opts_t *opts);

@@ -361,7 +361,7 @@ def test_lane_core_restatement_equals_the_general_core(n_p, n_l, sigma, iters):
     (cvx::solve_problem<TWIN = false>, first_check == hand-off point; run with its float64 eigen-solve as the yardstick -- measured
     on 512 four-point problems, parked iterates: restatement vs float64 core <= 3.4e-5, the general core's own single-precision
     mode vs its float64 mode 9.5e-2 on one ill-conditioned problem, 2e-5 at the 99th percentile), on the host: the same problems certify, with the same
-    pose (both Newton-polish to the stationary point: 1e-12) and the same certified bound; the same problems are parked, with
+    pose (both Newton-polish to the stationary point: 1e-10) and the same certified bound; the same problems are parked, with
     the same iterate to rounding (the restatement forms (W + sigma I) V in single precision and starts the polish from two
     polar steps + Gram-Schmidt instead of a converged polar iteration.  The eigen-solve stops at a column cosine of 6e-2, i.e. it
     is accurate to ~4e-3 by design, and whether one more sweep runs is a discrete decision that single-precision noise can flip:
@@ -387,8 +387,8 @@ def test_lane_core_restatement_equals_the_general_core(n_p, n_l, sigma, iters):
         assert cert.mean() > 0.9
     assert (a["iters"][cert] == iters).all() and (b["iters"][cert] == iters).all()
     if cert.any():
-        assert synth.geodesic(a["R"][cert], b["R"][cert]).max() < 1e-12
-        assert np.abs(a["t"][cert] - b["t"][cert]).max() < 1e-11
+        assert synth.geodesic(a["R"][cert], b["R"][cert]).max() < 1e-10  # (the polish takes its last Newton step from |g| < 1e-8: 1e-10 ... 1e-16)
+        assert np.abs(a["t"][cert] - b["t"][cert]).max() < 1e-9
         assert np.abs(a["cost"][cert] - b["cost"][cert]).max() < 1e-12 * max(1.0, np.abs(a["cost"][cert]).max()) + 2e-10  # (dobj carries the dual: <= eps apart)
         gap = b["cost"][cert, 0] - b["cost"][cert, 1]
         assert (gap >= -1e-15).all() and (gap <= 1.0001e-9 + 1e-12 * np.abs(b["cost"][cert, 0])).all()
