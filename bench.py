@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override problems per GPU per step")
     ap.add_argument("--n", type=int, default=0, help="points per problem of --workload pnp_scal")
     ap.add_argument("--blocked", default="auto", choices=("auto", "0", "1"), help="assembly path: 1 = cvxpnpl_assemble_large_batch + cost-seam solve, "
-                    "0 = in-kernel assembly, auto = the product's rule (cvxpnpl_amd.api.LARGE_N = 768 correspondence records)")
+                    "0 = in-kernel assembly, auto = the product's rule (cvxpnpl_amd.api.use_blocked_assembly: 768 correspondence records, 384 in batches of >= 2 048)")
     ap.add_argument("--no-f64-ab", action="store_true", help="skip the extra all-float64 measurement (value_all_f64)")
     ap.add_argument("--sigma", type=float, default=None, help="pixel noise of the synthetic problems")
     ap.add_argument("--seed", type=int, default=42, help="seed of the synthetic problems (diagnostics: the default is the judged workload)")
@@ -169,7 +169,7 @@ def main():
     pending = []  # (work, packed) of the gather in flight: overlapped with the next batch's solve
     side = torch.cuda.Stream(dev) if gather else None   # pack + all_gather of the finished step, off the solve stream
     packed_done = [None] * nsets                         # event: the records of this output set have been packed (it may be overwritten)
-    blocked = (n_p + 2 * n_l >= 768) if args.blocked == "auto" else args.blocked == "1"  # cvxpnpl_amd.api.LARGE_N: blocked assembly + cost-seam solve
+    blocked = ((n_p + 2 * n_l >= 768) or (n_p + 2 * n_l >= 384 and batch >= 2048)) if args.blocked == "auto" else args.blocked == "1"  # cvxpnpl_amd.api.use_blocked_assembly: blocked assembly + cost-seam solve
     if blocked:
         nb = L.cvxpnpl_assemble_large_scratch_bytes(batch, n_p, n_l)
         asm_scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)

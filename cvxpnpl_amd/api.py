@@ -102,7 +102,7 @@ def pnpl_batch(pts_2d, line_2d, pts_3d, line_3d, K, eps: float = 1e-9, max_iters
     per = int(Kd.dim() == 3)
     if Kd.dim() not in (2, 3) or (per and Kd.shape[0] != batch):
         raise ValueError("K must be [3,3] or [batch,3,3]")
-    if n_p + 2 * n_l >= LARGE_N and batch > 0:
+    if batch > 0 and use_blocked_assembly(n_p + 2 * n_l, batch):
         # the scalability regime (benchmarks/scalability/pnp.py:37-40: up to 10^4 points per problem): bandwidth-shaped
         # blocked assembly, then the solve at the cost seam -- instead of one wavefront streaming the problem
         Bt, Qt = assemble_batch(pts_2d, line_2d, p3 if n_p else None, l3 if n_l else None, Kd, device=device, blocked=True)
@@ -322,11 +322,19 @@ def solve_relaxation_rc(A: np.ndarray, B: np.ndarray, eps: float = 1e-9, max_ite
 
 
 # Correspondence records (points + 2 x lines) from which pnpl_batch assembles with the blocked kernel.  Measured, wall clock of pnpl_batch,
-# blocked / in-kernel (profiles/r03/large_n_crossover.jsonl): 384 records 1.4-1.5 (1-1000 problems), 1.0 (4 k-16 k), 1.5 (50 k); 768: 1.17 / 1.14 /
-# 0.97 / 0.72 / 0.73 / 1.0 (1 / 256 / 1 k / 4 k / 16 k / 50 k problems); 1536: 0.84-0.88 / 0.72 / 0.5.  In-kernel assembly costs one memory
-# round trip and is parallel over problems only; the blocked kernel is parallel over correspondences and pays two more launches.
+# blocked / in-kernel (profiles/r03/large_n_crossover.jsonl, with the LDS-ring assembly): 384 records 1.27-1.34 (1-256 problems), 1.10 (1 k),
+# 0.72 (4 k), 0.79 (16 k), 0.93 (50 k); 768: 1.08-1.11 (1-256) / 0.91 (1 k) / 0.54 (4 k) / 0.58 (16 k) / 0.72 (50 k); 1536: 0.80-0.82 / 0.73 /
+# 0.38-0.44; 192 records: 1.0 at best.  In-kernel assembly costs one memory round trip and is parallel over problems only; the blocked
+# kernel is parallel over correspondences and pays one more launch (two when a problem is split over several workgroups).
 # (Round 2 had 192, from launch-time measurements of 1 000-problem batches with the general lane core.)
 LARGE_N = 768
+LARGE_N_MANY = 384      # ... in batches of at least
+LARGE_N_MANY_BATCH = 2048
+
+
+def use_blocked_assembly(n_records, batch):
+    """the routing rule of pnpl_batch / assemble_batch(blocked=None)"""
+    return n_records >= LARGE_N or (n_records >= LARGE_N_MANY and batch >= LARGE_N_MANY_BATCH)
 
 
 def assemble_batch(pts_2d, line_2d, pts_3d, line_3d, K, device=None, blocked=None):
@@ -351,7 +359,7 @@ def assemble_batch(pts_2d, line_2d, pts_3d, line_3d, K, device=None, blocked=Non
     if n_p and n_l and l3.shape[0] != batch:
         raise ValueError(f"points and lines describe different batches ({batch} vs {l3.shape[0]})")
     if blocked is None:
-        blocked = n_p + 2 * n_l >= LARGE_N
+        blocked = use_blocked_assembly(n_p + 2 * n_l, batch)
     p3 = p3.reshape(batch, n_p, 3) if n_p else None
     l3 = l3.reshape(batch, n_l, 2, 3) if n_l else None
     with torch.cuda.device(dev):

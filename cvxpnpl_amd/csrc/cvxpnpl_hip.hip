@@ -521,8 +521,13 @@ int cvxpnpl_assemble_large_batch(int64_t batch, int32_t n_p, const double *d_pts
     a.nblk = cvxa::asm_blocks((int64_t)n_p + 2 * (int64_t)n_l, batch);
     a.p2 = d_pts_2d; a.p3 = d_pts_3d; a.l2 = d_line_2d; a.l3 = d_line_3d; a.K = d_K;
     a.partial = (double *)d_scratch;
-    hipLaunchKernelGGL(cvxa::assemble_large_kernel, dim3((unsigned)a.nblk, (unsigned)batch), dim3(cvxa::ASM_TPB), 0, (hipStream_t)stream, a);
-    hipLaunchKernelGGL(cvxa::assemble_finish_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a, d_B, d_Q45);
+    a.Bout = d_B; a.Qout = d_Q45;
+    if (cvxa::asm_tpb((int64_t)n_p + 2 * (int64_t)n_l, batch) == cvxa::ASM_TPB)
+        hipLaunchKernelGGL(cvxa::assemble_large_kernel<cvxa::ASM_TPB>, dim3((unsigned)a.nblk, (unsigned)batch), dim3(cvxa::ASM_TPB), 0, (hipStream_t)stream, a);
+    else // short problems or many of them: one wavefront per workgroup (cvxa::asm_tpb)
+        hipLaunchKernelGGL(cvxa::assemble_large_kernel<cvxa::ASM_TPB_NARROW>, dim3((unsigned)a.nblk, (unsigned)batch), dim3(cvxa::ASM_TPB_NARROW), 0, (hipStream_t)stream, a);
+    if (a.nblk > 1) // several workgroups per problem: their partial sums are added in a fixed order by a second kernel
+        hipLaunchKernelGGL(cvxa::assemble_finish_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a, d_B, d_Q45);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err("assemble_large_kernel launch", e);
     return 0;

@@ -1630,12 +1630,27 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
             CVX_UNROLL for (int i = 0; i < 9; ++i) CVX_UNROLL for (int j = i; j < 9; ++j) X[sidx(i, j)] -= irho * Qs[qidx(i, j)];
             proj_affine<VAR>(X, false);
             double r2 = 0;
+#ifdef CVX_AA_EXPERIMENT // host experiment (tools/experiments/aa_hostsim.cpp): Anderson acceleration of the fixed-point map
+            {
+                double g[55], f[55];
+                for (int i = 0; i < 10; ++i)
+                    for (int j = i; j < 10; ++j) {
+                        const int k_ = sidx(i, j);
+                        const double d = X[k_] - Wp[k_];
+                        r2 += (i == j ? 1.0 : 2.0) * d * d;
+                        f[k_] = o.alpha * d;
+                        g[k_] = W[k_] + f[k_];
+                    }
+                aa_step(it, W, g, f);
+            }
+#else
             CVX_UNROLL for (int i = 0; i < 10; ++i)
                 CVX_UNROLL for (int j = i; j < 10; ++j) {
                     double d = X[sidx(i, j)] - Wp[sidx(i, j)];
                     r2 += (i == j ? 1.0 : 2.0) * d * d;
                     W[sidx(i, j)] += o.alpha * d;
                 }
+#endif
             fp_res = sqrt_(r2);
 #ifdef CVX_TRACE
             {

@@ -63,6 +63,36 @@ def test_blocked_assembly_matches_reference_matrices(gpu, orc, n_p, n_l, batch):
         assert np.abs(Bn[i].reshape(3, 9) - B).max() < 1e-10 * max(1.0, np.abs(B).max())
 
 
+@pytest.mark.parametrize("n_p", [63, 64, 65, 128, 1000, 4099, 20000])
+def test_ring_and_direct_loads_agree(gpu, n_p):
+    """assemble_large_kernel streams full tiles of 64 records through its LDS ring when a problem's arrays start on a 16-byte boundary
+    and loads directly otherwise (and for the partial last tile): same lane, same order -- bit-identical sums.  The same batch is
+    assembled from aligned tensors and from views that start 8 bytes into their storage."""
+    import torch
+
+    import cvxpnpl_amd as ca
+    from cvxpnpl_amd import synth
+
+    batch = 6
+    d = synth.make_pnpl(batch, n_p, 0, 1.0, seed=5 + n_p)
+    tt = lambda x: torch.as_tensor(x, device=gpu)  # noqa: E731
+
+    def off8(x):  # the same values, storage shifted by one double
+        t = tt(x)
+        buf = torch.empty(t.numel() + 1, dtype=t.dtype, device=gpu)
+        v = buf[1:].view(t.shape)
+        v.copy_(t)
+        assert v.data_ptr() % 16 == 8
+        return v
+
+    K = tt(d["K"])
+    Ba, Qa = ca.assemble_batch(tt(d["pts_2d"]), None, tt(d["pts_3d"]), None, K, blocked=True)
+    Bb, Qb = ca.assemble_batch(off8(d["pts_2d"]), None, off8(d["pts_3d"]), None, K, blocked=True)
+    assert torch.equal(Ba, Bb) and torch.equal(Qa, Qb)
+    Bs, Qs = ca.assemble_batch(tt(d["pts_2d"]), None, tt(d["pts_3d"]), None, K, blocked=False)
+    assert (Qa - Qs).abs().max().item() < 1e-11 * Qa.abs().max().item() and (Ba - Bs).abs().max().item() < 1e-10
+
+
 @pytest.mark.parametrize("n", [200, 2000, 10000])
 def test_large_n_poses_vs_oracle(gpu, orc, n):
     """pnp_batch at n = 200, 2 000, 10 000 points per problem (from 768 points on routed through the blocked assembly): poses within 1e-6

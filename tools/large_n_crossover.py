@@ -35,12 +35,12 @@ for batch in (1, 16, 256, 1000, 4000, 16000, 50000):
             continue
         d = synth.device_pnpl(batch, n, 0, sigma=2.0, seed=3, device=dev)
         a = (d["pts_2d"], None, d["pts_3d"], None, d["K"])
-        old = api.LARGE_N
+        old = (api.LARGE_N, api.LARGE_N_MANY)
         reps = 20 if batch * n < 4e6 else 8
-        api.LARGE_N = 1 << 30
+        api.LARGE_N = api.LARGE_N_MANY = 1 << 30
         t_in = timed(lambda: ca.pnpl_batch(*a), reps)
-        api.LARGE_N = 1
+        api.LARGE_N = api.LARGE_N_MANY = 1
         t_bl = timed(lambda: ca.pnpl_batch(*a), reps)
-        api.LARGE_N = old
+        api.LARGE_N, api.LARGE_N_MANY = old
         print(json.dumps({"batch": batch, "n": n, "in_kernel_ms": round(1e3 * t_in, 4), "blocked_ms": round(1e3 * t_bl, 4),
                           "blocked_over_in_kernel": round(t_bl / t_in, 3)}), flush=True)
