@@ -1374,7 +1374,13 @@ __global__ void __launch_bounds__(64 * WPB, 2) solve_wave_kernel(WaveArgs a, cvx
 // touching anything -- with an empty queue (most launches) that is every block.  So every launch leaves the queue as it found it --
 // no host-side bookkeeping, no memset per launch, nothing a hipGraph replay could desynchronise -- and every index is range
 // checked, so a corrupted workspace cannot turn into an out-of-bounds write.  entries[] has RESUME_GRID_MAX spare slots.
-constexpr int RESUME_GRID_MAX = 2048; // one block per resident wavefront slot: more blocks only add launch time to the (usual) empty-queue case
+#ifndef CVXW_OCC_RESUME
+#define CVXW_OCC_RESUME 2
+#endif
+#ifndef CVXW_OCC_RESCUE
+#define CVXW_OCC_RESCUE 2
+#endif
+constexpr int RESUME_GRID_MAX = 1024 * (CVXW_OCC_RESUME > CVXW_OCC_RESCUE ? CVXW_OCC_RESUME : CVXW_OCC_RESCUE); // one block per resident wavefront slot: more blocks only add launch time to the (usual) empty-queue case
 // A block whose first queue slot is empty (every block of most launches) leaves after one load: the arguments of the
 // solve are read from the kernarg segment only behind that test, so that nothing is live -- and nothing spilled -- before
 // it (with by-value arguments the 8192 mostly idle wavefronts of a launch wrote 126 MB of spilled registers at kernel
@@ -1442,7 +1448,7 @@ __device__ __forceinline__ void resume_body(ResumeArgsPtr kp, int32_t first, dou
 #endif
 }
 
-__global__ void __launch_bounds__(64, 2) resume_wave_kernel(ResumeArgs k)
+__global__ void __launch_bounds__(64, CVXW_OCC_RESUME) resume_wave_kernel(ResumeArgs k)
 {
     __shared__ __attribute__((aligned(16))) double lds_all[LDSW];
     const int32_t first = k.entries[blockIdx.x];
@@ -1450,7 +1456,7 @@ __global__ void __launch_bounds__(64, 2) resume_wave_kernel(ResumeArgs k)
     resume_body<false>((ResumeArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), first, lds_all);
 }
 // the same for the 16-equality variant (quad schedule of cvxpnpl_solve_cost_batch / solve_batch with opts.variant = RC)
-__global__ void __launch_bounds__(64, 2) resume_wave_kernel_rc(ResumeArgs k)
+__global__ void __launch_bounds__(64, CVXW_OCC_RESUME) resume_wave_kernel_rc(ResumeArgs k)
 {
     __shared__ __attribute__((aligned(16))) double lds_all[LDSW];
     const int32_t first = k.entries[blockIdx.x];
@@ -1462,7 +1468,7 @@ __global__ void __launch_bounds__(64, 2) resume_wave_kernel_rc(ResumeArgs k)
 // rq_count, k.entries = rq_entries; same self-cleaning queue discipline), one wavefront each, through the interior-point solve.
 // In the quad layout the same launch also takes the place of resume_wave_kernel: its blocks from k.grid1 on serve the resume queue
 // (k.count2, k.entries2, k.ws), and a parked problem that reaches opts.rescue_from goes through the interior-point solve right here.
-__global__ void __launch_bounds__(64, 2) rescue_wave_kernel(ResumeArgs k)
+__global__ void __launch_bounds__(64, CVXW_OCC_RESCUE) rescue_wave_kernel(ResumeArgs k)
 {
     __shared__ __attribute__((aligned(16))) double lds_all[LDSW_IPM];
     const int32_t first = (int)blockIdx.x < k.grid1 ? k.entries[blockIdx.x] : k.entries2[(int)blockIdx.x - k.grid1];
@@ -1470,7 +1476,7 @@ __global__ void __launch_bounds__(64, 2) rescue_wave_kernel(ResumeArgs k)
     resume_body<true>((ResumeArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), first, lds_all);
 }
 // the same for the 16-equality variant: the interior-point solve on its 16 rows (cvx::ipm_rows)
-__global__ void __launch_bounds__(64, 2) rescue_wave_kernel_rc(ResumeArgs k)
+__global__ void __launch_bounds__(64, CVXW_OCC_RESCUE) rescue_wave_kernel_rc(ResumeArgs k)
 {
     __shared__ __attribute__((aligned(16))) double lds_all[LDSW_IPM];
     const int32_t first = (int)blockIdx.x < k.grid1 ? k.entries[blockIdx.x] : k.entries2[(int)blockIdx.x - k.grid1];
