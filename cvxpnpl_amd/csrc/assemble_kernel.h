@@ -20,12 +20,12 @@
 namespace cvxa {
 
 // Threads per workgroup.  The 60-value reduction that ends a workgroup costs as much as ~8 records per lane, so a workgroup of four
-// wavefronts pays only for long problems in short batches (10^4 points x 1 000 problems: 0.0765 ms against 0.094 with one wavefront
-// per workgroup); with >= 1 536 problems one wavefront each fills the chip, and below 2 048 records four wavefronts have too little
-// to stream (10^3 points x 10^4 problems: 0.099 ms narrow, 0.166 wide; 2 000 x 5 000: 0.091 / 0.118; 5 000 x 2 000: 0.085 / 0.089).
+// wavefronts pays only when a problem is long: from 4 096 records on (measured on ~10^7 points per launch, TB/s with four wavefronts /
+// one wavefront per workgroup: 2 263 records 4.65 / 5.44, 3 294: 5.2 / 5.5, 4 326: 5.3 / 5.1, 5 357: 5.2 / 4.4, 6 389: 5.0 / 4.1,
+// 10^4 x 1 000 problems: 5.7-5.9 / 4.3).
 constexpr int ASM_TPB = 256, ASM_TPB_NARROW = 64;
 constexpr int ASM_MAX_BLOCKS = 64; // workgroups per problem (upper bound)
-__host__ __device__ inline int asm_tpb(int64_t nrec, int64_t batch) { return (nrec >= 2048 && batch < 1536) ? ASM_TPB : ASM_TPB_NARROW; }
+__host__ __device__ inline int asm_tpb(int64_t nrec, int64_t batch) { (void)batch; return nrec >= 4096 ? ASM_TPB : ASM_TPB_NARROW; }
 
 struct AsmArgs {
     int64_t batch;
