@@ -148,7 +148,7 @@ def main():
     over = {}
     for kv in args.opt:
         k, v = kv.split("=")
-        over[k] = float(v) if k in ("eps", "rho", "alpha", "res_tol", "jacobi_tol", "rho_tail", "adapt_mu", "adapt_tau", "stall_lam", "stall_res", "stall_drop") else int(v)
+        over[k] = float(v) if k in ("eps", "rho", "alpha", "res_tol", "jacobi_tol", "rho_tail", "adapt_mu", "adapt_tau", "stall_lam", "stall_res", "stall_drop", "dual_shift") else int(v)
     opts = _lib.default_opts(layout=args.layout, **over)
     ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else C.c_void_p(0)  # noqa: E731
     stream = torch.cuda.current_stream(dev)

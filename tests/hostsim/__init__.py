@@ -18,7 +18,7 @@ class Opts(C.Structure):
                 ("first_check", C.c_int), ("check_every", C.c_int), ("res_tol", C.c_double), ("jacobi_sweeps", C.c_int),
                 ("jacobi_tol", C.c_double), ("warm_start", C.c_int), ("rho_tail", C.c_double), ("tail_from", C.c_int),
                 ("adapt_every", C.c_int), ("adapt_from", C.c_int), ("adapt_mu", C.c_double), ("adapt_tau", C.c_double),
-                ("stall_from", C.c_int), ("stall_lam", C.c_double), ("stall_res", C.c_double), ("stall_drop", C.c_double), ("variant", C.c_int), ("rescue_from", C.c_int), ("f32_sweeps_until", C.c_int), ("sweep_schedule", C.c_int)]
+                ("stall_from", C.c_int), ("stall_lam", C.c_double), ("stall_res", C.c_double), ("stall_drop", C.c_double), ("variant", C.c_int), ("rescue_from", C.c_int), ("f32_sweeps_until", C.c_int), ("sweep_schedule", C.c_int), ("dual_shift", C.c_double)]
 
 
 def build(force=False):
@@ -167,3 +167,18 @@ def lane_phase(pts_2d, pts_3d, line_2d, line_3d, K, iters, impl, opts=None, dbl=
     lib().hs_lane_phase(Bn, n_p, _p(a[0]), _p(a[1]), n_l, _p(a[2]), _p(a[3]), _p(K), int(K.ndim == 3), C.byref(o), int(iters), int(impl), int(dbl),
                         _p(R), _p(t), st.ctypes.data_as(_ip), it.ctypes.data_as(_ip), _p(cost), sw.ctypes.data_as(_ip), _p(ho), _p(Z))
     return {"R": R, "t": t, "status": st, "iters": it, "cost": cost, "sweeps": sw, "handoff": ho, "Z": Z}
+
+
+def dual_retry_direction(R):
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    D = np.zeros((10, 10))
+    lib().hs_dual_retry_direction.argtypes = [_dp, _dp]
+    lib().hs_dual_retry_direction(_p(R), _p(D))
+    return D
+
+
+def proj_affine_homog(E55, variant=0):
+    E = np.ascontiguousarray(E55, dtype=np.float64).copy()
+    lib().hs_proj_affine_homog.argtypes = [_dp, C.c_int]
+    lib().hs_proj_affine_homog(_p(E), int(variant))
+    return E

@@ -16,6 +16,19 @@ void hs_dual_lambda(const double *R9, const double *rhs10, int symm, double *lam
 // reuse test of the certificate (solver_core.h: rounds_to); returns 1/0, det of the rank-1 ratio in d0
 int hs_rounds_to(const double *v10, const double *Rp9, double tol, double *d0) { return cvx::rounds_to(v10, Rp9, *d0, tol) ? 1 : 0; }
 
+// the direction of the dual's second tries (solver_core.h: dual_retry_entry6): D(R) as a full 10 x 10
+void hs_dual_retry_direction(const double *R9, double *D100)
+{
+    for (int a = 0; a < 10; ++a)
+        for (int b = 0; b < 10; ++b) D100[a * 10 + b] = cvx::dual_retry_entry6(R9, a < b ? a : b, a < b ? b : a) * (1.0 / 6.0);
+}
+// homogeneous projection onto the direction space of the equalities (solver_core.h: proj_affine), packed 55 in place
+void hs_proj_affine_homog(double *E55, int variant)
+{
+    if (variant == cvx::VAR_RC) cvx::proj_affine<cvx::VAR_RC>(E55, true);
+    else cvx::proj_affine<cvx::VAR_FULL>(E55, true);
+}
+
 // same argument meaning as cvxpnpl_solve_batch (include/cvxpnpl_amd.h), host pointers
 int hs_solve_batch(int batch, int n_p, const double *pts_2d, const double *pts_3d, int n_l, const double *line_2d,
                    const double *line_3d, const double *K, int K_per_problem, const cvx::Opts *opts,

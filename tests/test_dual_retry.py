@@ -1,0 +1,120 @@
+"""opts.dual_shift: the second tries of a failed dual (solver_core.h: dual_retry_entry6, dual_certificate; wave_kernel.h: coop_dual).
+
+The duals that certify a pose z = [vec(R); 1] are the PSD members of  S1 + U,  U = { X in span A_i : X z = 0 }  (A_i: the equality
+matrices of cvxpnpl.py:387-451).  The second tries move the recovered dual along D(R) = P_U(I - z z^T / 4), for which the code uses a
+closed form.  Pinned here: (CPU) the closed form equals the projection computed numerically from the constraint matrices, for both
+constraint sets; D z = 0; D lies in span A_i; the scalar core with and without the tries certifies the same poses in fewer iterations.
+(GPU) a lane-hybrid launch with and without the tries: same statuses, same certified poses to 1e-9 rad, fewer iterations; option validated."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def _span_A(rc):
+    Ti = [[0, 3, 6], [0, 3, 6], [1, 4, 7], [0, 1, 2], [0, 1, 2], [3, 4, 5], [1, 2, 6], [2, 0, 7], [0, 1, 8], [4, 5, 0], [5, 3, 1], [3, 4, 2], [2, 1, 3], [0, 2, 4], [1, 0, 5]]
+    Tj = [[1, 4, 7], [2, 5, 8], [2, 5, 8], [3, 4, 5], [6, 7, 8], [6, 7, 8], [5, 4, 9], [3, 5, 9], [4, 3, 9], [8, 7, 9], [6, 8, 9], [7, 6, 9], [7, 8, 9], [8, 6, 9], [6, 7, 9]]
+    A = []
+    for t in range(3 if rc else 0, 15):      # cvxpnpl.py:404-435 as sign triples (solver_core.h: tri_i / tri_j / tri_s); rc.py:16-35 drops the first three
+        M = np.zeros((10, 10))
+        for k in range(3):
+            s = -1.0 if (t >= 6 and k >= 1) else 1.0
+            M[Ti[t][k], Tj[t][k]] += 0.5 * s
+            M[Tj[t][k], Ti[t][k]] += 0.5 * s
+        A.append(M)
+    if not rc:
+        for i in range(3):                   # rows of R have unit norm
+            M = np.zeros((10, 10))
+            for j in range(3):
+                M[3 * j + i, 3 * j + i] = 1
+            A.append(M)
+    for j in range(3):                       # columns of R have unit norm
+        M = np.zeros((10, 10))
+        for i in range(3):
+            M[3 * j + i, 3 * j + i] = 1
+        A.append(M)
+    M = np.zeros((10, 10))
+    M[9, 9] = 1
+    A.append(M)
+    return np.array([a.ravel() for a in A])
+
+
+def _numeric_direction(z, Am):
+    _, s, Vt = np.linalg.svd(Am, full_matrices=False)
+    B = Vt[: int(np.sum(s > 1e-10))]                               # orthonormal basis of span A_i
+    G = np.array([(b.reshape(10, 10) @ z) for b in B]).T            # X z = G c
+    _, s2, vt = np.linalg.svd(G)
+    Ub = vt[int(np.sum(s2 > 1e-10)):] @ B                          # orthonormal basis of U
+    T = np.eye(10) - np.outer(z, z) / 4.0
+    return ((Ub @ T.ravel()) @ Ub).reshape(10, 10), len(Ub)
+
+
+@pytest.mark.parametrize("rc", [False, True])
+def test_closed_form_of_the_retry_direction(rc):
+    from scipy.spatial.transform import Rotation
+
+    import hostsim
+
+    Am = _span_A(rc)
+    assert np.linalg.matrix_rank(Am) == (16 if rc else 21)  # (22 / 16 equalities, one redundant in the full set)
+    for seed in range(5):
+        R = Rotation.random(random_state=seed).as_matrix()
+        z = np.concatenate([R.T.ravel(), [1.0]])                    # z[3 j + i] = R[i][j]
+        D = hostsim.dual_retry_direction(R)
+        Dn, dim = _numeric_direction(z, Am)
+        assert rc or dim == 14
+        if not rc:
+            assert np.abs(D - Dn).max() < 1e-13
+        else:  # the rc family is larger; the SAME direction is used and must lie in it: D in span A_rc, D z = 0
+            c = np.linalg.lstsq(Am.T, D.ravel(), rcond=None)[0]
+            assert np.abs(Am.T @ c - D.ravel()).max() < 1e-12
+        assert np.abs(D @ z).max() < 1e-14 and np.abs(D - D.T).max() == 0.0
+        # in span A_i: the projection onto the equalities' direction space (proj_affine, homogeneous) annihilates it
+        vech = np.array([D[i, j] for i in range(10) for j in range(i, 10)])
+        assert np.abs(hostsim.proj_affine_homog(vech, 1 if rc else 0)).max() < 1e-14
+        lam = np.linalg.eigvalsh(D)
+        assert abs(lam[0] + 2.0 / 3.0) < 1e-12 and np.abs(lam[-5:] - 1.0 / 3.0).max() < 1e-12 and np.abs(lam[1:5]).max() < 1e-12
+
+
+def test_scalar_core_with_and_without_second_tries():
+    import hostsim
+    from cvxpnpl_amd import synth
+    from test_gpu_parity import geodesic_np
+
+    d = synth.make_pnpl(4000, 10, 0, 2.0, seed=42)
+    a = hostsim.solve_batch(d["pts_2d"], d["pts_3d"], None, None, d["K"], opts=hostsim.default_opts(dual_shift=0.0))
+    b = hostsim.solve_batch(d["pts_2d"], d["pts_3d"], None, None, d["K"], opts=hostsim.default_opts())
+    assert hostsim.default_opts().dual_shift == 0.015
+    assert (a["status"] == 0).all() and (b["status"] == 0).all()
+    assert max(geodesic_np(a["R"][i], b["R"][i]) for i in range(4000)) < 1e-9          # both are the certified global optimum
+    assert (b["iters"] <= a["iters"]).mean() > 0.999 and (b["iters"] >= 8).sum() < 0.75 * (a["iters"] >= 8).sum()  # (measured 32 against 52)
+    gap = b["cost"][:, 0] - b["cost"][:, 1]
+    assert (gap >= -1e-15).all() and (gap <= 1.0001e-9 + 1e-12 * np.abs(b["cost"][:, 0])).all()                # the certificate statement is unchanged
+
+
+@pytest.mark.gpu
+def test_second_tries_on_the_device():
+    import torch
+    from test_gpu_parity import _solve, geodesic_np
+
+    from cvxpnpl_amd import synth
+
+    from cvxpnpl_amd import _lib
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    _lib.lib()
+    dev = torch.device("cuda:0")
+    d = synth.make_pnpl(30000, 10, 0, 2.0, seed=7)   # lane-hybrid schedule: parked problems go to resume_wave_kernel, where the tries are made
+    a = _solve(dev, d, 10, 0, dual_shift=0.0)
+    b = _solve(dev, d, 10, 0)
+    assert (a["status"] == 0).all() and (b["status"] == 0).all()
+    worst = max(geodesic_np(a["R"][i], b["R"][i]) for i in np.flatnonzero(a["iters"] != b["iters"]))
+    assert worst < 1e-9
+    assert b["iters"].mean() < a["iters"].mean() and (b["iters"] >= 10).sum() <= (a["iters"] >= 10).sum()
+    gap = b["cost"][:, 0] - b["cost"][:, 1]
+    assert (gap >= -1e-15).all() and (gap <= 1.0001e-9 + 1e-12 * np.abs(b["cost"][:, 0])).all()
+    with pytest.raises(RuntimeError, match="bad options"):
+        _solve(dev, d, 10, 0, dual_shift=-0.1)
