@@ -344,7 +344,13 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     //   per problem, but it needs ~20 k problems to give every SIMD a wavefront (round 2, general scalar core: crossover 24 576).
     // The problems the quad phase leaves open are finished by the same wavefront, those of the lane phase by a second kernel,
     // one per wavefront in both cases.
-    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 2560 ? CVXPNPL_LAYOUT_WAVE : (batch < 20000 ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
+    // Minimal problems (four correspondences; the cost seam does not say): 18 iterations on average and a fifth of them beyond 32 --
+    // the lane-hybrid schedule would park nearly all of them for the one-problem-per-wavefront phase.  They stay four per wavefront
+    // for 24 iterations instead (first attempt after 7), like the rc variant: 50 k problems 11.2 -> 12.4 M poses/s (lane_iters 16 / 24 /
+    // 32 / 40: 12.1 / 12.4 / 11.7-12.2 / 12.3; five correspondences and more: the lane-hybrid schedule wins, 36.8 against 33.6 M at N = 5).
+    const bool minimal = !a.Q45 && a.n_p + a.n_l <= 4 && o.variant == cvx::VAR_FULL && layout == CVXPNPL_LAYOUT_AUTO && batch >= 2560 && o.max_iters > 24 &&
+                         (!opts || opts->lane_iters <= 0);
+    if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 2560 ? CVXPNPL_LAYOUT_WAVE : ((batch < 20000 || minimal) ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
     // The 16-equality variant (benchmarks/toolkit/methods/rc.py): wave-per-problem and, since round 3, the quad schedule (the
     // constraint set is a template parameter of the kernels); the lane kernels and the interior-point path are built for the full set.
     const bool rc = o.variant == cvx::VAR_RC;
@@ -358,9 +364,10 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     int quad_iters = opts ? opts->lane_iters : -1;
     // rc: the weaker relaxation certifies after ~21 iterations instead of 5 (N = 10): a longer first phase, first attempt later
     if (quad_iters <= 0 && rc) quad_iters = 36; // (profiles/r03/rc_tune.txt: 28 / 36 / 44 within 1 %)
+    if (quad_iters <= 0 && minimal) quad_iters = 24;
     if (quad_iters <= 0) quad_iters = 7; // measured (4 problem sets at 10 k, same box): 5: 0.242 ms, 7: 0.233, 8: 0.235, 10: 0.240; 24 k: 7 = 10 (round 1, second phase as a call: 8-12)
     if (quad_iters > 48) quad_iters = 48; // (rc: up to 48 -- still inside the wave kernel's own single-precision window of 64)
-    if (quad_iters > 16 && !rc) quad_iters = 16; // the quad phase runs its eigen-solve sweeps in single precision: fine for the first iterations, not for a slow tail (quad_kernel.h)
+    if (quad_iters > 16 && !rc && !minimal) quad_iters = 16; // the quad phase runs its eigen-solve sweeps in single precision: fine for the first iterations, not for a slow tail (quad_kernel.h)
     const bool lane_general = layout == 10; // experiment / A-B (tools/README.md): the lane schedule with the general scalar core (solve_lane_kernel)
     if (lane_general) layout = CVXPNPL_LAYOUT_LANE;
     const bool penta = layout == CVXPNPL_LAYOUT_PENTA && !(o.f32_sweeps_until < quad_iters); // (float64 sweeps: built for the sixteen-lane geometry only)
@@ -372,7 +379,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     // extra iteration: 125 k problems 157 -> 164 M poses/s, PnPL 100 k 116 -> 126 M.  The quad and wave layouts keep 5 (quad with 6, launch
     // time relative to 5 over 4 problem sets per size: 3 k 0.93, 5 k 1.07, 8 k 1.02, 10 k 0.98, 12 k 1.07, 16 k 1.03, 20 k 1.02, 24 k 0.97;
     // wave: -12 % at 2 k).
-    if (o.first_check <= 0) o.first_check = rc ? 11 : (layout == CVXPNPL_LAYOUT_LANE ? 6 : 5); // (rc: nothing certifies before ~10 iterations; 5 ... 15 within 3 %)
+    if (o.first_check <= 0) o.first_check = rc ? 11 : (minimal ? 7 : (layout == CVXPNPL_LAYOUT_LANE ? 6 : 5)); // (rc: nothing certifies before ~10 iterations; 5 ... 15 within 3 %)
     // interior-point path for the problems still open after rescue_from iterations (ipm_wave.h): its queue lives in the workspace
     // -1 (default): by problem size.  Slow convergence is a property of minimal and near-minimal configurations
     // (profiles/r02/remaining_iters.jsonl, 100 k problems each, first-order iterations only: with N = 4 / 5 / 6 / 7 correspondences
