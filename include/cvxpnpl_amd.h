@@ -40,7 +40,8 @@ enum {
 
 /* kernel layouts (A/B switch; all produce the same results) */
 enum {
-    CVXPNPL_LAYOUT_AUTO = 0, /* by launch size: wave below 2560 problems, quad below 20000, lane (hybrid) from there */
+    CVXPNPL_LAYOUT_AUTO = 0, /* by launch size: wave below 2560 problems, quad below 20000, lane (hybrid) from there; four-correspondence
+                                problems: quad from 2560 on, with a 24-iteration first phase and the first attempt after 7 */
     CVXPNPL_LAYOUT_LANE = 1, /* one problem per lane, 64 per wavefront, for the first lane_iters iterations;
                                 unfinished problems are then resumed one per wavefront (hybrid schedule) */
     CVXPNPL_LAYOUT_WAVE = 2, /* one problem per wavefront (cooperative lanes) */
