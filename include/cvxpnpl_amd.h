@@ -111,7 +111,7 @@ typedef struct {
                             A column pair that misses its last sweep is caught by the next iteration's warm start; what certifies is
                             unchanged to ~0.1 % of the first attempts (cvx::sweep_cap has the measurements), results are not affected.
                             0: only jacobi_sweeps. */
-    double dual_shift;      /* default 0.015.  A certificate attempt whose recovered dual S fails the PSD test while the pose is fine gets second
+    double dual_shift;      /* -1 (default): 0.015, rc variant 0.006.  A certificate attempt whose recovered dual S fails the PSD test while the pose is fine gets second
                             tries with S + s D(R), s = dual_shift, dual_shift / 4, D(R) the projection of the identity onto the family of
                             duals that are complementary to the pose (a constant in the frame of R: cvx::dual_retry_entry6) -- one more
                             LDL^T each, no fit.  Made for the problems a quad or lane phase has handed over to the wave-per-problem phase
