@@ -249,23 +249,25 @@ constexpr int C_ROW = L_EX + 190;   // 12   pivot row (+ rhs entry) of the elimi
 constexpr int C_LAM = L_EX + 202;   // 10   multipliers of the dual correction
 constexpr int C_SF = L_G;           // 100  full 10x10 S
 
-// In-place LDL^T elimination of the symmetric matrix held one entry (a <= b) per lane, through LDS row
-// broadcasts.  Returns the smallest pivot met; stops at the first non-positive one (the matrix is then
-// not positive definite and the caller rejects the certificate -- wave-uniform, the pivot is broadcast).
+// In-place LDL^T elimination of the symmetric matrix held one entry (a <= b) per lane (lane = vech index; lanes 55..63 alias 0..8).
+// Returns the smallest pivot met; stops at the first non-positive one (the matrix is then not positive definite and the caller
+// rejects the certificate -- wave-uniform, the pivot is read into a scalar register).  Row k of the current matrix sits in the lanes
+// sidx(k, k) ... sidx(k, 9) = c_k + k ... c_k + 9: a lane fetches its two row entries with ds_bpermute (no LDS traffic, no barrier).
+// (The first version broadcast the pivot row through LDS: write, barrier, three reads per step -- 5 300 cycles per factorisation,
+// a quarter of a certificate attempt; this one: see profiles/r03/coop_ldl_ab.txt.)
 __device__ __forceinline__ double coop_ldl(double *L, const Roles &r, double &Me)
 {
+    (void)L;
     double minp = 1e300;
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
-        if (r.ei == k && r.lane < 55) L[C_ROW + r.ej] = Me;
-        CVXW_SYNC();
-        const double d = L[C_ROW + k];
+        const int ck = k * 10 - k * (k - 1) / 2 - k; // sidx(k, x) = ck + x  for x >= k
+        const double d = wave_lane(Me, ck + k);
         minp = d < minp ? d : minp;
-        if (!(d > 0)) { CVXW_SYNC(); break; }
+        if (!(d > 0)) break;
         const double id = fast_rcp(d);
-        const double ra = L[C_ROW + r.ei], rb = L[C_ROW + r.ej];
+        const double ra = __shfl(Me, ck + r.ei), rb = __shfl(Me, ck + r.ej);
         if (r.ei > k) Me -= ra * id * rb;
-        CVXW_SYNC();
     }
     return minp;
 }
