@@ -103,7 +103,7 @@ typedef struct {
                             LDL^T -> gap has succeeded on it.  This field bounds the exception: sweeps are single precision while the
                             iteration count of the solve is below it.  -1 (default): 64.  0: never -- every sweep, rotation angles
                             included, in float64 (the A/B mode: `value_all_f64` of bench.py, tests/test_precision_modes.py).  The quad
-                            and lane phases (at most 16 / 6 iterations) run entirely in one precision: single only if the whole phase lies
+                            and lane phases (at most 16 / 6 iterations; four-correspondence problems 24, the rc variant up to 48) run entirely in one precision: single only if the whole phase lies
                             below the bound, float64 otherwise. */
     int32_t sweep_schedule; /* 1 (default): in the first phases of the quad and lane schedules -- where a wavefront runs the maximum number of
                             Jacobi sweeps over its 4 / 64 problems -- the sweeps of an eigen-solve are capped by iteration: 3 for the
