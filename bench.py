@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of results when --gpus > 1")
     ap.add_argument("--force-dist", action="store_true", help="diagnostics: run the RCCL path (process group, packed all_gather) "
                     "even with one rank, to measure / smoke-test it on a 1-GPU box")
+    ap.add_argument("--events-per-step", action="store_true", help="record a HIP event after every launch (per-launch durations) instead of "
+                    "one before the first and one after the last (their span / K)")
     ap.add_argument("--opt", action="append", default=[], help="solver option override name=value (diagnostics)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the steps are issued round-robin on (1 = the contract's "
                     "back-to-back steps; >1 lets independent batches overlap, reported in config)")
@@ -177,6 +179,11 @@ def main():
         Qt = torch.empty((batch, 45), dtype=torch.float64, device=dev)
     mid_events = []  # (event after the assembly) per timed step of the blocked path
 
+    # Hand-over of a finished step from the solve stream to the side stream: a flag in device memory (cvxpnpl_stream_write_value /
+    # cvxpnpl_stream_wait_value), not an event -- an event recorded between two solves costs the solve stream ~17 us per step
+    # (rocprofv3 trace of --force-dist: the next solve kernel starts 17.6 us after the previous step's last kernel, 2 us without)
+    step_flag = torch.zeros(1, dtype=torch.int64, device=dev) if gather else None
+
     def step():
         k = step_no[0] % nstreams
         oset = step_no[0] % nsets
@@ -204,13 +211,16 @@ def main():
             if rc != 0:
                 raise RuntimeError(_lib.last_error())
             if gather:  # north-star config 4: results of every shard on every rank (RCCL over xGMI)
-                solved = torch.cuda.Event()
-                solved.record(streams[k])
+                rc = L.cvxpnpl_stream_write_value(ptr(step_flag), step_no[0], shk)
+                if rc != 0:
+                    raise RuntimeError(_lib.last_error())
         if gather:
             # On the side stream: pack this step's records and all-gather them, while the solve stream goes on with the next
             # batch -- the exchange of step k runs under the solve of step k + 1 and nothing of it sits on the solve stream.
             with torch.cuda.stream(side):
-                side.wait_event(solved)
+                rc = L.cvxpnpl_stream_wait_value(ptr(step_flag), step_no[0], C.c_void_p(side.cuda_stream))
+                if rc != 0:
+                    raise RuntimeError(_lib.last_error())
                 while pending:  # at most one gather in flight (it fills `gathered`)
                     pending.pop()[0].wait()
                 packed = cdist.pack_results(sR, st_, sst)
@@ -242,15 +252,22 @@ def main():
     timing[0] = True
     t0 = time.perf_counter()
     L.cvxpnpl_event_record(ev[0], sh)
+    # One event before the first and one after the last launch: the K launches run back to back and their average duration is the
+    # events' span / K.  (An event after EVERY launch puts a marker between two kernels of the stream: rocprofv3 shows the next
+    # solve kernel starting 6 us after the previous step's last kernel instead of 2 -- 2-3 % of a 10 k step.  --events-per-step
+    # brings them back; the blocked-assembly workloads keep them, they time the assembly kernel alone.)
+    per_step_events = args.events_per_step or blocked or nstreams > 1
     for k in range(args.steps):
         ks = step()
-        L.cvxpnpl_event_record(ev[k + 1], C.c_void_p(streams[ks].cuda_stream))
+        if per_step_events or k == args.steps - 1:
+            L.cvxpnpl_event_record(ev[k + 1], C.c_void_p(streams[ks].cuda_stream))
+    enqueue_s = time.perf_counter() - t0  # host time to enqueue the K steps (close to `elapsed` = the host, not the device, sets the pace)
     barrier()
     elapsed = time.perf_counter() - t0
     timing[0] = False
     ms = C.c_float()
     launch_ms = []
-    if nstreams == 1:
+    if nstreams == 1 and per_step_events:
         for k in range(args.steps):
             L.cvxpnpl_event_elapsed_ms(ev[k], ev[k + 1], C.byref(ms))
             launch_ms.append(ms.value)
@@ -403,7 +420,7 @@ def main():
                                    "ranks": dist.get_world_size(), "devices": min(world, n_dev)} if dist_on else None)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                      "traffic": None, "kernel": _kernel_name(opts.layout, batch, blocked), "mean_launch_ms": 1e3 * mean_launch_s,
-                     "mean_step_ms": float(np.mean(launch_ms)),
+                     "mean_step_ms": float(np.mean(launch_ms)), "host_enqueue_ms_per_step": 1e3 * enqueue_s / args.steps,
                      "algorithmic_bytes_per_problem": algorithmic_bytes(n_p, n_l),
                      "note": ("HBM-bound stage: 40 B read per point against 60 FMAs; the roofline is that of assemble_large_kernel, the solve "
                               "behind it is in mean_step_ms" if blocked else

@@ -241,6 +241,13 @@ int cvxpnpl_disambiguate(int64_t batch, const double *d_R_all, const double *d_t
  * R (9, row-major), t (3), status.  DEVICE pointers; one launch on `stream`.  Returns 0, -1 for bad arguments. */
 int cvxpnpl_pack_results(int64_t batch, const double *d_R, const double *d_t, const int32_t *d_status, double *d_packed, void *stream);
 
+/* Ordering between two streams of one device without an event on the producing stream (bench.py: the solve stream hands a finished
+   step to the stream that packs and all-gathers it): the producer stores `value` to a flag in device memory after everything it has
+   enqueued so far, the consumer's stream does not go on before the flag has reached `value`.  The flag must only grow; it is polled
+   by one sleeping wavefront.  (An event record between two kernels of a stream costs that stream ~17 us here, this ~2 us.) */
+int cvxpnpl_stream_write_value(uint64_t *d_flag, uint64_t value, void *stream);
+int cvxpnpl_stream_wait_value(const uint64_t *d_flag, uint64_t value, void *stream);
+
 /*
  * Consensus scoring of pose hypotheses against one scene (RANSAC on top of the solver: BASELINE config 5;
  * SURVEY.md section 8(f) row 3 -- the reference has no RANSAC, this is the consumer of its minimal solves).
