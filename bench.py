@@ -182,7 +182,8 @@ def main():
     # Hand-over of a finished step from the solve stream to the side stream: a flag in device memory (cvxpnpl_stream_write_value /
     # cvxpnpl_stream_wait_value), not an event -- an event recorded between two solves costs the solve stream ~17 us per step
     # (rocprofv3 trace of --force-dist: the next solve kernel starts 17.6 us after the previous step's last kernel, 2 us without)
-    step_flag = torch.zeros(1, dtype=torch.int64, device=dev) if gather else None
+    step_flag = torch.zeros(2, dtype=torch.int64, device=dev) if gather else None  # [flag, "the wait gave up"]
+    handover = ["flag"]  # or "event": fallback when the two streams turn out to share a hardware queue (checked after the warm-up)
 
     def step():
         k = step_no[0] % nstreams
@@ -211,16 +212,23 @@ def main():
             if rc != 0:
                 raise RuntimeError(_lib.last_error())
             if gather:  # north-star config 4: results of every shard on every rank (RCCL over xGMI)
-                rc = L.cvxpnpl_stream_write_value(ptr(step_flag), step_no[0], shk)
-                if rc != 0:
-                    raise RuntimeError(_lib.last_error())
+                if handover[0] == "flag":
+                    rc = L.cvxpnpl_stream_write_value(ptr(step_flag), step_no[0], shk)
+                    if rc != 0:
+                        raise RuntimeError(_lib.last_error())
+                else:
+                    solved = torch.cuda.Event()
+                    solved.record(streams[k])
         if gather:
             # On the side stream: pack this step's records and all-gather them, while the solve stream goes on with the next
             # batch -- the exchange of step k runs under the solve of step k + 1 and nothing of it sits on the solve stream.
             with torch.cuda.stream(side):
-                rc = L.cvxpnpl_stream_wait_value(ptr(step_flag), step_no[0], C.c_void_p(side.cuda_stream))
-                if rc != 0:
-                    raise RuntimeError(_lib.last_error())
+                if handover[0] == "flag":
+                    rc = L.cvxpnpl_stream_wait_value(ptr(step_flag), step_no[0], C.c_void_p(side.cuda_stream))
+                    if rc != 0:
+                        raise RuntimeError(_lib.last_error())
+                else:
+                    side.wait_event(solved)
                 while pending:  # at most one gather in flight (it fills `gathered`)
                     pending.pop()[0].wait()
                 packed = cdist.pack_results(sR, st_, sst)
@@ -247,6 +255,11 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    if gather and (args.warmup == 0 or int(step_flag[1].item()) != 0):
+        # no warm-up to check the flag hand-over on, or a wait gave up (the solve and the side stream share a hardware queue): events
+        handover[0] = "event"
+        step()
+        barrier()
     # timed region: exactly K steps; HIP events on the launch stream give the per-launch time
     ev = [L.cvxpnpl_event_create() for _ in range(args.steps + 1)]
     timing[0] = True
@@ -417,7 +430,9 @@ def main():
                    "streams": nstreams,
                    "parallelism": f"batch-sharded x{world}" + (", RCCL all_gather of results" if gather else ""),
                    "collective": ({"backend": backend + (" (RCCL)" if backend == "nccl" else " (ranks share a device: diagnostics, not RCCL)"),
-                                   "ranks": dist.get_world_size(), "devices": min(world, n_dev)} if dist_on else None)},
+                                   "ranks": dist.get_world_size(), "devices": min(world, n_dev),
+                                   "handover": ("device flag (cvxpnpl_stream_write_value / _wait_value)" if handover[0] == "flag" else
+                                                "event (fallback)") if gather else None} if dist_on else None)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                      "traffic": None, "kernel": _kernel_name(opts.layout, batch, blocked), "mean_launch_ms": 1e3 * mean_launch_s,
                      "mean_step_ms": float(np.mean(launch_ms)), "host_enqueue_ms_per_step": 1e3 * enqueue_s / args.steps,

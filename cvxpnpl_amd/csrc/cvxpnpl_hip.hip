@@ -601,15 +601,22 @@ int cvxpnpl_recover_multi_device(int64_t batch, const int32_t *d_status, const d
 // that stores `value` to a flag in device memory (release, device scope); the consumer enqueues a one-wavefront kernel that sleeps
 // and polls until the flag has reached it.  (A hipEventRecord between two kernels of a stream costs that stream ~17 us on this
 // stack -- rocprofv3 trace of bench.py --force-dist: 17.6 us between the end of a solve and the start of the next against 2 us
-// without the event; this pair costs it ~2 us.)  The flag must only ever grow.
+// without the event; this pair costs it ~2 us.)  The flag must only ever grow; d_flag points to TWO words, the flag and the wait's
+// "gave up" mark.
 __global__ void stream_write_value_kernel(unsigned long long *flag, unsigned long long value)
 {
     __threadfence();
     __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void stream_wait_value_kernel(const unsigned long long *flag, unsigned long long value)
+__global__ void stream_wait_value_kernel(unsigned long long *flag, unsigned long long value)
 {
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < value) __builtin_amdgcn_s_sleep(32);
+    // bounded: if the two streams share a hardware queue the producer's kernel sits BEHIND this one and the flag can never arrive --
+    // after ~0.25 s of polling the wait gives up and says so in flag[1] (the caller falls back to an event)
+    for (int spin = 0; spin < (1 << 18); ++spin) {
+        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= value) return;
+        __builtin_amdgcn_s_sleep(32);
+    }
+    __hip_atomic_store(flag + 1, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 int cvxpnpl_stream_write_value(uint64_t *d_flag, uint64_t value, void *stream)
@@ -620,10 +627,10 @@ int cvxpnpl_stream_write_value(uint64_t *d_flag, uint64_t value, void *stream)
     return e == hipSuccess ? 0 : set_err("stream_write_value_kernel launch", e);
 }
 
-int cvxpnpl_stream_wait_value(const uint64_t *d_flag, uint64_t value, void *stream)
+int cvxpnpl_stream_wait_value(uint64_t *d_flag, uint64_t value, void *stream)
 {
     if (!d_flag) { snprintf(g_err, sizeof(g_err), "cvxpnpl_stream_wait_value: null flag"); return -1; }
-    hipLaunchKernelGGL(stream_wait_value_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const unsigned long long *)d_flag, (unsigned long long)value);
+    hipLaunchKernelGGL(stream_wait_value_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long *)d_flag, (unsigned long long)value);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : set_err("stream_wait_value_kernel launch", e);
 }

@@ -244,9 +244,12 @@ int cvxpnpl_pack_results(int64_t batch, const double *d_R, const double *d_t, co
 /* Ordering between two streams of one device without an event on the producing stream (bench.py: the solve stream hands a finished
    step to the stream that packs and all-gathers it): the producer stores `value` to a flag in device memory after everything it has
    enqueued so far, the consumer's stream does not go on before the flag has reached `value`.  The flag must only grow; it is polled
-   by one sleeping wavefront.  (An event record between two kernels of a stream costs that stream ~17 us here, this ~2 us.) */
+   by one sleeping wavefront.  (An event record between two kernels of a stream costs that stream ~17 us here, this ~2 us.)
+   d_flag points to TWO 64-bit words, both zero at the start: [0] the flag, [1] set to 1 by a wait that gave up after ~0.25 s -- which
+   happens when the two streams share a hardware queue (the producer's kernel then sits behind the wait): check it after the first
+   use and fall back to an event (bench.py does). */
 int cvxpnpl_stream_write_value(uint64_t *d_flag, uint64_t value, void *stream);
-int cvxpnpl_stream_wait_value(const uint64_t *d_flag, uint64_t value, void *stream);
+int cvxpnpl_stream_wait_value(uint64_t *d_flag, uint64_t value, void *stream);
 
 /*
  * Consensus scoring of pose hypotheses against one scene (RANSAC on top of the solver: BASELINE config 5;
