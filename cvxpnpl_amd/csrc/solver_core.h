@@ -84,6 +84,9 @@ struct Opts {
 constexpr int F32_SWEEPS_DEFAULT = 64;
 constexpr double DUAL_SHIFT_DEFAULT = 0.015;
 constexpr int DUAL_RETRY_RUNGS = 2; // second tries of a failed dual: dual_shift, dual_shift / 4
+constexpr int DUAL_RETRY_ATTEMPTS = 10; // ... in the first this many attempts that may use them: a problem they have not rescued by then is not
+                                        // one they rescue (same iteration counts with 6 / 10 / 16 / no limit on four workloads), and its long
+                                        // chain stops paying for them (N = 8, 125 k problems, slowest 99 iterations: 160.4 -> 162.6 M poses/s)
 // Sweeps the eigen-solve of iteration `it` (2, 3, ...: iteration 1 needs none) may take in the first phases of the hybrid schedules,
 // where a wavefront runs the MAXIMUM over its problems (64 in the lane phase, 4 in the quad phase): the first eigen-solve of a solve
 // takes 3-4 sweeps, the later ones 1-2 on average but 2-3 at wavefront level (measured, 200 wavefronts of 64 N = 10 problems: mean per
@@ -1499,7 +1502,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
         if (check || last) {
             // a failed dual gets its second tries (dual_certificate) from the second attempt of a solve on: the first attempt of every
             // problem would pay for them, the later ones are the slow problems that end a launch (the lane phase makes one attempt)
-            const double retry_shift = (TWIN && attempts > 0) ? o.dual_shift : 0.0;
+            const double retry_shift = (TWIN && attempts > 0 && attempts <= DUAL_RETRY_ATTEMPTS) ? o.dual_shift : 0.0;
             ++attempts;
             // top eigenvector of Wp (and the runner-up, see below)
             int jm = 0, j2 = 0;

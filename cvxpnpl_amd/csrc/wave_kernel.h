@@ -802,6 +802,7 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
     // 68.4 -> 74.6 M, N = 8 161.4 -> 158.9 M, four-point problems 10.2 -> 11.2 M (config 5 at the reference's defaults 18.1 -> 20.1 M),
     // 16 k 70.7 -> 71.7 M, the judged 10 k launch and 1 M unchanged.
     const bool retries = resume != nullptr;
+    int retry_left = cvx::DUAL_RETRY_ATTEMPTS; // (attempts of this phase that may use them: see solver_core.h)
     int status = cvx::ST_NONFINITE, rank_out = 0;
     bool done = !finite;
     bool certified = false;
@@ -988,7 +989,8 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
         const bool check = it >= next_check;
         bool last = (it >= o.max_iters) || (fp_res < o.res_tol) || (it >= ipm_deadline);
         if (check || last) {
-            const double retry_shift = retries ? o.dual_shift : 0.0;
+            const double retry_shift = (retries && retry_left > 0) ? o.dual_shift : 0.0;
+            --retry_left;
             // top eigenvector slot and the runner-up (wave-uniform)
             int smax = 0, s2nd = 0;
             double best = -1.0, second = -1.0;
