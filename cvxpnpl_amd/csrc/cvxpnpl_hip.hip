@@ -76,6 +76,9 @@ __global__ void __launch_bounds__(64) solve_lane_kernel(BatchArgs a, cvx::Opts o
 // line with streamed projections.  512 registers (256 + 256), ~20 spilled, 60 B of scratch per lane; the general core above needs
 // 2 640 B per lane (1 006 spilled registers, 1.1 GB of HBM traffic per 125 k launch) and stays for every other combination of
 // options (float64 sweeps, hand-off point != first attempt).
+// F64SW: every sweep, the product that starts them and the rotation angles in float64 (opts.f32_sweeps_until below the length of the
+// phase) -- cvxl::lane_phase_f64, the positive part streamed row by row instead of stored.
+template <bool F64SW>
 __global__ void __launch_bounds__(64) solve_lane2_kernel(BatchArgs a, cvx::Opts o, int handoff_at, int32_t *qcount, int32_t *qentries, double *ws)
 {
     __shared__ double lds_const[72 * 64];
@@ -84,7 +87,8 @@ __global__ void __launch_bounds__(64) solve_lane2_kernel(BatchArgs a, cvx::Opts 
     cvx::ProblemView pv = cvx::make_view(b, a.n_p, a.p2, a.p3, a.n_l, a.l2, a.l3, a.K, a.K_per_problem);
     if (a.Q45) { pv.Q45 = a.Q45 + b * 45; pv.B27 = a.B27 + b * 27; }
     cvx::Solution sol;
-    cvxl::lane_phase(pv, o, sol, a.Z ? a.Z + b * 55 : nullptr, handoff_at, ws + b * 56, cvx::LdsStore{lds_const + threadIdx.x});
+    if (F64SW) cvxl::lane_phase_f64(pv, o, sol, a.Z ? a.Z + b * 55 : nullptr, handoff_at, ws + b * 56, cvx::LdsStore{lds_const + threadIdx.x});
+    else cvxl::lane_phase(pv, o, sol, a.Z ? a.Z + b * 55 : nullptr, handoff_at, ws + b * 56, cvx::LdsStore{lds_const + threadIdx.x});
     if (sol.status == -1) {
         const int q = atomicAdd(qcount, 1);
         qentries[q] = (int32_t)b;
@@ -370,8 +374,12 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     if (quad_iters > 16 && !rc && !minimal) quad_iters = 16; // the quad phase runs its eigen-solve sweeps in single precision: fine for the first iterations, not for a slow tail (quad_kernel.h)
     const bool lane_general = layout == 10; // experiment / A-B (tools/README.md): the lane schedule with the general scalar core (solve_lane_kernel)
     if (lane_general) layout = CVXPNPL_LAYOUT_LANE;
-    const bool penta = layout == CVXPNPL_LAYOUT_PENTA && !(o.f32_sweeps_until < quad_iters); // (float64 sweeps: built for the sixteen-lane geometry only)
-    if (layout == 9 || penta) layout = CVXPNPL_LAYOUT_QUAD; // experiment (tools/README.md): quad iterations only, 3 waves/SIMD: quad iterations only (solve_quad_kernel<1>)
+    // the REQUEST (five problems per wavefront) and the kernel that serves it are separate: with float64 sweeps the twelve-lane geometry
+    // does not exist and the request runs the sixteen-lane quad kernel -- either way the layout from here on is QUAD (round-3 advisor:
+    // a PENTA request with f32_sweeps_until = 0 used to fall through to the lane branch with a workspace fetched for another stride)
+    const bool penta_req = layout == CVXPNPL_LAYOUT_PENTA;
+    const bool penta = penta_req && !(o.f32_sweeps_until < quad_iters); // (float64 sweeps: built for the sixteen-lane geometry only)
+    if (layout == 9 || penta_req) layout = CVXPNPL_LAYOUT_QUAD; // (9: experiment (tools/README.md): quad iterations only, 3 waves/SIMD, solve_quad_kernel<1>)
     if (layout == CVXPNPL_LAYOUT_QUAD && !(quad_iters >= 1 && o.max_iters > quad_iters)) layout = CVXPNPL_LAYOUT_WAVE;
     if (layout == CVXPNPL_LAYOUT_QUAD && rc && o.f32_sweeps_until < quad_iters) layout = CVXPNPL_LAYOUT_WAVE; // (rc quad kernel: single-precision sweeps only)
     // First certificate attempt (0 = by layout): after 5 iterations 94 % of N = 10 problems certify, after 6 99 %.  In the lane-hybrid
@@ -398,19 +406,22 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
         if (rc) o.rescue_from = 48; // (profiles/r03/rc_tune.txt, 50 k problems: 48 / 64 / 80 / 96 -> 2.92 / 3.10 / 3.46 / 3.63 ms, same outcomes)
     }
     const bool rescue = o.rescue_from > 0 && o.max_iters > o.rescue_from;
-    if (rescue) {
-        WsView wv;
-        const bool hybrid = layout == CVXPNPL_LAYOUT_QUAD || (layout == CVXPNPL_LAYOUT_LANE && o.max_iters > 1);
-        if (!get_workspace(batch, layout == CVXPNPL_LAYOUT_QUAD ? cvxw::RS_FULL : (hybrid ? cvxw::RS_LANE : 0), stream, wv)) return -2;
-        w.rq_count = wv.rq_count; w.rq_entries = wv.rq_entries;
+    // ONE workspace view per solve, fetched after the layout is settled and with the stride of the schedule that will run: a second
+    // fetch with a larger stride may free and reallocate the buffer, and queue pointers taken from the first would dangle
+    int lane_iters = opts ? opts->lane_iters : -1;
+    if (lane_iters <= 0) lane_iters = o.first_check;
+    if (lane_iters > 6) lane_iters = 6; // (see the lane branch below)
+    const bool lane_hybrid = layout == CVXPNPL_LAYOUT_LANE && o.max_iters > lane_iters;
+    WsView wv = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (rescue || layout == CVXPNPL_LAYOUT_QUAD || lane_hybrid) {
+        if (!get_workspace(batch, layout == CVXPNPL_LAYOUT_QUAD ? cvxw::RS_FULL : (lane_hybrid ? cvxw::RS_LANE : 0), stream, wv)) return -2;
     }
+    if (rescue) { w.rq_count = wv.rq_count; w.rq_entries = wv.rq_entries; }
     if (layout == CVXPNPL_LAYOUT_QUAD) {
         // four problems per wavefront for the first quad_iters iterations, survivors resumed one per wavefront
         // (a wavefront finishes its own survivors; only planar scenes, recognised before the first iteration,
         // are queued for the resume kernel behind it -- an empty queue costs that launch a few microseconds.
         // The resume kernel leaves the queue counter at zero for the next launch: no memset per call.)
-        WsView wv;
-        if (!get_workspace(batch, cvxw::RS_FULL, stream, wv)) return -2;
         int32_t *count = wv.count, *entries = wv.entries;
         double *ws = wv.parked;
         const int64_t qgrid = penta ? (batch + 4) / 5 : (batch + 3) / 4;
@@ -431,21 +442,17 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     } else {
         // hand-off point of the hybrid schedule (<= 0: default): right after the first certificate attempt (opts.first_check: 6
         // by default in this layout) -- later is slower (round 1, first attempt at 5: hand-off at 5 / 6 / 7: 110 / 105 / 100 M at 125 k).
-        int lane_iters = opts ? opts->lane_iters : -1;
-        if (lane_iters <= 0) lane_iters = o.first_check;
-        // The lane phase never runs past 6 iterations: from then on the few problems still open are the
+        // (lane_iters: above.)  The lane phase never runs past 6 iterations: from then on the few problems still open are the
         // slow / ambiguous ones (twin candidates, tails), which belong to the wave-per-problem kernel -- one of
         // them would hold 63 idle lanes, so the lane kernel is built without that logic.
-        if (lane_iters > 6) lane_iters = 6;
-        if (o.max_iters > lane_iters) {
+        if (lane_hybrid) {
             // hybrid: lanes for the first lane_iters iterations, survivors resumed one per wavefront
-            WsView wv;
-            if (!get_workspace(batch, cvxw::RS_LANE, stream, wv)) return -2;
             int32_t *count = wv.count, *entries = wv.entries;
             double *ws = wv.parked;
             // the register-budgeted kernel covers the schedule of the defaults (one attempt, right at the hand-off point, single-precision sweeps)
-            const bool budgeted = !lane_general && o.f32_sweeps_until >= lane_iters && o.first_check == lane_iters && lane_iters >= 2 && o.warm_start != 0;
-            if (budgeted) hipLaunchKernelGGL(solve_lane2_kernel, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws);
+            const bool budgeted = !lane_general && o.first_check == lane_iters && lane_iters >= 2 && o.warm_start != 0;
+            if (budgeted && o.f32_sweeps_until >= lane_iters) hipLaunchKernelGGL(solve_lane2_kernel<false>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws);
+            else if (budgeted) hipLaunchKernelGGL(solve_lane2_kernel<true>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws); // float64 sweeps
             else if (o.f32_sweeps_until < lane_iters) hipLaunchKernelGGL(solve_lane_kernel<true>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws); // float64 sweeps (A/B mode)
             else hipLaunchKernelGGL(solve_lane_kernel<false>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws);
             const int64_t rgrid = batch < cvxw::RESUME_GRID_MAX ? batch : cvxw::RESUME_GRID_MAX;
@@ -601,12 +608,14 @@ int cvxpnpl_recover_multi_device(int64_t batch, const int32_t *d_status, const d
 // that stores `value` to a flag in device memory (release, device scope); the consumer enqueues a one-wavefront kernel that sleeps
 // and polls until the flag has reached it.  (A hipEventRecord between two kernels of a stream costs that stream ~17 us on this
 // stack -- rocprofv3 trace of bench.py --force-dist: 17.6 us between the end of a solve and the start of the next against 2 us
-// without the event; this pair costs it ~2 us.)  The flag must only ever grow; d_flag points to TWO words, the flag and the wait's
-// "gave up" mark.
+// without the event; this pair costs it ~2 us.)  The flag only ever grows (the store is an atomic max); d_flag points to TWO words, the
+// flag and the wait's "gave up" mark.  The wait is BOUNDED and therefore fails open: a consumer must read d_flag[1] after every
+// synchronisation at which it consumes what the waits ordered, and discard those results when it is set (include/cvxpnpl_amd.h).
 __global__ void stream_write_value_kernel(unsigned long long *flag, unsigned long long value)
 {
     __threadfence();
-    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // max, not store: write kernels enqueued on different streams may complete out of order and the flag must never move backwards
+    __hip_atomic_fetch_max(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 __global__ void stream_wait_value_kernel(unsigned long long *flag, unsigned long long value)
 {

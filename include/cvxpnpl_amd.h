@@ -54,7 +54,10 @@ enum {
 enum {
     CVXPNPL_VARIANT_FULL = 0, /* the 22 equalities of cvxpnpl.py:387-451 (pnp / pnl / pnpl) */
     CVXPNPL_VARIANT_RC = 1    /* the 16 equalities of benchmarks/toolkit/methods/rc.py:9-64 (the reference's ablation "rc":
-                                 the six row-orthonormality rows are left out); wave-per-problem layout */
+                                 the six row-orthonormality rows are left out).  Layouts: wave-per-problem below 2 560 problems, from
+                                 there the quad schedule (four problems per wavefront, 36 iterations) whose survivors are finished one per
+                                 wavefront, with the interior-point path on the 16 rows behind it (opts.rescue_from: 48); the lane schedule
+                                 is built for the full set only and a LANE / PENTA request runs the quad schedule */
 };
 
 typedef struct {
@@ -243,11 +246,16 @@ int cvxpnpl_pack_results(int64_t batch, const double *d_R, const double *d_t, co
 
 /* Ordering between two streams of one device without an event on the producing stream (bench.py: the solve stream hands a finished
    step to the stream that packs and all-gathers it): the producer stores `value` to a flag in device memory after everything it has
-   enqueued so far, the consumer's stream does not go on before the flag has reached `value`.  The flag must only grow; it is polled
-   by one sleeping wavefront.  (An event record between two kernels of a stream costs that stream ~17 us here, this ~2 us.)
-   d_flag points to TWO 64-bit words, both zero at the start: [0] the flag, [1] set to 1 by a wait that gave up after ~0.25 s -- which
-   happens when the two streams share a hardware queue (the producer's kernel then sits behind the wait): check it after the first
-   use and fall back to an event (bench.py does). */
+   enqueued so far, the consumer's stream does not go on before the flag has reached `value`.  The flag only grows (the store is an
+   atomic max: values written from several streams may land out of order -- with more than one producing stream a wait for step n can
+   then pass on the strength of step n + 1, so use one flag per producing stream); it is polled by one sleeping wavefront.  (An event
+   record between two kernels of a stream costs that stream ~17 us here, this ~2 us.)
+   d_flag points to TWO 64-bit words, both zero at the start: [0] the flag, [1] set to 1 (and never cleared) by a wait that gave up
+   after ~0.25 s of polling -- which happens when the two streams share a hardware queue (the producer's kernel then sits behind the
+   wait), or when the producer simply takes longer than that.  THE WAIT FAILS OPEN: after a give-up the consumer stream goes on, and
+   what it reads may not be finished.  A consumer must therefore read d_flag[1] at EVERY point where it synchronises and uses what the
+   waits ordered -- not only after the first use -- and throw those results away (and fall back to an event) when it is set; bench.py
+   checks after its warm-up and again after its timed region, and repeats a region in which a wait gave up. */
 int cvxpnpl_stream_write_value(uint64_t *d_flag, uint64_t value, void *stream);
 int cvxpnpl_stream_wait_value(uint64_t *d_flag, uint64_t value, void *stream);
 

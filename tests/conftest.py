@@ -11,6 +11,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: CPU tests that take a minute or more (the sanitizer run); still part of -m 'not gpu'")
 
 
 @pytest.fixture(scope="session")

@@ -33,8 +33,12 @@ def build(force=False):
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(_SO)
+        override = os.environ.get("CVXPNPL_HOSTSIM_LIB")  # tools/sanitize.sh: the same source built with ASan + UBSan
+        if override:
+            _lib = C.CDLL(override)
+        else:
+            build()
+            _lib = C.CDLL(_SO)
     return _lib
 
 

@@ -126,7 +126,7 @@ extern "C" void hs_proj_affine_rc(double *E, int homog) { cvx::proj_affine<cvx::
 
 // the first phase of the lane-hybrid schedule on the host: the general scalar core (impl 0: cvx::solve_problem<TWIN = false>, what
 // solve_lane_kernel<DBL> instantiates; dbl != 0: float64 eigen-solve) or the register-budgeted restatement (impl 1: cvxl::lane_phase,
-// what solve_lane2_kernel instantiates).  status -1 = parked: handoff[b][0..54] = W, [55] = iteration count.
+// what solve_lane2_kernel<false> instantiates; impl 2: cvxl::lane_phase_f64, its float64 instantiation).  status -1 = parked: handoff[b][0..54] = W, [55] = iteration count.
 extern "C" int hs_lane_phase(int batch, int n_p, const double *pts_2d, const double *pts_3d, int n_l, const double *line_2d, const double *line_3d,
                              const double *K, int K_per_problem, const cvx::Opts *opts, int iters, int impl, int dbl, double *R_out, double *t_out,
                              int *status, int *its, double *cost, int *sweeps, double *handoff, double *Z_out)
@@ -141,7 +141,8 @@ extern "C" int hs_lane_phase(int batch, int n_p, const double *pts_2d, const dou
         double Z[55];
         double *ho = handoff + (size_t)b * 56;
         for (int i = 0; i < 56; ++i) ho[i] = NAN;
-        if (impl == 1) cvxl::lane_phase(pv, *opts, sol, Z_out ? Z : nullptr, iters, ho, cvx::RegStore());
+        if (impl == 2) cvxl::lane_phase_f64(pv, *opts, sol, Z_out ? Z : nullptr, iters, ho, cvx::RegStore());
+        else if (impl == 1) cvxl::lane_phase(pv, *opts, sol, Z_out ? Z : nullptr, iters, ho, cvx::RegStore());
         else if (dbl) cvx::solve_problem<false, cvx::RegStore, cvx::VAR_FULL, true>(pv, *opts, sol, Z_out ? Z : nullptr, iters, ho);
         else cvx::solve_problem<false, cvx::RegStore, cvx::VAR_FULL, false>(pv, *opts, sol, Z_out ? Z : nullptr, iters, ho);
         for (int i = 0; i < 9; ++i) R_out[(size_t)b * 9 + i] = sol.R[i];

@@ -409,6 +409,44 @@ def test_lane_core_restatement_equals_the_general_core(n_p, n_l, sigma, iters):
     assert (pb["status"] == pc["status"]).all() and (pb["status"] == 3).all() and np.isnan(pb["R"]).all()
 
 
+@pytest.mark.parametrize("n_p,n_l,sigma,iters", [(10, 0, 2.0, 6), (5, 5, 1.0, 6), (4, 0, 1.0, 6), (0, 6, 1.0, 5), (7, 2, 3.0, 4), (10, 0, 2.0, 2), (10, 0, 2.0, 3)])
+def test_lane_core_float64_instantiation_equals_the_general_core(n_p, n_l, sigma, iters):
+    """cvxl::lane_phase_f64 (csrc/lane_core.h: the lane phase with every sweep in float64 -- the reference's precision,
+    cvxpnpl.py:475-513 -- where the positive part is never stored: the update, linear in it, is added into the iterate one eigen
+    column at a time and its projection onto span A_i taken from the difference of the constraint sums, cvxl::pos_update_cols)
+    against the general scalar core with its float64 eigen-solve (cvx::solve_problem<false, ., ., DBL = true>), on the host.  Both
+    are float64 throughout and run the same sweeps, so unlike the single-precision restatement above the parked iterates agree to
+    rounding (the two differ in the ORDER of the update's additions and in where the polish starts from: measured <= 2e-13), the same
+    problems certify, and the sweep counts are identical.  With iters >= 4 the tail_from switch (iteration 3: sc != 1) falls into the
+    column-wise update, with iters = 3 into the last iteration of the phase, with iters = 2 it does not happen."""
+    import hostsim
+    from cvxpnpl_amd import synth
+
+    d = synth.make_pnpl(512, n_p, n_l, sigma, seed=177 + n_p + 3 * n_l + iters)
+    o = hostsim.default_opts(first_check=iters, f32_sweeps_until=0)
+    args = (d["pts_2d"] if n_p else None, d["pts_3d"] if n_p else None, d["line_2d"] if n_l else None, d["line_3d"] if n_l else None, d["K"])
+    a = hostsim.lane_phase(*args, iters, 0, o, dbl=True)
+    b = hostsim.lane_phase(*args, iters, 2, o)
+    assert set(np.unique(a["status"])) <= {-1, 0} and set(np.unique(b["status"])) <= {-1, 0}
+    same = a["status"] == b["status"]
+    assert same.mean() >= 0.998, np.flatnonzero(~same)  # (certificate decisions at the acceptance threshold may differ)
+    cert = same & (a["status"] == 0)
+    park = same & (a["status"] == -1)
+    assert (a["sweeps"] == b["sweeps"]).mean() > 0.99
+    assert (a["iters"][cert] == iters).all() and (b["iters"][cert] == iters).all()
+    if cert.any():
+        assert synth.geodesic(a["R"][cert], b["R"][cert]).max() < 1e-10
+        assert np.abs(a["t"][cert] - b["t"][cert]).max() < 1e-9
+        gap = b["cost"][cert, 0] - b["cost"][cert, 1]
+        assert (gap >= -1e-15).all() and (gap <= 1.0001e-9 + 1e-12 * np.abs(b["cost"][cert, 0])).all()
+    assert park.any()
+    assert (a["handoff"][park, 55] == b["handoff"][park, 55]).all()
+    eq = park & (a["sweeps"] == b["sweeps"])
+    dW = np.abs(a["handoff"][eq, :55] - b["handoff"][eq, :55]).max()
+    print(f"lane core f64: n_p={n_p} n_l={n_l} iters={iters}: {cert.sum()} certified, {park.sum()} parked, status mismatches {(~same).sum()}, max |dW| parked {dW:.2e}")
+    assert dW < 1e-11  # (measured <= 1.6e-13)
+
+
 def test_gram_sums_are_taken_about_a_robust_centre():
     """The Gram sums are shifted about the per-coordinate median of the first three 3D records (cvx::shift_centre; rounds 1-2: about
     the first record -- the round-2 advisor's finding: a far point in first position drags the centre away from the scene).  The

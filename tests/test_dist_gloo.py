@@ -46,6 +46,61 @@ def _worker(rank, world, port, batch, out_dir):
     dist.destroy_process_group()
 
 
+def _cheap_solver(p2, l2, p3, l3, K, **kw):
+    """a closed-form stand-in (a function of each problem's own inputs, so that shards can be compared with the whole): the large
+    ragged test is about the sharding and the exchange, not about the solve"""
+    p2, p3 = np.asarray(p2), np.asarray(p3)
+    n = p3.shape[0]
+    R = np.zeros((n, 3, 3))
+    R[:, 0, :] = p3[:, 0, :]
+    R[:, 1, :2] = p2[:, 0, :]
+    R[:, 2, 2] = p3[:, 0, :].sum(axis=1)
+    t = p3[:, 0, :] * 2.0 - 1.0
+    status = (np.floor(np.abs(p3[:, 0, 0]) * 1e4).astype(np.int64) % 5).astype(np.int32)
+    return {"R": R, "t": t, "status": status}
+
+
+def _big_inputs(batch):
+    rs = np.random.RandomState(11)
+    return rs.random_sample((batch, 1, 2)), rs.random_sample((batch, 1, 3)), np.eye(3)
+
+
+def _worker_big(rank, world, port, batch, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cvxpnpl_amd import dist as cd
+
+    p2, p3, K = _big_inputs(batch)
+    R, t, st = cd.solve_sharded(torch.as_tensor(p2), None, torch.as_tensor(p3), None, K, solver=_cheap_solver)
+    lo, hi = cd.shard_range(batch, rank, world)
+    # every rank holds the WHOLE result; each writes a digest of it and its own span
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), lo=lo, hi=hi, n=R.shape[0], sR=R.numpy().sum(axis=(1, 2))[::997], st=st.numpy()[::997],
+             t_last=t.numpy()[-1], R_first=R.numpy()[0], cs=np.array([R.numpy().sum(), t.numpy().sum(), st.numpy().astype(np.int64).sum()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_gloo_sharding_of_a_ragged_million(tmp_path):
+    """config 4's shape on CPU: 1 000 003 problems over EIGHT ranks (ragged by one: three shards of 125 001, five of 125 000), the padded all-gather of cvxpnpl_amd.dist.gather_results, every rank ends with the whole result, identical to the
+    single-process one.  (A closed-form stand-in for the solve: this is the sharding and the exchange at size.)"""
+    batch, world = 1_000_003, 8
+    mp.spawn(_worker_big, args=(world, _free_port(), batch, str(tmp_path)), nprocs=world, join=True)
+    p2, p3, K = _big_inputs(batch)
+    ref = _cheap_solver(p2, None, p3, None, K)
+    cs = np.array([ref["R"].sum(), ref["t"].sum(), ref["status"].astype(np.int64).sum()])
+    spans = []
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        assert int(got["n"]) == batch
+        assert np.array_equal(got["sR"], ref["R"].sum(axis=(1, 2))[::997]) and np.array_equal(got["st"], ref["status"][::997])
+        assert np.array_equal(got["t_last"], ref["t"][-1]) and np.array_equal(got["R_first"], ref["R"][0])
+        assert np.allclose(got["cs"], cs, rtol=1e-12, atol=0) and got["cs"][2] == cs[2]
+        spans.append((int(got["lo"]), int(got["hi"])))
+    assert spans[0][0] == 0 and spans[-1][1] == batch and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert sorted(b - a for a, b in spans) == [125_000] * 5 + [125_001] * 3
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -111,6 +111,27 @@ def test_f64_mode_against_the_oracle(gpu, orc):  # noqa: F811
         assert g.max() < 1e-6 and np.abs(r["t"][ok] - o["t"][ok, 0]).max() < 1e-6
 
 
+def test_penta_request_with_float64_sweeps_runs_the_quad_geometry(gpu):  # noqa: F811
+    """Round-3 advisor finding: CVXPNPL_LAYOUT_PENTA with f32_sweeps_until = 0 (the twelve-lane geometry has no float64 instantiation)
+    used to fall through to the LANE branch with a workspace fetched for another stride -- the rescue queue's pointers could dangle and
+    problems past rescue_from never finish.  The request now runs the sixteen-lane quad kernel: every problem comes back, and with
+    exactly what a QUAD request returns.  Minimal problems, so that the resume and the interior-point queues are really used; two
+    launch sizes on one stream, the second larger, so that the workspace has to grow between them."""
+    import torch
+
+    from cvxpnpl_amd import synth
+
+    torch.cuda.synchronize()
+    for batch in (300, 3000):
+        d = synth.make_pnpl(batch, 4, 0, 1.0, seed=5 + batch)
+        a = _solve(gpu, d, 4, 0, layout=_ALL_LAYOUTS["penta"], f32_sweeps_until=0, want_Z=True)
+        b = _solve(gpu, d, 4, 0, layout=_ALL_LAYOUTS["quad"], f32_sweeps_until=0, want_Z=True)
+        assert ((a["status"] >= 0) & (a["status"] <= 4)).all() and (a["iters"] >= 1).all()
+        assert (a["iters"] > 32).sum() >= 10  # (some of them did go through the queues)
+        assert (a["status"] == b["status"]).all() and (a["iters"] == b["iters"]).all()
+        assert np.array_equal(np.nan_to_num(a["R"]), np.nan_to_num(b["R"])) and np.array_equal(np.nan_to_num(a["t"]), np.nan_to_num(b["t"]))
+
+
 def test_f32_sweeps_until_is_validated(gpu):  # noqa: F811
     from cvxpnpl_amd import synth
 
