@@ -456,40 +456,52 @@ def main():
     # k), solve, pack, and the 13-double records back to pinned host memory on a third stream.  Never `value`.
     transfer = None
     if nstreams == 1 and world == 1 and not args.no_transfer and not blocked and not dist_on:
-        def pin(x):
-            return torch.from_numpy(np.ascontiguousarray(x)).pin_memory()
-        h_in = [pin(d[k]) if n_ else None for k, n_ in (("pts_2d", n_p), ("pts_3d", n_p), ("line_2d", n_l), ("line_3d", n_l))]
-        d_in = [[torch.empty_like(h, device=dev) if h is not None else None for h in h_in] for _ in range(2)]
+        # one pinned host buffer and one device buffer per input set: [pts_2d | pts_3d | line_2d | line_3d] back to back, so that a step
+        # is ONE H2D copy (the C ABI takes the four device pointers separately: views into the buffer); events are created once
+        parts = [np.ascontiguousarray(d[k]).ravel() for k, n_ in (("pts_2d", n_p), ("pts_3d", n_p), ("line_2d", n_l), ("line_3d", n_l)) if n_]
+        offs = np.cumsum([0] + [x.size for x in parts])
+        h_all = torch.from_numpy(np.concatenate(parts)).pin_memory()
+        d_all = [torch.empty_like(h_all, device=dev) for _ in range(2)]
+
+        def views(buf):
+            out_, j = [], 0
+            for n_ in (n_p, n_p, n_l, n_l):
+                if n_:
+                    out_.append(buf[int(offs[j]):int(offs[j + 1])]); j += 1
+                else:
+                    out_.append(None)
+            return out_
+        d_in = [views(x) for x in d_all]
+        h_in = [h_all]
         d_pk = [torch.empty((batch, cdist.PACK), dtype=torch.float64, device=dev) for _ in range(2)]
         h_pk = [torch.empty((batch, cdist.PACK), dtype=torch.float64).pin_memory() for _ in range(2)]
         s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-        in_ready, solved, out_done = [None, None], [None, None], [None, None]
+        in_ready, solved, out_done = ([torch.cuda.Event(), torch.cuda.Event()] for _ in range(3))
+        seen = [False, False]
 
         def tstep(k):
             b_ = k % 2
             with torch.cuda.stream(s_in):
-                if solved[b_] is not None:
+                if seen[b_]:
                     s_in.wait_event(solved[b_])  # the solve that read this input set
-                for h, dd in zip(h_in, d_in[b_]):
-                    if h is not None:
-                        dd.copy_(h, non_blocking=True)
-                e = torch.cuda.Event(); e.record(s_in); in_ready[b_] = e
-            with torch.cuda.stream(stream):
-                stream.wait_event(in_ready[b_])
-                if out_done[b_] is not None:
-                    stream.wait_event(out_done[b_])  # the records of two steps ago have left d_pk[b_]
-                q2, q3, m2, m3 = d_in[b_]
-                rc = L.cvxpnpl_solve_batch(batch, n_p, ptr(q2), ptr(q3), n_l, ptr(m2), ptr(m3), ptr(K), 0, C.byref(opts), ptr(R), ptr(t), ptr(status),
-                                           ptr(iters), ptr(cost), C.c_void_p(0), ptr(work), sh)
-                if rc == 0:
-                    rc = L.cvxpnpl_pack_results(batch, ptr(R), ptr(t), ptr(status), ptr(d_pk[b_]), sh)
-                if rc != 0:
-                    raise RuntimeError(_lib.last_error())
-                e = torch.cuda.Event(); e.record(stream); solved[b_] = e
+                d_all[b_].copy_(h_all, non_blocking=True)
+                in_ready[b_].record(s_in)
+            stream.wait_event(in_ready[b_])
+            if seen[b_]:
+                stream.wait_event(out_done[b_])  # the records of two steps ago have left d_pk[b_]
+            q2, q3, m2, m3 = d_in[b_]
+            rc = L.cvxpnpl_solve_batch(batch, n_p, ptr(q2), ptr(q3), n_l, ptr(m2), ptr(m3), ptr(K), 0, C.byref(opts), ptr(R), ptr(t), ptr(status),
+                                       ptr(iters), ptr(cost), C.c_void_p(0), ptr(work), sh)
+            if rc == 0:
+                rc = L.cvxpnpl_pack_results(batch, ptr(R), ptr(t), ptr(status), ptr(d_pk[b_]), sh)
+            if rc != 0:
+                raise RuntimeError(_lib.last_error())
+            solved[b_].record(stream)
             with torch.cuda.stream(s_out):
                 s_out.wait_event(solved[b_])
                 h_pk[b_].copy_(d_pk[b_], non_blocking=True)
-                e = torch.cuda.Event(); e.record(s_out); out_done[b_] = e
+                out_done[b_].record(s_out)
+            seen[b_] = True
 
         for k in range(max(2, min(args.warmup, 4))):
             tstep(k)
@@ -502,7 +514,7 @@ def main():
         # the records that arrived on the host are those of the device-resident run (same inputs, same options)
         last = (args.steps - 1) % 2
         same = bool(torch.equal(torch.nan_to_num(h_pk[last]), torch.nan_to_num(cdist.pack_results(R, t, status).cpu())))
-        bytes_in = sum(h.numel() * 8 for h in h_in if h is not None)
+        bytes_in = int(h_all.numel()) * 8
         bytes_out = batch * cdist.PACK * 8
         transfer = {"value": batch * args.steps / dtt, "unit": "poses/s", "ms_per_step": 1e3 * dtt / args.steps,
                     "h2d_bytes_per_step": int(bytes_in), "d2h_bytes_per_step": int(bytes_out),

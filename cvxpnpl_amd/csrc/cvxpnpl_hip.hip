@@ -239,6 +239,21 @@ void launch_rescue(int64_t batch, hipStream_t s, const cvxw::WaveArgs &w, const 
     else hipLaunchKernelGGL(cvxw::rescue_wave_kernel, dim3((unsigned)(count ? 2 * rgrid : rgrid)), dim3(64), 0, s, ra);
 }
 
+#ifdef CVXW_SPLIT_IPM
+// split interior-point path: the rescue queue through cvxw::ipm_wave_kernel into the resume queue (a launch of the resume kernel follows)
+void launch_ipm(int64_t batch, hipStream_t s, const cvxw::WaveArgs &w, const cvx::Opts &o, int32_t *count, int32_t *entries)
+{
+    const int64_t grid = batch < cvxw::IPM_GRID_MAX ? batch : cvxw::IPM_GRID_MAX;
+    cvxw::IpmArgs ia;
+    ia.batch = batch; ia.rho = o.rho; ia.rho_tail = o.rho_tail; ia.tail_from = o.tail_from;
+    ia.rq_count = w.rq_count; ia.rq_entries = w.rq_entries; ia.count = count; ia.entries = entries; ia.ws = w.rq_ws; ia.stride = w.rq_stride;
+    if (o.variant == cvx::VAR_RC) hipLaunchKernelGGL(cvxw::ipm_wave_kernel<cvx::VAR_RC>, dim3((unsigned)grid), dim3(64), 0, s, ia);
+    else hipLaunchKernelGGL(cvxw::ipm_wave_kernel<cvx::VAR_FULL>, dim3((unsigned)grid), dim3(64), 0, s, ia);
+}
+#else
+void launch_ipm(int64_t, hipStream_t, const cvxw::WaveArgs &, const cvx::Opts &, int32_t *, int32_t *) {}
+#endif
+
 int set_err(const char *what, hipError_t e)
 {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
@@ -358,7 +373,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     // The 16-equality variant (benchmarks/toolkit/methods/rc.py): wave-per-problem and, since round 3, the quad schedule (the
     // constraint set is a template parameter of the kernels); the lane kernels and the interior-point path are built for the full set.
     const bool rc = o.variant == cvx::VAR_RC;
-    if (rc && (layout == CVXPNPL_LAYOUT_LANE || layout == CVXPNPL_LAYOUT_PENTA || layout == 9 || layout == 10)) layout = CVXPNPL_LAYOUT_QUAD;
+    if (rc && (layout == CVXPNPL_LAYOUT_LANE || layout == CVXPNPL_LAYOUT_PENTA || layout >= 9)) layout = CVXPNPL_LAYOUT_QUAD;
     cvxw::WaveArgs w;
     w.batch = batch; w.n_p = a.n_p; w.n_l = a.n_l; w.K_per_problem = a.K_per_problem;
     w.p2 = a.p2; w.p3 = a.p3; w.l2 = a.l2; w.l3 = a.l3; w.K = a.K;
@@ -379,7 +394,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     // a PENTA request with f32_sweeps_until = 0 used to fall through to the lane branch with a workspace fetched for another stride)
     const bool penta_req = layout == CVXPNPL_LAYOUT_PENTA;
     const bool penta = penta_req && !(o.f32_sweeps_until < quad_iters); // (float64 sweeps: built for the sixteen-lane geometry only)
-    if (layout == 9 || penta_req) layout = CVXPNPL_LAYOUT_QUAD; // (9: experiment (tools/README.md): quad iterations only, 3 waves/SIMD, solve_quad_kernel<1>)
+    if (layout == 9 || layout == 11 || layout == 12 || layout == 13 || penta_req) layout = CVXPNPL_LAYOUT_QUAD; // (9: experiment (tools/README.md): quad iterations only, 3 waves/SIMD, solve_quad_kernel<1>)
     if (layout == CVXPNPL_LAYOUT_QUAD && !(quad_iters >= 1 && o.max_iters > quad_iters)) layout = CVXPNPL_LAYOUT_WAVE;
     if (layout == CVXPNPL_LAYOUT_QUAD && rc && o.f32_sweeps_until < quad_iters) layout = CVXPNPL_LAYOUT_WAVE; // (rc quad kernel: single-precision sweeps only)
     // First certificate attempt (0 = by layout): after 5 iterations 94 % of N = 10 problems certify, after 6 99 %.  In the lane-hybrid
@@ -412,11 +427,24 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     if (lane_iters <= 0) lane_iters = o.first_check;
     if (lane_iters > 6) lane_iters = 6; // (see the lane branch below)
     const bool lane_hybrid = layout == CVXPNPL_LAYOUT_LANE && o.max_iters > lane_iters;
+    // The interior-point path comes in two builds.  Fused (cvxw::rescue_wave_kernel: the solve compiled into a resume kernel, one launch
+    // behind the first kernel) where it is a safety net -- seven correspondences and more: its queue is empty in nearly every launch and
+    // one more (empty) launch would cost the 10 k-problem step 2 %.  Split (cvxw::ipm_wave_kernel + the plain resume kernel) where
+    // problems really go through it -- at most six correspondences, the 16-equality variant: a fifth of the four-point problems.
+#ifdef CVXW_SPLIT_IPM
+    const bool split = rescue && (rc || (!a.Q45 && a.n_p + a.n_l <= 6));
+#else
+    const bool split = false; // measured (profiles/r04/split_ipm_experiment.txt): the split path loses -- see there and DESIGN.md section 9
+#endif
     WsView wv = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const int ws_stride = layout == CVXPNPL_LAYOUT_QUAD ? cvxw::RS_FULL : ((lane_hybrid || split) ? cvxw::RS_LANE : 0);
     if (rescue || layout == CVXPNPL_LAYOUT_QUAD || lane_hybrid) {
-        if (!get_workspace(batch, layout == CVXPNPL_LAYOUT_QUAD ? cvxw::RS_FULL : (lane_hybrid ? cvxw::RS_LANE : 0), stream, wv)) return -2;
+        if (!get_workspace(batch, ws_stride, stream, wv)) return -2;
     }
+    w.rq_ws = nullptr; w.rq_stride = 0;
     if (rescue) { w.rq_count = wv.rq_count; w.rq_entries = wv.rq_entries; }
+    if (split) { w.rq_ws = wv.parked; w.rq_stride = ws_stride; }
+    const int64_t rgrid_all = batch < cvxw::RESUME_GRID_MAX ? batch : cvxw::RESUME_GRID_MAX;
     if (layout == CVXPNPL_LAYOUT_QUAD) {
         // four problems per wavefront for the first quad_iters iterations, survivors resumed one per wavefront
         // (a wavefront finishes its own survivors; only planar scenes, recognised before the first iteration,
@@ -428,12 +456,22 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
         cvxq::QuadArgs qa;
         qa.a = w; qa.o = o; qa.handoff_at = quad_iters; qa.qcount = count; qa.qentries = entries; qa.ws = ws;
         if (opts && opts->layout == 9) hipLaunchKernelGGL((cvxq::solve_quad_kernel<1, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // experiment
+        else if (opts && opts->layout == 11) hipLaunchKernelGGL((cvxq::solve_quad_kernel<2, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // experiment (round 4)
+        else if (opts && opts->layout == 13) hipLaunchKernelGGL((cvxq::solve_quad_kernel<3, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // experiment (round 4)
+        else if (opts && opts->layout == 12) hipLaunchKernelGGL((cvxq::solve_quad_kernel<2, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // experiment (round 4)
         else if (penta) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 12>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (rc) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 16, false, cvx::VAR_RC>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (o.f32_sweeps_until < quad_iters) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 16, true>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // float64 sweeps (A/B mode)
         else hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         const int64_t rgrid = batch < cvxw::RESUME_GRID_MAX ? batch : cvxw::RESUME_GRID_MAX;
-        if (rescue) launch_rescue(batch, s, w, o, count, entries, ws); // (both queues in one launch)
+        if (split) {
+            // the wavefronts' own slow survivors (rescue queue) through the interior-point kernel into the resume queue, behind the planar
+            // scenes parked there; a parked problem that reaches rescue_from in the resume kernel takes the second round
+            for (int round = 0; round < 2; ++round) {
+                launch_ipm(batch, s, w, o, count, entries);
+                launch_resume(rgrid, s, w, o, count, entries, ws, true);
+            }
+        } else if (rescue) launch_rescue(batch, s, w, o, count, entries, ws); // (both queues in one launch)
         else launch_resume(rgrid, s, w, o, count, entries, ws, true);
     } else if (layout == CVXPNPL_LAYOUT_WAVE) {
         int64_t wgrid = (batch + cvxw::WPB - 1) / cvxw::WPB;
@@ -463,7 +501,10 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
             launch_wave(wgrid, s, w, o);
         }
     }
-    if (rescue && layout != CVXPNPL_LAYOUT_QUAD) launch_rescue(batch, s, w, o);
+    if (split && layout != CVXPNPL_LAYOUT_QUAD) {
+        launch_ipm(batch, s, w, o, wv.count, wv.entries);
+        launch_resume(rgrid_all, s, w, o, wv.count, wv.entries, wv.parked, false);
+    } else if (rescue && layout != CVXPNPL_LAYOUT_QUAD) launch_rescue(batch, s, w, o);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err("solve kernel launch", e);
     return 0;

@@ -29,6 +29,11 @@ constexpr int I_M = 908, I_T1 = 1350, I_T2 = 1450, I_TEST = 1550, I_COL = 2150, 
 constexpr int I_QS = I_T1, I_W = I_M; // hand-over between cvxw::solve_pass and the solve: cost in (64), iterate out (55)
 constexpr int LDS_IPM_END = 2304;
 static_assert(LDS_IPM_END <= LDSW_IPM, "the interior-point solve needs LDSW_IPM doubles per wavefront");
+// Where the solve keeps its matrices (doubles from the start of the wavefront's LDS slice).  Fused: inside cvxw::rescue_wave_kernel, around
+// the first-order solver's state ([684, 908) survives: the translation map and the canonical frame).  Compact: cvxw::ipm_wave_kernel, which
+// runs nothing else -- 1 480 doubles = 11.6 KB per wavefront, so that three wavefronts per SIMD fit the 160 KB of a CU (fused: 18 KB, two).
+struct IpmLayFused { static constexpr int Z = I_Z, S = I_S, SI = I_SI, DZ = I_DZ, DS = I_DS, RC = I_RC, DY = I_DY, RHS = I_RHS, M = I_M, T1 = I_T1, T2 = I_T2, COL = I_COL, TAB = I_TAB; };
+struct IpmLayCompact { static constexpr int Z = 0, S = 100, SI = 200, DZ = 300, DS = 400, RC = 500, DY = 600, RHS = 624, M = 684, T1 = 1126, T2 = 1226, TAB = 1326, COL = 1358, END = 1480; };
 
 struct IpmTab { signed char r[21][3], c[21][3], s[21][3]; signed char ent_con[55], ent_sgn[55]; signed char d1[10], d2[10]; };
 // (rows: cvx::ipm_term<VAR>; ent_con / ent_sgn: the row an off-diagonal entry belongs to and its sign; d1 / d2: the row(s) a
@@ -172,13 +177,14 @@ __device__ __forceinline__ void coop_steps(double *L, const double *Z, const dou
 
 // The solve.  qe: this lane's entry (ei, ej) of the trace-normalised cost (lanes < 55, 0 outside the 9 x 9 block).
 // On exit Z and S (full, symmetric) are at L[I_Z], L[I_S]; returns the iterations, gap = <Z, S>.
-template <int VAR>
-__device__ __noinline__ int coop_ipm(double *L, int lane, double qe, int ei, int ej, double tol, int max_iters, double *gap_out)
+template <int VAR, class LAY>
+__device__ __forceinline__ int coop_ipm_body(double *L, int lane, double qe, int ei, int ej, double tol, int max_iters, double *gap_out)
 {
     constexpr int NR = cvx::ipm_rows(VAR), NSCH = NR * (NR + 1) / 2; // constraint rows; entries of the Schur matrix's lower triangle
     const IpmTab &tab = VAR == cvx::VAR_RC ? kIpmTabRc : kIpmTab;
-    double *Z = L + I_Z, *S = L + I_S, *Si = L + I_SI, *dZ = L + I_DZ, *dS = L + I_DS, *Rc = L + I_RC, *dy = L + I_DY, *rhs = L + I_RHS;
-    double *M = L + I_M, *T1 = L + I_T1, *T2 = L + I_T2;
+    constexpr int I_COL = LAY::COL; // (diagnostic build only)
+    double *Z = L + LAY::Z, *S = L + LAY::S, *Si = L + LAY::SI, *dZ = L + LAY::DZ, *dS = L + LAY::DS, *Rc = L + LAY::RC, *dy = L + LAY::DY, *rhs = L + LAY::RHS;
+    double *M = L + LAY::M, *T1 = L + LAY::T1, *T2 = L + LAY::T2;
     CVXW_SYNC();
     for (int e = lane; e < 100; e += 64) {
         const int i = e / 10, j = e % 10;
@@ -192,7 +198,7 @@ __device__ __noinline__ int coop_ipm(double *L, int lane, double qe, int ei, int
     // loads per Schur entry -- it was most of the solve's time).  The 63 terms, packed r | c << 4 | (s + 1) << 8, go to LDS;
     // rhs: the terms of row `lane`;  dS entries e = lane + 64 r (r < 2): dS[e] = c1 dy[i1] + c2 dy[i2].
     auto pack_term = [&](int i, int k) { return (int)tab.r[i][k] | ((int)tab.c[i][k] << 4) | (((int)tab.s[i][k] + 1) << 8); };
-    int *TI = reinterpret_cast<int *>(L + I_TAB);
+    int *TI = reinterpret_cast<int *>(L + LAY::TAB);
     if (lane < 63) TI[lane] = pack_term(lane / 3, lane % 3);
     int sch_i[4], sch_j[4]; // Schur entries e = lane + 64 r (lower triangle, 231 of them): row and column
 #pragma unroll
@@ -395,6 +401,14 @@ __device__ __noinline__ int coop_ipm(double *L, int lane, double qe, int ei, int
     }
     *gap_out = gap;
     return it;
+}
+
+// inside cvxw::rescue_wave_kernel: a call, not inlined -- merely compiled into the first-order loop of that kernel the solve costs the
+// loop its register allocation
+template <int VAR>
+__device__ __noinline__ int coop_ipm(double *L, int lane, double qe, int ei, int ej, double tol, int max_iters, double *gap_out)
+{
+    return coop_ipm_body<VAR, IpmLayFused>(L, lane, qe, ei, ej, tol, max_iters, gap_out);
 }
 
 } // namespace cvxw

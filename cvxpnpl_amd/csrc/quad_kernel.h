@@ -322,7 +322,10 @@ __device__ __forceinline__ void finish_own(QuadArgsPtr kp, unsigned parked, doub
 #endif
 }
 
-// MODE 0: the schedule described above.  MODE 1 (experiment, tools/phase_a_time.sh): the iterations only -- no
+// MODE 0: the schedule described above.  MODE 2 (experiment, round 4: layouts 11 / 12): the first phase with its certificate attempts, but
+// every survivor is queued for the resume kernel instead of being finished by its own wavefront -- the kernel then holds no
+// wave-per-problem code and can run three wavefronts per SIMD (one round of 3 072 slots for the 2 500 wavefronts of a 10 k launch).
+// MODE 1 (experiment, tools/phase_a_time.sh): the iterations only -- no
 // certificate code is compiled in, every problem is parked after handoff_at iterations -- to measure what the
 // iteration phase costs at the occupancy it gets without the certificate's registers.
 // F64SW: the Jacobi sweeps, G = (W + sigma I) V and the warm-start eigenvectors in float64 (see pair_cs_f64)
@@ -790,7 +793,7 @@ CVXQ_PH(1); /* jacobi */
         }
 CVXQ_PH(2); /* Wp */
         ++it;
-        const bool check = MODE == 0 && it >= next_check;
+        const bool check = MODE != 1 && it >= next_check;
         if (check) {
             // ---- certificate attempt (cvx::solve_sdp, non-twin branch): top eigenvector of Wp
             const double best = grp_max<LPP>(L, gl, gl < 10 ? al : -1.0);
@@ -1101,6 +1104,23 @@ CVXQ_PH(7); /* projection + update */
 #pragma unroll
     for (int g = 0; g < NPW; ++g) pmask |= (unsigned)((pm >> (LPP * g)) & 1ull) << g;
     if (MODE == 1) { if (gvalid && gl == 0) a.status[b] = cvx::ST_UNCERTIFIED; return; }
+    if (MODE == 2) { // every survivor goes to the queue of the resume kernel launched behind this one: no wave-per-problem code in this kernel
+        if (parked && gvalid && gl == 0) {
+            const int q = atomicAdd(qcount, 1);
+            qentries[q] = (int32_t)b;
+        }
+        return;
+    }
+    if (MODE == 3 && (pmask & (pmask - 1))) { // (experiment, layout 13) more than one survivor: this wavefront keeps the first, the others are
+        // queued for the resume kernel behind this launch instead of being finished one after the other here
+        const unsigned keep = pmask & (0u - pmask);
+        const int g = grp < NPW ? grp : 0;
+        if (parked && gvalid && gl == 0 && !((keep >> g) & 1u)) {
+            const int q = atomicAdd(qcount, 1);
+            qentries[q] = (int32_t)b;
+        }
+        pmask = keep;
+    }
     if (pmask) { // wave-uniform
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // every park() acknowledged before the iterate is read back
         CVXW_SYNC();
