@@ -447,6 +447,10 @@ def main():
             rc = L.cvxpnpl_calibration_copy(ptr(src), ptr(dst), nbytes, width, sh)
             if rc != 0:
                 raise RuntimeError(_lib.last_error())
+        if ransac:  # the scoring kernel of the frame, so that the byte counters of the same passes see it too
+            from cvxpnpl_amd.api import score_hypotheses
+            for _ in range(8):
+                score_hypotheses(R, t, K, tt(d["scene_2d"]), tt(d["scene_3d"]), 2.0, status=status, usable=(0, 2))
         torch.cuda.synchronize(dev)
         return None
 
@@ -880,6 +884,7 @@ def _measure_pmc(args):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     solve = {k: v for k, v in res.items() if "solve_" in k or "resume_" in k or "rescue_" in k or "assemble_" in k}
+    extra = {k: v for k, v in res.items() if "score_kernel" in k}  # (reported in by_kernel, not part of a solve step)
     calib = {k: v for k, v in res.items() if "calibration_copy" in k}
     if not solve:
         return None
@@ -901,7 +906,7 @@ def _measure_pmc(args):
     by_kernel = {k: {"fetch_bytes": (sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"])) * 1024 / ff if "FETCH_SIZE" in v else None,
                      "write_bytes": (sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])) * 1024 / wf if "WRITE_SIZE" in v else None,
                      "valu_insts": sum(v["SQ_INSTS_VALU"]) / len(v["SQ_INSTS_VALU"]) if "SQ_INSTS_VALU" in v else None,
-                     "waves": sum(v["SQ_WAVES"]) / len(v["SQ_WAVES"]) if "SQ_WAVES" in v else None} for k, v in solve.items()}
+                     "waves": sum(v["SQ_WAVES"]) / len(v["SQ_WAVES"]) if "SQ_WAVES" in v else None} for k, v in list(solve.items()) + list(extra.items())}
     return {"hbm_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
             "valu_insts_per_launch": per_step("SQ_INSTS_VALU"), "salu_insts_per_launch": per_step("SQ_INSTS_SALU"),
             "lds_insts_per_launch": per_step("SQ_INSTS_LDS"), "waves_per_launch": per_step("SQ_WAVES"), "by_kernel": by_kernel,

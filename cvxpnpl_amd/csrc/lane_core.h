@@ -160,14 +160,16 @@ CVX_HD bool certify_in_place(QV Qs, double *S, const double *vt, double delta, d
 //   * Wp is never stored (pos_update_cols below): the update is linear in Wp and is added into W one COLUMN at a time, so that the
 //     operands of every loop outside the sweeps are W and one column;
 //   * W is parked BY HAND in accumulation registers across the sweeps (cvxl::Bank: "a"-class inline-asm values, one
-//     v_accvgpr_write_b32 / _read_b32 per half), likewise the constraint sums of the update while the columns are added, and W
-//     again while the last positive part is accumulated and while the certificate runs;
+//     v_accvgpr_write_b32 / _read_b32 per half), likewise the constraint sums of the update while the columns are added -- and nowhere
+//     else: parked around the last positive part and around the certificate as well, the allocator spilled the parked values
+//     themselves (796 B, 524 us; without: 468 B, 457 us);
 //   * the last iteration forms Wp column by column into the registers that then hold the dual hint (dr_update_with_hint).
-// Result: 303 spilled registers, 752 B (the loop: ~100 scratch operations per iteration instead of 250; the rest is the last
-// iteration, whose Wp + W + columns are 420 registers again), 583 us.  Measured and NOT kept: the whole idle state in a fixed bank of
-// 210 AGPRs with staged swaps around the sweeps (the allocator then spills the "a"-class values themselves: 2 240-2 504 B, 1 100 us);
-// parking with tied ("+a") operands (whole-kernel live ranges: same effect); the row-ordered two-pass update (1 784 B); walking the
-// update in the order of the equality triples (2 152 B); a dozen -mllvm scheduling / allocation switches (no effect).
+// Result (kernel of the library: tools/resource_table.py): ~240 spilled registers, ~470 B, ~115 scratch operations per iteration
+// instead of 250; 125 k launch 838 -> 457 us (tools/microbench/lane_bench.py; the single-precision kernel: 275 us).  Measured and NOT
+// kept: the whole idle state in a fixed bank of 210 AGPRs with staged swaps around the sweeps (the allocator then spills the "a"-class
+// values themselves: 2 240-2 504 B, 1 100 us); parking with tied ("+a") operands (whole-kernel live ranges: same effect); the
+// row-ordered two-pass update (1 784 B); walking the update in the order of the equality triples (2 152 B); a dozen -mllvm scheduling /
+// allocation switches (no effect).  profiles/r04/lane_f64_variants.txt, lane_bench_2.txt.
 
 // The bank: float64 slots in accumulation registers.  A put defines a fresh "a"-class value, a get reads it: a slot lives from its put
 // to its last get, and the asm statements are volatile so that the moves stay where they are written.  Host build: a plain array.
@@ -363,8 +365,7 @@ CVX_HD void lane_phase_f64(const ProblemView &pv, const Opts &o, Solution &sol, 
     // place of Wp and the iterate the next phase continues from.
     CVXL_MARK("final_update");
     double S[55], vt[10]; // S: Wp first, then the dual hint
-    Bank bf;
-    CVX_UNROLL for (int k = 0; k < 55; ++k) bank_put(bf, k, W[k]);
+
     {
         int jm = 0;
         double best = -1.0;
@@ -385,7 +386,6 @@ CVX_HD void lane_phase_f64(const ProblemView &pv, const Opts &o, Solution &sol, 
             }
         }
     }
-    CVX_UNROLL for (int k = 0; k < 55; ++k) W[k] = bank_get(bf, k);
     if (it == o.tail_from) { // (the switch fell on the last iteration of the phase: rho, irho are the new ones already)
         const double sc = o.rho / o.rho_tail;
         CVX_UNROLL for (int i = 0; i < 55; ++i) W[i] = S[i] + (W[i] - S[i]) * sc;
@@ -394,8 +394,7 @@ CVX_HD void lane_phase_f64(const ProblemView &pv, const Opts &o, Solution &sol, 
     double chk = 0.0;
     CVX_UNROLL for (int i = 0; i < 55; ++i) chk += W[i];
     const bool bad = !(chk == chk);
-    Bank bc;
-    CVX_UNROLL for (int k = 0; k < 55; ++k) bank_put(bc, k, W[k]); // W waits in the bank while the certificate runs
+
     CVXL_MARK("certify");
     double R[9], pobj, zSz;
     const bool certified = certify_in_place(Qs, S, vt, delta, tr, gap_tol, R, pobj, zSz);
@@ -409,7 +408,7 @@ CVX_HD void lane_phase_f64(const ProblemView &pv, const Opts &o, Solution &sol, 
         return;
     }
     if (!certified) {
-        CVX_UNROLL for (int i = 0; i < 55; ++i) handoff[i] = bank_get(bc, i);
+        CVX_UNROLL for (int i = 0; i < 55; ++i) handoff[i] = W[i];
         handoff[55] = (double)it;
         sol.status = -1;
         return;

@@ -9,12 +9,12 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 WORKLOAD_KEY = {"default": "pnp_n10_10k:10000", "quad_24k": "pnp_n10_10k:24000", "quad_16k": "pnp_n10_10k:16000", "hybrid_125k": "pnp_n10_125k:125000",
-                "pnpl_100k": "pnpl_5p5l_100k:100000", "large_n": "pnp_n10000_1k:1000", "minimal_50k": "pnp_n4_50k:50000"}
+                "pnpl_100k": "pnpl_5p5l_100k:100000", "hybrid_125k_f64": "pnp_n10_125k:125000:f64", "pnpl_100k_f64": "pnpl_5p5l_100k:100000:f64", "ransac": "ransac_n4_50k:50000", "large_n": "pnp_n10000_1k:1000", "minimal_50k": "pnp_n4_50k:50000"}
 
 
 def counters(run):
@@ -52,7 +52,7 @@ for run in WORKLOAD_KEY:
     c = counters(run)
     json.dump(c, open(os.path.join(dst, run, "pmc_summary.json"), "w"), indent=1)
     # the kernels of one step; the known-size copies of the same passes calibrate the byte counters (bench.py does the same)
-    step = {k: v for k, v in c.items() if any(t in k for t in ("solve_", "resume_", "rescue_", "assemble_"))}
+    step = {k: v for k, v in c.items() if any(t in k for t in ("solve_", "resume_", "rescue_", "assemble_"))}  # (score_kernel: in pmc_summary.json, not part of a solve step)
     cal = [v for k, v in c.items() if "calibration_copy_kernel<8>" in k]
     nbytes = float(64 << 20)
     ff = cal[0]["FETCH_SIZE"]["mean_per_launch"] * 1024 / nbytes if cal and "FETCH_SIZE" in cal[0] else 1.0

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for one round on the GPU box (run from the repo root):
-#   tools/profile_round.sh r03
+#   tools/profile_round.sh r04
 # Writes gpurun_out/<tag>/ ; `python tools/collect_profiles.py <tag>` (container) then condenses it into
 # profiles/<tag>/ and profiles/pmc_traffic.json.  Counter passes are separate runs with no tracing
 # (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950, MI355X guide).
-tag=${1:-r03}
+tag=${1:-r04}
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/$tag
 rm -rf $out; mkdir -p $out
@@ -22,7 +22,10 @@ prof() { # name, bench args...
 prof default
 prof quad_16k --batch 16000
 prof hybrid_125k --workload pnp_n10_125k
+prof hybrid_125k_f64 --workload pnp_n10_125k --opt f32_sweeps_until=0
 prof pnpl_100k --workload pnpl_5p5l_100k
+prof pnpl_100k_f64 --workload pnpl_5p5l_100k --opt f32_sweeps_until=0
+prof ransac --workload ransac_n4_50k
 prof large_n --workload pnp_n10000_1k
 prof minimal_50k --workload pnp_n4_50k
 cd $root
@@ -34,6 +37,7 @@ python bench.py --workload pnpl_5p5l_100k --no-cpu-baseline > $out/bench_pnpl_10
 python bench.py --workload pnp_n10000_1k --steps 20 > $out/bench_n10000_1k.json 2>/dev/null
 python bench.py --workload pnp_n10_125k --batch 1000000 --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_1m.json 2>/dev/null
 python bench.py --workload pnp_n4_50k --no-cpu-baseline > $out/bench_n4_50k.json 2>/dev/null
+python bench.py --workload ransac_n4_50k --no-cpu-baseline > $out/bench_ransac_n4_50k.json 2>/dev/null
 python bench.py --opt variant=1 --batch 50000 --no-cpu-baseline --pmc off > $out/bench_rc_50k.json 2>/dev/null
 python bench.py --force-dist --steps 20 --warmup 3 --no-cpu-baseline --pmc off > $out/bench_force_dist_1rank_rccl.json 2>/dev/null
 python bench.py --gpus 2 --steps 20 --warmup 3 > $out/bench_2ranks_one_device.json 2>/dev/null
