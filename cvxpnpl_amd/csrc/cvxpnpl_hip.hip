@@ -336,7 +336,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
                  opts->struct_size, sizeof(cvxpnpl_opts_t));
         return -1;
     }
-    if (opts && (opts->max_iters < 1 || opts->f32_sweeps_until < -1 || !(opts->rho > 0) || !(opts->eps > 0) || opts->check_every < 1 || opts->first_check < 0 ||
+    if (opts && (opts->max_iters < 1 || opts->f32_sweeps_until < -1 || opts->f32_sweeps_until > cvx::F32_SWEEPS_DEFAULT || !(opts->rho > 0) || !(opts->eps > 0) || opts->check_every < 1 || opts->first_check < 0 ||
                  (opts->variant != CVXPNPL_VARIANT_FULL && opts->variant != CVXPNPL_VARIANT_RC) || opts->adapt_every < 0 ||
                  (opts->adapt_every > 0 && !(opts->adapt_mu >= 1.0 && opts->adapt_tau > 1.0)) || opts->rescue_from < -1 || !((opts->dual_shift >= 0.0 && opts->dual_shift <= 1.0) || opts->dual_shift == -1.0))) {
         snprintf(g_err, sizeof(g_err), "cvxpnpl: bad options");
@@ -386,7 +386,9 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     if (quad_iters <= 0 && minimal) quad_iters = 24;
     if (quad_iters <= 0) quad_iters = 7; // measured (4 problem sets at 10 k, same box): 5: 0.242 ms, 7: 0.233, 8: 0.235, 10: 0.240; 24 k: 7 = 10 (round 1, second phase as a call: 8-12)
     if (quad_iters > 48) quad_iters = 48; // (rc: up to 48 -- still inside the wave kernel's own single-precision window of 64)
-    if (quad_iters > 16 && !rc && !minimal) quad_iters = 16; // the quad phase runs its eigen-solve sweeps in single precision: fine for the first iterations, not for a slow tail (quad_kernel.h)
+    if (quad_iters > 16 && !rc && !minimal) quad_iters = 16; // (a caller's lane_iters: the quad phase is the YOUNG part of a solve, its slow survivors belong to the wave-per-problem phase.
+    // Minimal problems and the rc variant run 24 / 36-48 iterations here, in single-precision sweeps by default -- inside the window of 64 that
+    // opts.f32_sweeps_until allows and the host experiment covers; device A/B against float64 sweeps: profiles/r04/f32_phase_ab.txt)
     const bool lane_general = layout == 10; // experiment / A-B (tools/README.md): the lane schedule with the general scalar core (solve_lane_kernel)
     if (lane_general) layout = CVXPNPL_LAYOUT_LANE;
     // the REQUEST (five problems per wavefront) and the kernel that serves it are separate: with float64 sweeps the twelve-lane geometry

@@ -107,7 +107,10 @@ typedef struct {
                             iteration count of the solve is below it.  -1 (default): 64.  0: never -- every sweep, rotation angles
                             included, in float64 (the A/B mode: `value_all_f64` of bench.py, tests/test_precision_modes.py).  The quad
                             and lane phases (at most 16 / 6 iterations; four-correspondence problems 24, the rc variant up to 48) run entirely in one precision: single only if the whole phase lies
-                            below the bound, float64 otherwise. */
+                            below the bound, float64 otherwise.  Valid: -1 ... 64 -- the window the experiments cover (host experiment of DESIGN.md section 1.2:
+                            identical iteration histograms and certified counts up to 64, longer tails from 128 on; device A/B of the 24- and
+                            48-iteration single-precision phases of four-point problems and the rc variant: profiles/r04/f32_phase_ab.txt);
+                            larger values are rejected ("bad options"). */
     int32_t sweep_schedule; /* 1 (default): in the first phases of the quad and lane schedules -- where a wavefront runs the maximum number of
                             Jacobi sweeps over its 4 / 64 problems -- the sweeps of an eigen-solve are capped by iteration: 3 for the
                             first one (iteration 2), then 2 (lane phase: 1 from iteration 5 on); jacobi_sweeps still bounds everything.

@@ -138,6 +138,9 @@ def test_f32_sweeps_until_is_validated(gpu):  # noqa: F811
     d = synth.make_pnp(8, 10, sigma=1.0, seed=1)
     with pytest.raises(RuntimeError, match="bad options"):
         _solve(gpu, d, 10, 0, f32_sweeps_until=-2)
+    with pytest.raises(RuntimeError, match="bad options"):
+        _solve(gpu, d, 10, 0, f32_sweeps_until=65)  # (the documented maximum: 64, the window the accuracy experiments cover)
+    assert (_solve(gpu, d, 10, 0, f32_sweeps_until=64)["status"] == 0).all()
     r = _solve(gpu, d, 10, 0, f32_sweeps_until=3)  # in between: phases shorter than the bound stay single, the others float64
     assert (r["status"] == 0).all()
 
