@@ -424,6 +424,33 @@ def score_hypotheses(R, t, K, pts_2d, pts_3d, thresh: float = 2.0, status=None, 
     return (count, mask) if want_mask else count
 
 
+def sample_minimal_sets(pts_2d, pts_3d, n_hyp: int, k: int = 4, seed: int = 0, want_idx: bool = False):
+    """k distinct correspondences of the scene per hypothesis, drawn uniformly and gathered into the inputs of a minimal solve
+    (cvxpnpl_sample_minimal_sets: one HIP launch; counter-based Philox stream, reproducible per (seed, hypothesis)).
+
+    pts_2d [M,2], pts_3d [M,3] device tensors (or anything torch.as_tensor takes).  Returns (p2 [H,k,2], p3 [H,k,3]) or, with want_idx,
+    (p2, p3, idx [H,k] int32)."""
+    _require_gpu()
+    L = _lib.lib()
+    dev = pts_3d.device if isinstance(pts_3d, torch.Tensor) and pts_3d.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    x = _as_dev(pts_2d, dev, (2,))
+    X = _as_dev(pts_3d, dev, (3,))
+    if x.dim() != 2 or X.dim() != 2 or x.shape[0] != X.shape[0]:
+        raise ValueError("expected pts_2d [M,2], pts_3d [M,3]")
+    M, H = int(X.shape[0]), int(n_hyp)
+    if not (1 <= k <= 8) or M < k or H < 0:
+        raise ValueError(f"k must be 1..8 and at most the number of correspondences (k={k}, M={M})")
+    with torch.cuda.device(dev):
+        p2 = torch.empty((H, k, 2), dtype=torch.float64, device=dev)
+        p3 = torch.empty((H, k, 3), dtype=torch.float64, device=dev)
+        idx = torch.empty((H, k), dtype=torch.int32, device=dev) if want_idx else None
+        rc = L.cvxpnpl_sample_minimal_sets(H, M, _ptr(x), _ptr(X), int(k), int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(idx), _ptr(p2), _ptr(p3),
+                                           C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"cvxpnpl_sample_minimal_sets failed ({rc}): {_lib.last_error()}")
+    return (p2, p3, idx) if want_idx else (p2, p3)
+
+
 def _translation_map(p2, l2, p3, l3, Kn):
     Bt, Qt = assemble_batch(p2, l2, p3, l3, Kn)
     return Bt[0].cpu().numpy(), Qt[0].cpu().numpy()

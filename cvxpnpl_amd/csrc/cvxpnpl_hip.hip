@@ -719,6 +719,23 @@ int cvxpnpl_score_hypotheses(int64_t n_hyp, const double *d_R, const double *d_t
     return 0;
 }
 
+int cvxpnpl_sample_minimal_sets(int64_t n_hyp, int32_t n_corr, const double *d_scene_2d, const double *d_scene_3d, int32_t k, uint64_t seed,
+                                int32_t *d_idx, double *d_pts_2d, double *d_pts_3d, void *stream)
+{
+    if (n_hyp < 0 || k < 1 || k > cvxs::SAMPLE_KMAX || n_corr < k || !d_scene_2d || !d_scene_3d || !d_pts_2d || !d_pts_3d) {
+        snprintf(g_err, sizeof(g_err), "cvxpnpl_sample_minimal_sets: bad arguments (n_hyp=%lld n_corr=%d k=%d)", (long long)n_hyp, n_corr, k);
+        return -1;
+    }
+    if (n_hyp == 0) return 0;
+    const int64_t grid = (n_hyp + 255) / 256;
+    if (grid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl_sample_minimal_sets: too many hypotheses for one launch"); return -1; }
+    cvxs::SampleArgs a;
+    a.n_hyp = n_hyp; a.n_corr = n_corr; a.k = k; a.seed = seed; a.s2 = d_scene_2d; a.s3 = d_scene_3d; a.idx = d_idx; a.p2 = d_pts_2d; a.p3 = d_pts_3d;
+    hipLaunchKernelGGL(cvxs::sample_sets_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : set_err("sample_sets_kernel launch", e);
+}
+
 size_t cvxpnpl_workspace_bytes(int64_t max_batch) { return max_batch > 0 ? hybrid_ws_bytes(max_batch) : 0; }
 
 int cvxpnpl_set_workspace(void *d_workspace, size_t bytes, void *stream)

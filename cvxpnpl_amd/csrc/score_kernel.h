@@ -86,4 +86,65 @@ __global__ void __launch_bounds__(SCORE_BLOCK) score_kernel(ScoreArgs a)
     if (live) a.count[h] = cnt;
 }
 
+// Minimal sets for the hypotheses of a RANSAC frame: K distinct correspondences of the scene per hypothesis, drawn uniformly (partial
+// Fisher-Yates on a counter-based stream: Philox4x32-10 keyed by the seed with counter (hypothesis, 0xFFFFFFFE, draw) -- the generator of
+// synth_kernel.h), and gathered straight into the [n_hyp][K][2] / [n_hyp][K][3] inputs of the solve.  One lane per hypothesis; the draw
+// j picks r = j + floor(u (M - j)) and maps it through the swaps made so far (K <= 8: the swap list lives in registers).
+constexpr int SAMPLE_KMAX = 8;
+struct SampleArgs {
+    int64_t n_hyp;
+    int32_t n_corr, k;
+    uint64_t seed;
+    const double *s2, *s3; // scene [n_corr][2], [n_corr][3]
+    int32_t *idx;          // [n_hyp][k] (optional)
+    double *p2, *p3;       // [n_hyp][k][2], [n_hyp][k][3]
+};
+__host__ __device__ inline void sample_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t *out)
+{
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__global__ void __launch_bounds__(256) sample_sets_kernel(SampleArgs a)
+{
+    const int64_t h = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (h >= a.n_hyp) return;
+    int pos[SAMPLE_KMAX], val[SAMPLE_KMAX]; // positions already swapped and what sits there now
+    int pick[SAMPLE_KMAX];
+    const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < SAMPLE_KMAX; ++j) {
+        if (j >= a.k) break;
+        if ((j & 3) == 0) sample_philox((uint32_t)h, (uint32_t)((uint64_t)h >> 32), 0xFFFFFFFEu, (uint32_t)(j >> 2), k0, k1, w);
+        const uint32_t span = (uint32_t)(a.n_corr - j);
+        const int r = j + (int)(((uint64_t)w[j & 3] * span) >> 32); // uniform on j .. n_corr - 1 (bias < 2^-32 n_corr)
+        // value at position r and at position j under the swaps so far
+        int vr = r, vj = j;
+#pragma unroll
+        for (int m = 0; m < SAMPLE_KMAX; ++m) {
+            if (m >= j) break;
+            vr = pos[m] == r ? val[m] : vr;
+            vj = pos[m] == j ? val[m] : vj;
+        }
+        pick[j] = vr;
+        pos[j] = r; val[j] = vj; // position r now holds what position j held (position j is never looked at again)
+#pragma unroll
+        for (int m = 0; m < SAMPLE_KMAX; ++m) { // a later entry for the same position overrides an earlier one: drop the earlier
+            if (m >= j) break;
+            if (pos[m] == r) pos[m] = -1;
+        }
+    }
+    for (int j = 0; j < a.k; ++j) {
+        const int c = pick[j];
+        if (a.idx) a.idx[h * a.k + j] = c;
+        a.p2[(h * a.k + j) * 2] = a.s2[c * 2]; a.p2[(h * a.k + j) * 2 + 1] = a.s2[c * 2 + 1];
+        a.p3[(h * a.k + j) * 3] = a.s3[c * 3]; a.p3[(h * a.k + j) * 3 + 1] = a.s3[c * 3 + 1]; a.p3[(h * a.k + j) * 3 + 2] = a.s3[c * 3 + 2];
+    }
+}
+
 } // namespace cvxs

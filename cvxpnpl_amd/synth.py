@@ -146,6 +146,25 @@ def _u53(a, b):
     return ((a >> np.uint64(5)).astype(np.float64) * 67108864.0 + (b >> np.uint64(6)).astype(np.float64)) / 9007199254740992.0
 
 
+def philox_minimal_sets(n_hyp, n_corr, k=4, seed=0):
+    """numpy restatement of cvxpnpl_sample_minimal_sets (score_kernel.h: partial Fisher-Yates on the Philox stream with counter
+    (hypothesis, 0xFFFFFFFE, draw / 4)): idx [n_hyp, k] -- the checker of the device sampler."""
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    h = np.arange(n_hyp, dtype=np.uint64)
+    idx = np.zeros((n_hyp, k), dtype=np.int64)
+    perm = np.tile(np.arange(n_corr, dtype=np.int64), (n_hyp, 1))
+    rows = np.arange(n_hyp)
+    w = None
+    for j in range(k):
+        if j % 4 == 0:
+            c = np.stack([h & np.uint64(0xFFFFFFFF), h >> np.uint64(32), np.full(n_hyp, 0xFFFFFFFE, np.uint64), np.full(n_hyp, j // 4, np.uint64)], axis=-1)
+            w = _philox4x32(c, k0, k1)
+        r = j + ((w[j % 4] * np.uint64(n_corr - j)) >> np.uint64(32)).astype(np.int64)
+        idx[:, j] = perm[rows, r]
+        perm[rows, r] = perm[rows, j]
+    return idx
+
+
 def philox_pnpl(batch, n_p, n_l, sigma=0.0, seed=42, K=K_KINECT):
     """numpy restatement of cvxpnpl_synth_batch (same counters, same arithmetic up to libm rounding): the checker of
     the device generator."""

@@ -277,6 +277,17 @@ int cvxpnpl_score_hypotheses(int64_t n_hyp, const double *d_R, const double *d_t
                              int32_t *d_count, uint8_t *d_mask, void *stream);
 
 /*
+ * Minimal sets for the hypotheses of a RANSAC frame (same row of SURVEY.md section 8(f) as the scoring above; no reference counterpart):
+ * for every hypothesis k (1 ... 8) DISTINCT correspondences of the scene d_scene_2d [n_corr][2], d_scene_3d [n_corr][3], uniformly at
+ * random (partial Fisher-Yates on a counter-based stream, Philox4x32-10 keyed by `seed` with counter (hypothesis, draw): every hypothesis
+ * is drawn independently and reproducibly), gathered into d_pts_2d [n_hyp][k][2], d_pts_3d [n_hyp][k][3] -- the inputs of
+ * cvxpnpl_solve_batch(n_hyp, k, ...) -- and, if d_idx is not NULL, their indices into d_idx [n_hyp][k].  DEVICE pointers, one launch.
+ * Returns 0, -1 for bad arguments (k > 8, n_corr < k), -2 HIP error.
+ */
+int cvxpnpl_sample_minimal_sets(int64_t n_hyp, int32_t n_corr, const double *d_scene_2d, const double *d_scene_3d, int32_t k, uint64_t seed,
+                                int32_t *d_idx, double *d_pts_2d, double *d_pts_3d, void *stream);
+
+/*
  * Scratch of the lane / quad schedules (queue of parked problems + their iterates).  By default the library
  * keeps one grow-only hipMalloc allocation per (device, stream).  A caller that wants the memory under its own
  * allocator (e.g. torch's caching allocator) registers a DEVICE buffer of at least

@@ -95,6 +95,9 @@ def test_bad_arguments_are_rejected_without_gpu(L):
     assert rc == -1 and b"cvxpnpl_pack_results: bad arguments" in L.cvxpnpl_last_error()
     rc = L.cvxpnpl_score_hypotheses(8, None, None, None, 5, None, 10, None, None, 2.0, None, None, None)
     assert rc == -1 and b"cvxpnpl_score_hypotheses: bad arguments" in L.cvxpnpl_last_error()
+    for n_corr, k in ((100, 9), (3, 4), (100, 0)):  # more than 8 per set, fewer correspondences than a set, empty sets
+        rc = L.cvxpnpl_sample_minimal_sets(16, n_corr, C.c_void_p(8), C.c_void_p(8), k, 1, None, C.c_void_p(8), C.c_void_p(8), None)
+        assert rc == -1 and b"cvxpnpl_sample_minimal_sets: bad arguments" in L.cvxpnpl_last_error()
 
 
 def test_product_fails_loudly_without_gpu():

@@ -127,3 +127,45 @@ def test_device_metrics_and_disambiguation_match_numpy(gpu):
     picked = n_poses > 0
     picked[11] = picked[11] and (where[11] % max(n_poses[11], 1)) != 0
     assert (i0[picked] == (where % np.maximum(n_poses, 1))[picked]).all()
+
+
+def test_minimal_set_sampler_restatement_is_a_uniform_draw_without_replacement():
+    """cvxpnpl_amd.synth.philox_minimal_sets (the numpy twin of cvxpnpl_sample_minimal_sets): k distinct indices per hypothesis, every
+    correspondence equally likely in every position, reproducible, different seeds differ"""
+    from cvxpnpl_amd import synth
+
+    idx = synth.philox_minimal_sets(40000, 25, 4, seed=11)
+    assert idx.min() == 0 and idx.max() == 24
+    s = np.sort(idx, axis=1)
+    assert (s[:, 1:] != s[:, :-1]).all()
+    for j in range(4):  # 1 600 expected per cell, sigma 39: 6 sigma
+        cnt = np.bincount(idx[:, j], minlength=25)
+        assert np.abs(cnt - 1600).max() < 240, cnt
+    # pairs: every unordered pair of the 300 equally likely (6 per draw x 40 000 / 300 = 800 expected)
+    pc = np.zeros((25, 25), int)
+    for a in range(4):
+        for b in range(a + 1, 4):
+            np.add.at(pc, (np.minimum(idx[:, a], idx[:, b]), np.maximum(idx[:, a], idx[:, b])), 1)
+    pu = pc[np.triu_indices(25, 1)]
+    assert np.abs(pu - 800).max() < 170, (pu.min(), pu.max())
+    assert np.array_equal(idx, synth.philox_minimal_sets(40000, 25, 4, seed=11)) and not np.array_equal(idx[:100], synth.philox_minimal_sets(100, 25, 4, seed=12))
+    assert np.array_equal(np.sort(synth.philox_minimal_sets(50, 8, 8, seed=3), axis=1), np.tile(np.arange(8), (50, 1)))  # k = n_corr: a permutation
+
+
+@pytest.mark.gpu
+def test_device_minimal_set_sampler_matches_numpy_restatement(gpu):
+    """cvxpnpl_sample_minimal_sets: the same indices as the numpy twin, the gathered correspondences are the scene's"""
+    import torch
+
+    import cvxpnpl_amd as ca
+    from cvxpnpl_amd import synth
+
+    rs = np.random.RandomState(5)
+    for n_corr, k, H, seed in ((100, 4, 50000, 7), (9, 6, 1000, 2**40 + 3), (8, 8, 257, 0), (5, 1, 64, 9)):
+        x, X = rs.random_sample((n_corr, 2)), rs.random_sample((n_corr, 3))
+        p2, p3, idx = ca.sample_minimal_sets(torch.as_tensor(x, device=gpu), torch.as_tensor(X, device=gpu), H, k, seed, want_idx=True)
+        idx = idx.cpu().numpy()
+        assert np.array_equal(idx, synth.philox_minimal_sets(H, n_corr, k, seed))
+        assert np.array_equal(p2.cpu().numpy(), x[idx]) and np.array_equal(p3.cpu().numpy(), X[idx])
+    with pytest.raises(ValueError):
+        ca.sample_minimal_sets(torch.zeros((3, 2), device=gpu), torch.zeros((3, 3), device=gpu), 10, 4)
