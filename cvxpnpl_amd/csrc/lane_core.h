@@ -222,8 +222,8 @@ CVX_HD void constraint_sums(const double *W, double *m, double *rs, double *cs, 
 // ONE column --, and take R0 of what was added from the DIFFERENCE of the constraint sums after and before (they are linear).
 // Nothing of the size of Wp is ever formed; rounding differs from the stored form by a few ulp of |W| (tests/hostsim: parked
 // iterates agree with the general core to 1e-13).  COLS: a callable col(c, g) that yields column c (lam'_c v_c) in g[0..9].
-template <class QV, class COLS>
-CVX_HD void pos_update_cols(double *W, const double *n2, double sigma, COLS col, QV Qs, double irho, double alpha, double sc)
+template <class QV, class COLS, class N2T>
+CVX_HD void pos_update_cols(double *W, const N2T *n2, double sigma, COLS col, QV Qs, double irho, double alpha, double sc)
 {
     CVX_UNROLL for (int i = 0; i < 55; ++i) W[i] *= sc;
     dr_update_affine_part(W, Qs, irho, alpha);
@@ -237,8 +237,9 @@ CVX_HD void pos_update_cols(double *W, const double *n2, double sigma, COLS col,
 #endif
     const double a = 1.0 - sc + alpha * sc, b = alpha * (1.0 + sc);
     CVX_UNROLL for (int c = 0; c < 10; ++c) {
-        const double lam = sqrt_fast(n2[c]) - sigma;
-        const double wc = lam > 0 ? a * lam * rcp(n2[c]) : 0.0; // a (lam'_c - sigma)_+ / lam'_c^2  (cvx::eig_pospart)
+        const double n2c = (double)n2[c];
+        const double lam = sqrt_fast(n2c) - sigma;
+        const double wc = lam > 0 ? a * lam * rcp(n2c) : 0.0; // a (lam'_c - sigma)_+ / lam'_c^2  (cvx::eig_pospart)
         double g[10];
         col(c, g);
         CVX_UNROLL for (int i = 0; i < 10; ++i) {
