@@ -458,9 +458,11 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
         cvxq::QuadArgs qa;
         qa.a = w; qa.o = o; qa.handoff_at = quad_iters; qa.qcount = count; qa.qentries = entries; qa.ws = ws;
         if (opts && opts->layout == 9) hipLaunchKernelGGL((cvxq::solve_quad_kernel<1, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // experiment
-        else if (opts && opts->layout == 11) hipLaunchKernelGGL((cvxq::solve_quad_kernel<2, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // experiment (round 4)
-        else if (opts && opts->layout == 13) hipLaunchKernelGGL((cvxq::solve_quad_kernel<3, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // experiment (round 4)
-        else if (opts && opts->layout == 12) hipLaunchKernelGGL((cvxq::solve_quad_kernel<2, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // experiment (round 4)
+#ifdef CVXQ_TAIL_EXPERIMENTS // round 4, profiles/r04/tail_experiments.txt: survivors queued (layouts 11: three, 12: two wavefronts per SIMD), extras queued (13)
+        else if (opts && opts->layout == 11) hipLaunchKernelGGL((cvxq::solve_quad_kernel<2, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
+        else if (opts && opts->layout == 13) hipLaunchKernelGGL((cvxq::solve_quad_kernel<3, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
+        else if (opts && opts->layout == 12) hipLaunchKernelGGL((cvxq::solve_quad_kernel<2, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
+#endif
         else if (penta) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 12>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (rc) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 16, false, cvx::VAR_RC>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (o.f32_sweeps_until < quad_iters) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 16, true>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // float64 sweeps (A/B mode)
