@@ -145,12 +145,14 @@ def _fuzz_shapes(n):
     return out
 
 
-@pytest.mark.parametrize("layout", [1, 2, 3])
-def test_fuzz_parity_slice(gpu, orc, layout):
+@pytest.mark.parametrize("layout,f64", [(1, False), (2, False), (3, False), (1, True)])
+def test_fuzz_parity_slice(gpu, orc, layout, f64):
     """16 random shapes x 128 problems (tools/fuzz_parity.py's first 16 configurations) in every layout: no certified
-    pose beyond 1e-6 of the oracle's converged single-pose solve."""
+    pose beyond 1e-6 of the oracle's converged single-pose solve.  (1, True): the lane layout with every sweep in float64 --
+    cvxl::lane_phase_f64, round 4; the whole campaign in that mode: profiles/r04/fuzz_parity_f64.txt, 65 536 solves.)"""
     from cvxpnpl_amd import synth
 
+    extra = {"f32_sweeps_until": 0} if f64 else {}
     tot = cmp_ = 0
     for c, n_p, n_l, sigma in _fuzz_shapes(16):
         d = synth.make_pnpl(128, n_p, n_l, sigma, seed=5000 + c)
@@ -159,7 +161,7 @@ def test_fuzz_parity_slice(gpu, orc, layout):
             _ORC[key] = orc.pnpl_batch(d["pts_2d"] if n_p else None, d["line_2d"] if n_l else None, d["pts_3d"] if n_p else None,
                                        d["line_3d"] if n_l else None, d["K"], eps=1e-11, max_iters=200000)
         o = _ORC[key]
-        r = _solve(gpu, d, n_p, n_l, layout=layout)
+        r = _solve(gpu, d, n_p, n_l, layout=layout, **extra)
         ok = (r["status"] == 0) & (o["n_poses"] == 1)
         geo = synth.geodesic(r["R"], o["R"][:, 0])
         te = np.linalg.norm(r["t"] - o["t"][:, 0], axis=1) / np.linalg.norm(o["t"][:, 0], axis=1)

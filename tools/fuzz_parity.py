@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity campaign: HIP path (every layout) vs the CPU oracle over many problem shapes and noise
-levels (GPU box, repo root):  python tools/fuzz_parity.py [n_configs] [problems_per_config]
+levels (GPU box, repo root):  python tools/fuzz_parity.py [n_configs] [problems_per_config] [f64]
+("f64": every layout with opts.f32_sweeps_until = 0 -- the float64 instantiations, round 4: cvxl::lane_phase_f64 among them)
 One line per configuration + a summary; certified GPU poses are compared with the oracle's converged solve
 (rotation geodesic, relative translation).  Diagnostics / evidence tool (uses the oracle: not product code)."""
 import os
@@ -18,6 +19,7 @@ from cvxpnpl_amd import synth  # noqa: E402
 
 ncfg = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 nprob = int(sys.argv[2]) if len(sys.argv) > 2 else 192
+extra = {"f32_sweeps_until": 0} if "f64" in sys.argv[3:] else {}
 rs = np.random.RandomState(2026)
 dev = torch.device("cuda:0")
 worst = {"rot": 0.0, "t": 0.0}
@@ -37,7 +39,7 @@ for c in range(ncfg):
     line = f"cfg {c:2d} {kind:4s} n_p {n_p:2d} n_l {n_l:2d} sigma {sigma:3.1f}:"
     for name, layout in (("wave", 2), ("quad", 3), ("lane", 1), ("penta", 4)):
         r = ca.pnpl_batch(tt(d["pts_2d"]) if n_p else None, tt(d["line_2d"]) if n_l else None, tt(d["pts_3d"]) if n_p else None,
-                          tt(d["line_3d"]) if n_l else None, tt(d["K"]), layout=layout)
+                          tt(d["line_3d"]) if n_l else None, tt(d["K"]), layout=layout, **extra)
         st = r.status.cpu().numpy()
         R, t = r.R.cpu().numpy(), r.t.cpu().numpy()
         ok = (st == 0) & (o["n_poses"] == 1)
@@ -49,6 +51,6 @@ for c in range(ncfg):
         tot += nprob; cert += int((st == 0).sum()); cmp_ += int(ok.sum()); mism += bad
         line += f" {name} cert {np.mean(st == 0):.3f} rot {g:.1e} t {e:.1e}" + (f" MISMATCH {bad}" if bad else "")
     print(line, flush=True)
-print(f"summary: {ncfg} configurations x {nprob} problems x 4 layouts = {tot} solves, {cert} certified, {cmp_} compared with a "
+print(("float64 sweeps (f32_sweeps_until = 0) -- " if extra else "") + f"summary: {ncfg} configurations x {nprob} problems x 4 layouts = {tot} solves, {cert} certified, {cmp_} compared with a "
       f"converged single-pose oracle solve, {mism} beyond 1e-6; worst rotation {worst['rot']:.2e} rad, worst relative "
       f"translation {worst['t']:.2e}; {time.time() - t0:.0f} s")
