@@ -46,19 +46,23 @@ def ransac_pnp(pts_2d, pts_3d, K, n_hyp: int = 4096, thresh: float = 2.0, max_it
     x4, X4 = sample_minimal_sets(x, X, n_hyp, 4, seed)
     res = pnp_batch(x4, X4, Kd, eps=eps, max_iters=max_iters)
     score = score_hypotheses(res.R, res.t, Kd, x, X, thresh, status=res.status, usable=(0, 2))
-    best = int(torch.argmax(score))
-    R, t = res.R[best], res.t[best]
+    # From here on the host needs a few integers (the size of the consensus set is the N of the refit, a host argument of the solve); each
+    # read-back is a synchronisation of ~40 us, so they are batched: ONE per stage instead of one per number.
+    best = torch.argmax(score).reshape(1)                      # stays on the device
+    R, t = res.R.index_select(0, best)[0], res.t.index_select(0, best)[0]
     mask = reprojection_inliers(R[None], t[None], Kd, X, x, thresh)[0]
-    final_status = int(res.status[best])
-    if refit and int(mask.sum()) >= 4:
+    head = torch.stack([res.status.index_select(0, best)[0].to(torch.int64), mask.sum(), (res.status == 0).sum()]).cpu()   # sync 1
+    final_status, n_inl, n_cert = int(head[0]), int(head[1]), int(head[2])
+    if refit and n_inl >= 4:
         for _ in range(2):  # refit on the consensus set, re-evaluate it once
-            fit = pnp_batch(x[mask][None], X[mask][None], Kd, eps=1e-9, max_iters=2500)
-            if int(fit.status[0]) not in (0, 2):
+            sel = torch.argsort((~mask).to(torch.int8), stable=True)[:n_inl]   # the inliers' indices, in order, without a host round trip
+            fit = pnp_batch(x.index_select(0, sel)[None], X.index_select(0, sel)[None], Kd, eps=1e-9, max_iters=2500)
+            new = reprojection_inliers(fit.R, fit.t, Kd, X, x, thresh)[0]
+            st_new = torch.stack([fit.status[0].to(torch.int64), new.sum()]).cpu()   # sync 2 (3)
+            if int(st_new[0]) not in (0, 2):
                 break
-            R, t, final_status = fit.R[0], fit.t[0], int(fit.status[0])
-            new = reprojection_inliers(R[None], t[None], Kd, X, x, thresh)[0]
-            if int(new.sum()) <= int(mask.sum()):
+            R, t, final_status = fit.R[0], fit.t[0], int(st_new[0])
+            if int(st_new[1]) <= n_inl:
                 break
-            mask = new
-    return {"R": R, "t": t, "inliers": mask, "n_inliers": int(mask.sum()), "status": final_status,
-            "n_certified": int((res.status == 0).sum()), "n_hyp": n_hyp}
+            mask, n_inl = new, int(st_new[1])
+    return {"R": R, "t": t, "inliers": mask, "n_inliers": n_inl, "status": final_status, "n_certified": n_cert, "n_hyp": n_hyp}
