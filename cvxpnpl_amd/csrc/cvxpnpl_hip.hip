@@ -367,13 +367,18 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     // the lane-hybrid schedule would park nearly all of them for the one-problem-per-wavefront phase.  They stay four per wavefront
     // for 24 iterations instead (first attempt after 7), like the rc variant: 50 k problems 11.2 -> 12.4 M poses/s (lane_iters 16 / 24 /
     // 32 / 40: 12.1 / 12.4 / 11.7-12.2 / 12.3; five correspondences and more: the lane-hybrid schedule wins, 36.8 against 33.6 M at N = 5).
-    const bool minimal = !a.Q45 && a.n_p + a.n_l <= 4 && o.variant == cvx::VAR_FULL && layout == CVXPNPL_LAYOUT_AUTO && batch >= 2560 && o.max_iters > 24 &&
+#ifdef CVXQ_TAIL_EXPERIMENTS
+    const bool layout_auto_like = layout == CVXPNPL_LAYOUT_AUTO || layout == 11 || layout == 12 || layout == 13;
+#else
+    const bool layout_auto_like = layout == CVXPNPL_LAYOUT_AUTO;
+#endif
+    const bool minimal = !a.Q45 && a.n_p + a.n_l <= 4 && o.variant == cvx::VAR_FULL && layout_auto_like && batch >= 2560 && o.max_iters > 24 &&
                          (!opts || opts->lane_iters <= 0);
     if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 2560 ? CVXPNPL_LAYOUT_WAVE : ((batch < 20000 || minimal) ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
     // The 16-equality variant (benchmarks/toolkit/methods/rc.py): wave-per-problem and, since round 3, the quad schedule (the
     // constraint set is a template parameter of the kernels); the lane kernels and the interior-point path are built for the full set.
     const bool rc = o.variant == cvx::VAR_RC;
-    if (rc && (layout == CVXPNPL_LAYOUT_LANE || layout == CVXPNPL_LAYOUT_PENTA || layout >= 9)) layout = CVXPNPL_LAYOUT_QUAD;
+    if (rc && (layout == CVXPNPL_LAYOUT_LANE || layout == CVXPNPL_LAYOUT_PENTA || layout == 9 || layout == 10 || layout == 12 || layout == 13)) layout = CVXPNPL_LAYOUT_QUAD;
     cvxw::WaveArgs w;
     w.batch = batch; w.n_p = a.n_p; w.n_l = a.n_l; w.K_per_problem = a.K_per_problem;
     w.p2 = a.p2; w.p3 = a.p3; w.l2 = a.l2; w.l3 = a.l3; w.K = a.K;
@@ -459,10 +464,18 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
         qa.a = w; qa.o = o; qa.handoff_at = quad_iters; qa.qcount = count; qa.qentries = entries; qa.ws = ws;
         if (opts && opts->layout == 9) hipLaunchKernelGGL((cvxq::solve_quad_kernel<1, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // experiment
 #ifdef CVXQ_TAIL_EXPERIMENTS // round 4, profiles/r04/tail_experiments.txt: survivors queued (layouts 11: three, 12: two wavefronts per SIMD), extras queued (13)
+        else if (opts && opts->layout == 11 && rc) hipLaunchKernelGGL((cvxq::solve_quad_kernel<2, 3, 16, false, cvx::VAR_RC>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (opts && opts->layout == 11) hipLaunchKernelGGL((cvxq::solve_quad_kernel<2, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (opts && opts->layout == 13) hipLaunchKernelGGL((cvxq::solve_quad_kernel<3, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (opts && opts->layout == 12) hipLaunchKernelGGL((cvxq::solve_quad_kernel<2, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
 #endif
+        else if (minimal && !(o.f32_sweeps_until < quad_iters))
+            // Four-correspondence problems: every survivor of the 24-iteration first phase goes to the queue of the launch behind this one
+            // instead of being finished by its own wavefront -- 59 % of these wavefronts end with survivors, most of which are headed for
+            // the interior-point path anyway, and without the wave-per-problem code the kernel runs three wavefronts per SIMD (168 registers).
+            // Measured (profiles/r04/quad_mode2_minimal.txt): 50 k four-point problems 12.4 -> 13.1 M poses/s, config 5 19.8 -> 21.3 M
+            // hypotheses/s; the same schedule LOSES on the N = 10 launches, whose few survivors then start late (tail_experiments.txt).
+            hipLaunchKernelGGL((cvxq::solve_quad_kernel<2, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (penta) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 12>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (rc) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 16, false, cvx::VAR_RC>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (o.f32_sweeps_until < quad_iters) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 16, true>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // float64 sweeps (A/B mode)
