@@ -372,8 +372,12 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
 #else
     const bool layout_auto_like = layout == CVXPNPL_LAYOUT_AUTO;
 #endif
+#ifdef CVXQ_TAIL_EXPERIMENTS // (tuning builds: opts.lane_iters sets the length of the first phase of four-point problems)
+    const bool minimal = !a.Q45 && a.n_p + a.n_l <= 4 && o.variant == cvx::VAR_FULL && layout_auto_like && batch >= 2560 && o.max_iters > 24;
+#else
     const bool minimal = !a.Q45 && a.n_p + a.n_l <= 4 && o.variant == cvx::VAR_FULL && layout_auto_like && batch >= 2560 && o.max_iters > 24 &&
                          (!opts || opts->lane_iters <= 0);
+#endif
     if (layout == CVXPNPL_LAYOUT_AUTO) layout = batch < 2560 ? CVXPNPL_LAYOUT_WAVE : ((batch < 20000 || minimal) ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_LANE);
     // The 16-equality variant (benchmarks/toolkit/methods/rc.py): wave-per-problem and, since round 3, the quad schedule (the
     // constraint set is a template parameter of the kernels); the lane kernels and the interior-point path are built for the full set.
@@ -409,7 +413,12 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     // extra iteration: 125 k problems 157 -> 164 M poses/s, PnPL 100 k 116 -> 126 M.  The quad and wave layouts keep 5 (quad with 6, launch
     // time relative to 5 over 4 problem sets per size: 3 k 0.93, 5 k 1.07, 8 k 1.02, 10 k 0.98, 12 k 1.07, 16 k 1.03, 20 k 1.02, 24 k 0.97;
     // wave: -12 % at 2 k).
-    if (o.first_check <= 0) o.first_check = rc ? 11 : (minimal ? 7 : (layout == CVXPNPL_LAYOUT_LANE ? 6 : 5)); // (rc: nothing certifies before ~10 iterations; 5 ... 15 within 3 %)
+    // Four-correspondence problems in the schedule that queues its survivors (below): an attempt costs the whole wavefront two to three
+    // iterations' worth -- at three wavefronts per SIMD the certificate's code is the part that spills -- and these problems need 14-20
+    // iterations on average: first attempt after 17 (profiles/r04/minimal_tune*.txt, 50 k problems / config 5, M per second: first attempt
+    // after 7: 13.0 / 21.3, 9: 13.5 / 22.4, 13: 14.5 / 23.5, 17: 14.9 / 24.0, 21: 14.5 / 23.9; every third iteration instead of every second: same).
+    const bool minimal_queued = minimal && layout == CVXPNPL_LAYOUT_QUAD && !(o.f32_sweeps_until < quad_iters);
+    if (o.first_check <= 0) o.first_check = rc ? 11 : (minimal_queued ? 17 : (minimal ? 7 : (layout == CVXPNPL_LAYOUT_LANE ? 6 : 5))); // (rc: nothing certifies before ~10 iterations; 5 ... 15 within 3 %)
     // interior-point path for the problems still open after rescue_from iterations (ipm_wave.h): its queue lives in the workspace
     // -1 (default): by problem size.  Slow convergence is a property of minimal and near-minimal configurations
     // (profiles/r02/remaining_iters.jsonl, 100 k problems each, first-order iterations only: with N = 4 / 5 / 6 / 7 correspondences
@@ -469,12 +478,12 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
         else if (opts && opts->layout == 13) hipLaunchKernelGGL((cvxq::solve_quad_kernel<3, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (opts && opts->layout == 12) hipLaunchKernelGGL((cvxq::solve_quad_kernel<2, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
 #endif
-        else if (minimal && !(o.f32_sweeps_until < quad_iters))
+        else if (minimal_queued)
             // Four-correspondence problems: every survivor of the 24-iteration first phase goes to the queue of the launch behind this one
             // instead of being finished by its own wavefront -- 59 % of these wavefronts end with survivors, most of which are headed for
             // the interior-point path anyway, and without the wave-per-problem code the kernel runs three wavefronts per SIMD (168 registers).
             // Measured (profiles/r04/quad_mode2_minimal.txt): 50 k four-point problems 12.4 -> 13.1 M poses/s, config 5 19.8 -> 21.3 M
-            // hypotheses/s; the same schedule LOSES on the N = 10 launches, whose few survivors then start late (tail_experiments.txt).
+            // hypotheses/s (with the first attempt after 17 iterations, above: 14.9 / 24.0 M); the same schedule LOSES on the N = 10 launches, whose few survivors then start late (tail_experiments.txt).
             hipLaunchKernelGGL((cvxq::solve_quad_kernel<2, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (penta) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 12>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (rc) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 16, false, cvx::VAR_RC>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
