@@ -418,7 +418,8 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     // iterations on average: first attempt after 17 (profiles/r04/minimal_tune*.txt, 50 k problems / config 5, M per second: first attempt
     // after 7: 13.0 / 21.3, 9: 13.5 / 22.4, 13: 14.5 / 23.5, 17: 14.9 / 24.0, 21: 14.5 / 23.9; every third iteration instead of every second: same).
     const bool minimal_queued = minimal && layout == CVXPNPL_LAYOUT_QUAD && !(o.f32_sweeps_until < quad_iters);
-    if (o.first_check <= 0) o.first_check = rc ? 11 : (minimal_queued ? 17 : (minimal ? 7 : (layout == CVXPNPL_LAYOUT_LANE ? 6 : 5))); // (rc: nothing certifies before ~10 iterations; 5 ... 15 within 3 %)
+    // (rc in the quad schedule: 19 instead of 11 -- profiles/r04/rc_tune_r04.txt: 50 k problems 18.3 -> 19.3 M poses/s, 10 k 9.0 -> 9.3 M; the same effect, smaller)
+    if (o.first_check <= 0) o.first_check = rc ? (layout == CVXPNPL_LAYOUT_QUAD ? 19 : 11) : (minimal_queued ? 17 : (minimal ? 7 : (layout == CVXPNPL_LAYOUT_LANE ? 6 : 5))); // (rc: nothing certifies before ~10 iterations; 5 ... 15 within 3 %)
     // interior-point path for the problems still open after rescue_from iterations (ipm_wave.h): its queue lives in the workspace
     // -1 (default): by problem size.  Slow convergence is a property of minimal and near-minimal configurations
     // (profiles/r02/remaining_iters.jsonl, 100 k problems each, first-order iterations only: with N = 4 / 5 / 6 / 7 correspondences

@@ -69,7 +69,7 @@ typedef struct {
     int32_t max_iters; /* iteration cap; reference `max_iters` (cvxpnpl.py:528), default 2500 */
     double rho;        /* ADMM penalty on the trace-normalised cost, default 0.1 */
     double alpha;      /* over-relaxation, default 1.4 */
-    int32_t first_check; /* first certification attempt after this many iterations; 0 (default): 5, or 6 in the lane-hybrid layout; the rc variant 11;
+    int32_t first_check; /* first certification attempt after this many iterations; 0 (default): 5, or 6 in the lane-hybrid layout; the rc variant 11 (19 in the quad schedule);
                            launches of >= 2 560 four-correspondence problems 17 (their first phase queues its survivors, an attempt there costs the
                            whole wavefront two to three iterations; profiles/r04/minimal_tune*.txt) */
     int32_t check_every; /* then every this many (widening ~sqrt(iteration) from iteration 10 on), default 2 */
