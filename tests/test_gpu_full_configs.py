@@ -129,6 +129,38 @@ def test_config5_50k_minimal_hypotheses_tolerance_sweep(gpu):
     assert prev_cert[(1e-9, 2500)] >= prev_cert[(1e-9, 100)] >= prev_cert[(1e-9, 20)]  # a larger budget certifies more
 
 
+@pytest.mark.parametrize("kw", [{}, {"want_Z": True}, {"max_iters": 28}, {"max_iters": 30, "want_Z": True}, {"first_check": 5}, {"f32_sweeps_until": 0},
+                                {"rescue_from": 0}, {"eps": 1e-6, "max_iters": 100}])
+def test_four_point_schedule_equals_the_wave_layout(gpu, kw):  # noqa: F811
+    """Launches of >= 2 560 four-correspondence problems run a schedule of their own (round 4: the quad phase queues every survivor for the
+    launch behind it, first attempt after 17 iterations).  Same problems through the wave-per-problem layout: same certified set up to the
+    attempts that sit at the acceptance threshold, the same pose wherever both certify, uncertified exits follow the same rules -- under
+    budgets that end inside the first phase's queue hand-over (max_iters 28 / 30: no interior-point path), explicit attempt schedules,
+    float64 sweeps (the schedule that finishes its own survivors), the path switched off, Z requested."""
+    from cvxpnpl_amd import synth
+
+    d = synth.make_ransac(6000, n_corr=60, outlier_frac=0.3, sigma=0.5, seed=7)
+    a = _solve(gpu, d, 4, 0, **kw)                 # AUTO: the four-point schedule
+    b = _solve(gpu, d, 4, 0, layout=2, **kw)       # one wavefront per problem
+    assert np.isin(a["status"], (0, 1, 2, 4)).all() and (a["iters"] >= 1).all()
+    both = (a["status"] == 0) & (b["status"] == 0)
+    # (a budget that ends a few iterations after the first phase: WHEN the attempts are made decides what is certified by then -- measured 0.991)
+    lo = 0.985 if kw.get("max_iters", 2500) <= 32 else 0.995
+    assert (a["status"] == 0).sum() >= lo * (b["status"] == 0).sum() and both.sum() >= (lo - 0.005) * (b["status"] == 0).sum(), ((a["status"] == 0).sum(), (b["status"] == 0).sum())
+    g = synth.geodesic(a["R"][both], b["R"][both])
+    assert g.max() < 1e-7 and np.abs(a["t"][both] - b["t"][both]).max() < 1e-7, (g.max(),)   # (minimal problems: flat costs, the polish leaves 1e-9)
+    c = a["cost"][a["status"] == 0]
+    eps = kw.get("eps", 1e-9)
+    assert ((c[:, 0] - c[:, 1]) >= -1e-15).all() and ((c[:, 0] - c[:, 1]) <= 1.0001 * eps + 1e-12 * np.abs(c[:, 0])).all()
+    assert np.isfinite(a["R"]).all()
+    if kw.get("want_Z"):
+        cert = a["status"] == 0
+        z = np.concatenate([np.transpose(a["R"][cert], (0, 2, 1)).reshape(-1, 9), np.ones((cert.sum(), 1))], axis=1)
+        iu = np.triu_indices(10)
+        assert np.abs(a["Z"][cert] - (z[:, :, None] * z[:, None, :])[:, iu[0], iu[1]]).max() < 1e-12   # a certified Z is z z^T
+        assert np.isfinite(a["Z"]).all()
+
+
 # --------------------------------------------------------------------------------------------- campaign slices
 def _fuzz_shapes(n):
     """the shape / noise generator of tools/fuzz_parity.py (same RandomState stream)"""
