@@ -365,7 +365,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     // one per wavefront in both cases.
     // Minimal problems (four correspondences; the cost seam does not say): 18 iterations on average and a fifth of them beyond 32 --
     // the lane-hybrid schedule would park nearly all of them for the one-problem-per-wavefront phase.  They stay four per wavefront
-    // for 24 iterations instead (first attempt after 7), like the rc variant: 50 k problems 11.2 -> 12.4 M poses/s (lane_iters 16 / 24 /
+    // for 24 iterations instead (first attempt after 7 -- round 4: 17, and their survivors are queued: minimal_queued below), like the rc variant: 50 k problems 11.2 -> 12.4 M poses/s (lane_iters 16 / 24 /
     // 32 / 40: 12.1 / 12.4 / 11.7-12.2 / 12.3; five correspondences and more: the lane-hybrid schedule wins, 36.8 against 33.6 M at N = 5).
 #ifdef CVXQ_TAIL_EXPERIMENTS
     const bool layout_auto_like = layout == CVXPNPL_LAYOUT_AUTO || layout == 11 || layout == 12 || layout == 13;
