@@ -21,7 +21,7 @@ def main(path):
     names = subprocess.run(["c++filt"] + [r["name"] for r in rows], capture_output=True, text=True).stdout.splitlines()
     print(f"{'kernel':72s} {'VGPR':>5s} {'AGPR':>5s} {'scratch':>8s} {'occ':>4s} {'sgprS':>6s} {'vgprS':>6s} {'LDS':>7s}")
     for r, d in zip(rows, names):
-        d = re.sub(r"\(.*", "", d).replace("void ", "")
+        d = re.sub(r"\(.*", "", d.replace("(anonymous namespace)::", "")).replace("void ", "")
         print(f"{d[:72]:72s} {r.get('VGPRs'):>5s} {r.get('AGPRs'):>5s} {r.get('ScratchSize [bytes/lane]'):>8s} {r.get('Occupancy [waves/SIMD]'):>4s} "
               f"{r.get('SGPRs Spill'):>6s} {r.get('VGPRs Spill'):>6s} {r.get('LDS Size [bytes/block]'):>7s}")
 
