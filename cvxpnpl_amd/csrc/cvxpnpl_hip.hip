@@ -361,6 +361,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     // * from there four problems per wavefront (one per DPP row): 2.5x fewer instructions per problem;
     // * from 20 000 the lane-hybrid schedule (64 problems per wavefront for the first lane_iters iterations): fewest instructions
     //   per problem, but it needs ~20 k problems to give every SIMD a wavefront (round 2, general scalar core: crossover 24 576).
+    //   (with every sweep in float64 the crossover is the same: quad / lane 16 k: 58.0 / 57.0, 20 k: 59.0 / 59.6, 24 k: 62.2 / 75.9, 32 k: 67.9 / 99.0 -- profiles/r04/f64_layout_crossover.txt)
     // The problems the quad phase leaves open are finished by the same wavefront, those of the lane phase by a second kernel,
     // one per wavefront in both cases.
     // Minimal problems (four correspondences; the cost seam does not say): 18 iterations on average and a fifth of them beyond 32 --
