@@ -14,7 +14,9 @@ Extra objects in the JSON line:
   cpu_baseline  this solver's algorithm built for the host (tests/hostsim: solver_core.h under g++, OpenMP over
                 problems), timed on a bounded sample of the same workload on this box's host cores (rank 0,
                 N=1 only); cpu_baseline_reference_path_port: the CPU oracle (restated reference path) likewise.
-  value_all_f64 the same K steps with opts.f32_sweeps_until = 0 (every Jacobi sweep in float64).
+  value / dtype the timed region runs at the REFERENCE's precision: float64 throughout (opts.f32_sweeps_until = 0; the reference is
+                float64 end to end, cvxpnpl.py:475-513).  value_mixed: the same K steps with the library's default, which runs the
+                Jacobi sweeps of young solves on single-precision columns (--precision mixed makes that the timed region instead).
 """
 import argparse
 import ctypes as C
@@ -76,7 +78,12 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="points per problem of --workload pnp_scal")
     ap.add_argument("--blocked", default="auto", choices=("auto", "0", "1"), help="assembly path: 1 = cvxpnpl_assemble_large_batch + cost-seam solve, "
                     "0 = in-kernel assembly, auto = the product's rule (cvxpnpl_amd.api.use_blocked_assembly: 768 correspondence records, 384 in batches of >= 2 048)")
-    ap.add_argument("--no-f64-ab", action="store_true", help="skip the extra all-float64 measurement (value_all_f64)")
+    ap.add_argument("--precision", default="f64", choices=("f64", "mixed"), help="arithmetic of the timed region: f64 = every Jacobi sweep in float64 "
+                    "like the reference (opts.f32_sweeps_until = 0; the headline), mixed = the library's default (single-precision sweeps while a "
+                    "solve is young); the other mode is measured beside it (value_mixed / value_all_f64)")
+    ap.add_argument("--no-f64-ab", action="store_true", help="skip the extra measurement in the other precision mode (value_mixed / value_all_f64)")
+    ap.add_argument("--collective", default="all_gather", choices=("all_gather", "gather"), help="--gpus N exchange: all_gather = every rank ends with "
+                    "every shard's records (north-star config 4 as written); gather = rank 0 only (one consumer: 1/N of the bytes per rank)")
     ap.add_argument("--sigma", type=float, default=None, help="pixel noise of the synthetic problems")
     ap.add_argument("--seed", type=int, default=42, help="seed of the synthetic problems (diagnostics: the default is the judged workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -170,6 +177,8 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         over[k] = float(v) if k in ("eps", "rho", "alpha", "res_tol", "jacobi_tol", "rho_tail", "adapt_mu", "adapt_tau", "stall_lam", "stall_res", "stall_drop", "dual_shift") else int(v)
+    if args.precision == "f64" and "f32_sweeps_until" not in over:
+        over["f32_sweeps_until"] = 0  # the reference's precision (cvxpnpl.py:475-513: numpy float64 throughout) is the headline
     opts = _lib.default_opts(layout=args.layout, **over)
     ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else C.c_void_p(0)  # noqa: E731
     stream = torch.cuda.current_stream(dev)
@@ -181,7 +190,13 @@ def main():
     # records per rank in the exchange: the largest shard (strong scaling: shards differ by at most one problem and the short ones are
     # padded with zero records, so that the exchange stays ONE all_gather_into_tensor of equal slices)
     batch_pad = batch if args.scaling == "weak" else -(-total_job // world)
-    gathered = torch.empty((world * batch_pad, cdist.PACK), dtype=torch.float64, device=dev) if gather else None
+    to_root = args.collective == "gather"   # one consumer: only rank 0 receives (1/N of the all_gather's bytes per rank; none at all for N - 1 ranks)
+    # TWO receive buffers: the exchange of step k may still be in flight when that of step k + 1 is enqueued (a step of config 4 is
+    # ~0.45 ms, 91 MB arrive per rank per step: the exchange is of the order of the solve and must not be serialised behind its predecessor)
+    gathered2 = [torch.empty((world * batch_pad, cdist.PACK), dtype=torch.float64, device=dev) if (gather and (rank == 0 or not to_root)) else None
+                 for _ in range(2)]
+    gathered = gathered2[0]
+    MAX_IN_FLIGHT = 2
     gather_on = [True]  # (switched off for the second timed region that prices the exchange: config.collective.gather_ms_per_step)
     nstreams = max(1, args.streams)
     streams = [stream] + [torch.cuda.Stream(dev) for _ in range(nstreams - 1)]
@@ -257,15 +272,19 @@ def main():
                         raise RuntimeError(_lib.last_error())
                 else:
                     side.wait_event(solved)
-                while pending:  # at most one gather in flight (it fills `gathered`)
-                    pending.pop()[0].wait()
+                while len(pending) >= MAX_IN_FLIGHT:  # at most two exchanges in flight (one receive buffer each)
+                    pending.pop(0)[0].wait()
                 packed = cdist.pack_results(sR, st_, sst)
                 if batch_pad != batch:
                     packed = torch.cat([packed, packed.new_zeros((batch_pad - batch, cdist.PACK))])
                 ev_p = torch.cuda.Event()
                 ev_p.record(side)
                 packed_done[oset] = ev_p
-                _, work_h = cdist.gather_results(packed, world * batch_pad, out=gathered, async_op=True)
+                gbuf = gathered2[step_no[0] % 2]
+                if to_root:
+                    work_h = cdist.gather_to_root(packed, world * batch_pad, out=gbuf, async_op=True)[1]
+                else:
+                    _, work_h = cdist.gather_results(packed, world * batch_pad, out=gbuf, async_op=True)
                 pending.append((work_h, packed))
         return k
 
@@ -282,11 +301,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def any_rank_gave_up():
+        """has a flag wait given up on ANY rank?  The decision to switch the hand-over mode / to repeat a timed region changes the sequence of
+        collectives a rank issues, so it must be the same on every rank: all_reduce(MAX) of the local flag (round-4 advisor)"""
+        f = step_flag[1:2].to(torch.float64)
+        if dist_on:
+            dist.all_reduce(f, op=dist.ReduceOp.MAX)
+        return int(f.item()) != 0
+
     for _ in range(args.warmup):
         step()
     barrier()
-    if gather and (args.warmup == 0 or int(step_flag[1].item()) != 0):
-        # no warm-up to check the flag hand-over on, or a wait gave up (the solve and the side stream share a hardware queue): events
+    if gather and (args.warmup == 0 or any_rank_gave_up()):
+        # no warm-up to check the flag hand-over on, or a wait gave up on some rank (the solve and the side stream share a hardware
+        # queue): events, on every rank
         handover[0] = "event"
         step()
         barrier()
@@ -307,9 +335,9 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         timing[0] = False
-        if gather and handover[0] == "flag" and int(step_flag[1].item()) != 0:
-            # a wait gave up inside the timed region: the side stream may have packed records the solve had not finished -- the run is
-            # invalid; repeat it with event hand-over
+        if gather and handover[0] == "flag" and any_rank_gave_up():
+            # a wait gave up inside the timed region of some rank: its side stream may have packed records the solve had not finished --
+            # the run is invalid; every rank repeats it with event hand-over (the decision is collective: see any_rank_gave_up)
             handover[0] = "event"
             handover_retries += 1
             for e in ev + mid_events:
@@ -395,7 +423,10 @@ def main():
                 pk = cdist.pack_results(sR, st_, sst)
                 if batch_pad != batch:
                     pk = torch.cat([pk, pk.new_zeros((batch_pad - batch, cdist.PACK))])
-                cdist.gather_results(pk, world * batch_pad, out=gathered)
+                if to_root:
+                    cdist.gather_to_root(pk, world * batch_pad, out=gathered)
+                else:
+                    cdist.gather_results(pk, world * batch_pad, out=gathered)
             g1.record(side)
         barrier()
         alone = g0.elapsed_time(g1) / ng
@@ -405,18 +436,21 @@ def main():
         exposed = max(0.0, 1e3 * (elapsed - el_nog) / args.steps)
         gather_cost = {"alone": alone, "exposed": exposed, "hidden": max(0.0, alone - exposed), "unit": "ms per step",
                        "ms_per_step_without_exchange": 1e3 * el_nog / args.steps,
-                       "bytes_received_per_rank_per_step": int(world * batch_pad * cdist.PACK * 8),
+                       "bytes_received_per_rank_per_step": int(world * batch_pad * cdist.PACK * 8) if not to_root else {"rank 0": int(world * batch_pad * cdist.PACK * 8), "other ranks": 0},
+                       "in_flight": MAX_IN_FLIGHT,
                        "how": "alone: pack + all_gather_into_tensor back to back on the side stream (events); exposed: ms_per_step minus the same "
                               "K steps without the exchange (both max over ranks); hidden = alone - exposed: what runs under the next step's solve. "
                               "With N ranks every rank receives N x the records of one shard: the exposed share grows with N."}
 
-    # ---- the same K steps with EVERY Jacobi sweep in float64 (opts.f32_sweeps_until = 0): the reference is float64
-    # throughout (cvxpnpl.py:475-513); `value` is measured with the library's default, which runs the sweeps of the first
-    # iterations of a solve on single-precision columns -- both are reported
-    all_f64 = None
-    if world == 1 and not dist_on and nstreams == 1 and not args.pmc_child and not args.no_f64_ab and "f32_sweeps_until" not in over:
+    # ---- the same K steps in the OTHER precision mode.  The timed region above runs at the reference's precision by default (float64
+    # throughout, cvxpnpl.py:475-513; opts.f32_sweeps_until = 0); the library's default runs the sweeps of the first iterations of a
+    # solve on single-precision columns.  Both are reported: value_all_f64 and value_mixed.
+    other_mode = None
+    if world == 1 and not dist_on and nstreams == 1 and not args.pmc_child and not args.no_f64_ab and not any(kv.startswith("f32_sweeps_until=") for kv in args.opt):
         opts_d = opts
-        opts = _lib.default_opts(layout=args.layout, f32_sweeps_until=0, **over)
+        over_o = dict(over)
+        over_o["f32_sweeps_until"] = -1 if args.precision == "f64" else 0
+        opts = _lib.default_opts(layout=args.layout, **over_o)
         st_d, it_d = status.clone(), iters.clone()
         R_d = R.clone()
         for _ in range(args.warmup):
@@ -426,15 +460,16 @@ def main():
         for _ in range(args.steps):
             step()
         barrier()
-        dt64 = time.perf_counter() - t0
-        st64, it64 = status.cpu().numpy(), iters.cpu().numpy()
-        cert = (st64 == 0) & (st_d.cpu().numpy() == 0)
-        all_f64 = {"value": batch * args.steps / dt64, "unit": "poses/s", "ms_per_step": 1e3 * dt64 / args.steps, "opts": "f32_sweeps_until=0",
-                   "certified_frac": float((st64 == 0).mean()), "mean_iters": float(it64.mean()), "max_iters_seen": int(it64.max()),
-                   "status_equal_to_default_frac": float((st64 == st_d.cpu().numpy()).mean()),
-                   "max_rot_diff_vs_default_rad": float(synth.geodesic(R.cpu().numpy()[cert], R_d.cpu().numpy()[cert]).max()) if cert.any() else None}
+        dto = time.perf_counter() - t0
+        sto, ito = status.cpu().numpy(), iters.cpu().numpy()
+        cert = (sto == 0) & (st_d.cpu().numpy() == 0)
+        other_mode = {"value": batch * args.steps / dto, "unit": "poses/s", "ms_per_step": 1e3 * dto / args.steps,
+                      "opts": f"f32_sweeps_until={over_o['f32_sweeps_until']}" + (" (the library's default: 64)" if over_o["f32_sweeps_until"] < 0 else ""),
+                      "certified_frac": float((sto == 0).mean()), "mean_iters": float(ito.mean()), "max_iters_seen": int(ito.max()),
+                      "status_equal_to_timed_region_frac": float((sto == st_d.cpu().numpy()).mean()),
+                      "max_rot_diff_vs_timed_region_rad": float(synth.geodesic(R.cpu().numpy()[cert], R_d.cpu().numpy()[cert]).max()) if cert.any() else None}
         opts = opts_d
-        step()  # (the outputs read below are those of the default mode again)
+        step()  # (the outputs read below are those of the timed region's mode again)
         barrier()
 
     if args.pmc_child:
@@ -510,20 +545,30 @@ def main():
                 tstep(k, nst)
             torch.cuda.synchronize(dev)
             return time.perf_counter() - t1
-        dt1 = timed(1)
-        dtt = timed(2)
+        # Both schedules are measured, twice each and interleaved (boxes differ: on the round-4 driver box the two-stream schedule was
+        # 39 % SLOWER than the plain sequence, on the builder's box equal); `value` is the better one and says which -- a caller should
+        # measure the same way before choosing.
+        dt1 = min(timed(1), timed(1))
+        dt2 = timed(2)
+        dt1 = min(dt1, timed(1))
+        dt2 = min(dt2, timed(2))
+        best_two = dt2 < dt1
+        dtt = min(dt1, dt2)
         # the records that arrived on the host are those of the device-resident run (same inputs, same options)
         last = (args.steps - 1) % 2
         same = bool(torch.equal(torch.nan_to_num(h_pk[last]), torch.nan_to_num(cdist.pack_results(R, t, status).cpu())))
         bytes_in = int(h_all.numel()) * 8
         bytes_out = batch * cdist.PACK * 8
         transfer = {"value": batch * args.steps / dtt, "unit": "poses/s", "ms_per_step": 1e3 * dtt / args.steps,
+                    "schedule": "two_streams" if best_two else "one_stream",
                     "one_stream": {"value": batch * args.steps / dt1, "ms_per_step": 1e3 * dt1 / args.steps},
+                    "two_streams": {"value": batch * args.steps / dt2, "ms_per_step": 1e3 * dt2 / args.steps},
                     "h2d_bytes_per_step": int(bytes_in), "d2h_bytes_per_step": int(bytes_out),
                     "pcie_GBps_both_ways": (bytes_in + bytes_out) * args.steps / dtt / 1e9, "records_equal_device_run": same,
                     "how": "pinned host inputs (one buffer) -> H2D -> cvxpnpl_solve_batch -> cvxpnpl_pack_results -> D2H of the [batch][13] records to "
-                           "pinned memory, in order on a stream; `value`: steps alternate between two such streams (each with its own buffers), so "
-                           "that one step's copies run under the other's solve; one_stream: a single stream, nothing overlapped; wall clock over the K steps"}
+                           "pinned memory, in order on a stream; one_stream: a single stream, nothing overlapped; two_streams: steps alternate between "
+                           "two such streams (each with its own buffers), so that one step's copies can run under the other's solve; wall clock over the "
+                           "K steps, best of two interleaved runs each; `value` = the faster schedule (named in `schedule`), the other is the loser"}
 
     # ---- BASELINE config 5 as a frame: sample 4-subsets -> solve -> score every hypothesis against the scene (cvxpnpl_score_hypotheses) ->
     # arg-max -> refit on the consensus set.  `value` above is the solve alone (the metric's unit); this is the consumer's rate.
@@ -628,14 +673,18 @@ def main():
         barrier()
         last = (step_no[0] - 1) % nsets
         mine = cdist.pack_results(outs[last][0], outs[last][1], outs[last][2])
-        sl_ = gathered[rank * batch_pad:rank * batch_pad + batch]
-        own = bool(torch.equal(torch.nan_to_num(sl_), torch.nan_to_num(mine)))
-        stc = gathered[:, 12]
-        others = bool(((stc == stc.round()) & (stc >= 0) & (stc <= 4)).all().item())
+        glast = gathered  # (last written by the exchange-alone loop above: the records of output set 0, identical to every other set's)
+        if glast is not None:
+            sl_ = glast[rank * batch_pad:rank * batch_pad + batch]
+            own = bool(torch.equal(torch.nan_to_num(sl_), torch.nan_to_num(mine)))
+            stc = glast[:, 12]
+            others = bool(((stc == stc.round()) & (stc >= 0) & (stc <= 4)).all().item())
+        else:  # --collective gather: this rank only sends
+            own = others = True
         flag = torch.tensor([1.0 if (own and others) else 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         gather_check = {"own_slice_bit_equal": own, "all_slices_valid_status": others, "all_ranks_ok": bool(flag.item() == 1.0),
-                        "records": int(gathered.shape[0])}
+                        "records": int(world * batch_pad), "held_by": "rank 0" if to_root else "every rank"}
 
     st = status.cpu().numpy()
     it = iters.cpu().numpy()
@@ -660,8 +709,9 @@ def main():
                 "value_is": "problems of all ranks over the K steps / the slowest rank's wall time (all_reduce MAX)",
                 "handover": (("device flag (cvxpnpl_stream_write_value / _wait_value)" if handover[0] == "flag" else "event") +
                              (f"; {handover_retries} timed region(s) discarded because a flag wait gave up" if handover_retries else "")) if gather else None,
-                "exchange": (f"one all_gather_into_tensor of {world} x {batch_pad} records of 13 doubles per step, on a side stream under the next step's solve"
-                             if gather else None)}
+                "exchange": ((f"one gather to rank 0 of {world} x {batch_pad} records of 13 doubles per step" if to_root else
+                              f"one all_gather_into_tensor of {world} x {batch_pad} records of 13 doubles per step") +
+                             f", on a side stream under the next steps' solves, up to {MAX_IN_FLIGHT} in flight" if gather else None)}
     mean_launch_s = float(np.mean(asm_ms if asm_ms else launch_ms)) * 1e-3  # the dominant kernel's launch
     bytes_per_launch = algorithmic_bytes(n_p, n_l) * batch
     achieved = bytes_per_launch / mean_launch_s / 1e9
@@ -669,11 +719,12 @@ def main():
         "metric": "poses/sec (batched 10x10 SDP solves/sec)", "value": value, "unit": "poses/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": args.scaling, "vs_baseline": None,
-        "dtype": ("f64" if opts.f32_sweeps_until == 0 else "f64 (f32 Jacobi sweeps)"),  # what the timed region ran; value_all_f64 beside it
+        "dtype": ("f64" if opts.f32_sweeps_until == 0 else "f64 (f32 Jacobi sweeps)"),  # what the timed region ran; the other mode beside it
         "data": "synthetic",
         "config": {"workload": args.workload, "n_points": n_p, "n_lines": n_l, "problems_per_gpu_per_step": batch,
                    "pixel_noise_sigma": sigma, "eps": opts.eps, "max_iters": opts.max_iters,
-                   "precision": ("f64 throughout (opts.f32_sweeps_until = 0)" if opts.f32_sweeps_until == 0 else
+                   "precision": ("f64 throughout, as the reference (opts.f32_sweeps_until = 0); value_mixed is the same run with the library's default "
+                                 "(single-precision Jacobi sweeps while a solve is younger than 64 iterations)" if opts.f32_sweeps_until == 0 else
                                  "f64: inputs, Gram sums, iterate, Newton polish, dual certificate, outputs; the Jacobi sweeps of the PSD projection "
                                  "(and the product (W + sigma I) V that starts them) run on f32 columns while a solve is younger than "
                                  f"opts.f32_sweeps_until = {opts.f32_sweeps_until if opts.f32_sweeps_until >= 0 else 64} iterations -- all of "
@@ -727,9 +778,16 @@ def main():
         out["ransac_frame"] = ransac_frame
         out["solver"]["rank_gt1_frac"] = float((st == 1).mean())
         out["solver"]["uncertified_frac"] = float(((st == 2) | (st == 4)).mean())
-    if all_f64:
-        out["value_all_f64"] = all_f64["value"]
-        out["all_f64"] = all_f64
+    f64_run = opts.f32_sweeps_until == 0
+    if f64_run:
+        out["value_all_f64"] = value  # (= value: the timed region is the all-float64 run)
+    if other_mode:
+        if f64_run:
+            out["value_mixed"] = other_mode["value"]
+            out["mixed"] = other_mode
+        else:
+            out["value_all_f64"] = other_mode["value"]
+            out["all_f64"] = other_mode
     if overlapped:
         out["overlapped"] = overlapped
     if graph_replay:
@@ -859,7 +917,7 @@ def _measure_pmc(args):
         return None
     steps, warm = 6, 2
     child = ["--pmc-child", "--steps", str(steps), "--warmup", str(warm), "--workload", args.workload, "--layout", str(args.layout),
-             "--seed", str(args.seed), "--no-cpu-baseline", "--no-overlap", "--pmc", "off"]
+             "--seed", str(args.seed), "--no-cpu-baseline", "--no-overlap", "--pmc", "off", "--precision", args.precision]
     if args.batch:
         child += ["--batch", str(args.batch)]
     if args.n:

@@ -32,6 +32,7 @@ struct BatchArgs {
     const double *Q45, *B27; // cost entry (cvxpnpl_solve_cost_batch)
 };
 
+#ifdef CVXPNPL_EXPERIMENTS // the general scalar core on lanes: experiment builds only (layout 10) since round 5 -- see the lane branch of launch_solve
 // ---------------------------------------------------------------------------------------
 // lane-per-problem: each lane owns one problem (assembly -> ADMM -> certificate -> pose) for the first
 // handoff_at (1..5) iterations; 64 independent problems per wavefront, no cross-lane traffic, no LDS.
@@ -71,7 +72,12 @@ __global__ void __launch_bounds__(64) solve_lane_kernel(BatchArgs a, cvx::Opts o
     }
 }
 
-// The same phase from the register-budgeted restatement of the scalar core (lane_core.h): the schedule the launch policy
+#endif // CVXPNPL_EXPERIMENTS
+
+// Lane-per-problem, the first phase of the lane-hybrid schedule: each lane owns one problem (assembly -> ADMM -> one certificate attempt ->
+// pose) for the first handoff_at (2..6) iterations; 64 independent problems per wavefront, no cross-lane traffic.  A lane that is not
+// finished by then parks its iterate in ws[b] and queues b for resume_wave_kernel, so that one slow problem cannot hold the other 63 lanes.
+// The register-budgeted restatement of the scalar core (lane_core.h): the schedule the launch policy
 // actually uses -- handoff_at iterations, one certificate attempt after the last, single-precision sweeps -- written straight
 // line with streamed projections.  512 registers (256 + 256), ~20 spilled, 60 B of scratch per lane; the general core above needs
 // 2 640 B per lane (1 006 spilled registers, 1.1 GB of HBM traffic per 125 k launch) and stays for every other combination of
@@ -342,6 +348,15 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
         snprintf(g_err, sizeof(g_err), "cvxpnpl: bad options");
         return -1;
     }
+    // layouts: the public enum only.  The experiment layouts of rounds 2-4 (9: quad iterations only at three wavefronts per SIMD, 10: the lane
+    // schedule on the general scalar core, 11-13: the tail experiments of profiles/r04/tail_experiments.txt) exist in experiment builds
+    // (-DCVXPNPL_EXPERIMENTS, tools/experiments/build_experiments.sh) and nowhere else
+#ifdef CVXPNPL_EXPERIMENTS
+    const bool layout_known = !opts || (opts->layout >= CVXPNPL_LAYOUT_AUTO && opts->layout <= CVXPNPL_LAYOUT_PENTA) || (opts->layout >= 9 && opts->layout <= 13);
+#else
+    const bool layout_known = !opts || (opts->layout >= CVXPNPL_LAYOUT_AUTO && opts->layout <= CVXPNPL_LAYOUT_PENTA);
+#endif
+    if (!layout_known) { snprintf(g_err, sizeof(g_err), "cvxpnpl: bad options (layout %d is not one of CVXPNPL_LAYOUT_*)", opts->layout); return -1; }
     cvx::Opts o = to_core(opts);
     if (!opts) o.first_check = 0; // (by layout, below)
     int cur_dev = 0;
@@ -368,12 +383,12 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     // the lane-hybrid schedule would park nearly all of them for the one-problem-per-wavefront phase.  They stay four per wavefront
     // for 24 iterations instead (first attempt after 7 -- round 4: 17, and their survivors are queued: minimal_queued below), like the rc variant: 50 k problems 11.2 -> 12.4 M poses/s (lane_iters 16 / 24 /
     // 32 / 40: 12.1 / 12.4 / 11.7-12.2 / 12.3; five correspondences and more: the lane-hybrid schedule wins, 36.8 against 33.6 M at N = 5).
-#ifdef CVXQ_TAIL_EXPERIMENTS
+#ifdef CVXPNPL_EXPERIMENTS
     const bool layout_auto_like = layout == CVXPNPL_LAYOUT_AUTO || layout == 11 || layout == 12 || layout == 13;
 #else
     const bool layout_auto_like = layout == CVXPNPL_LAYOUT_AUTO;
 #endif
-#ifdef CVXQ_TAIL_EXPERIMENTS // (tuning builds: opts.lane_iters sets the length of the first phase of four-point problems)
+#ifdef CVXPNPL_EXPERIMENTS // (tuning builds: opts.lane_iters sets the length of the first phase of four-point problems)
     const bool minimal = !a.Q45 && a.n_p + a.n_l <= 4 && o.variant == cvx::VAR_FULL && layout_auto_like && batch >= 2560 && o.max_iters > 24;
 #else
     const bool minimal = !a.Q45 && a.n_p + a.n_l <= 4 && o.variant == cvx::VAR_FULL && layout_auto_like && batch >= 2560 && o.max_iters > 24 &&
@@ -383,7 +398,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     // The 16-equality variant (benchmarks/toolkit/methods/rc.py): wave-per-problem and, since round 3, the quad schedule (the
     // constraint set is a template parameter of the kernels); the lane kernels and the interior-point path are built for the full set.
     const bool rc = o.variant == cvx::VAR_RC;
-    if (rc && (layout == CVXPNPL_LAYOUT_LANE || layout == CVXPNPL_LAYOUT_PENTA || layout == 9 || layout == 10 || layout == 12 || layout == 13)) layout = CVXPNPL_LAYOUT_QUAD;
+    if (rc && (layout == CVXPNPL_LAYOUT_LANE || layout == CVXPNPL_LAYOUT_PENTA || layout == 9 || layout == 10 || layout == 12 || layout == 13)) layout = CVXPNPL_LAYOUT_QUAD; // (9-13: experiment builds only)
     cvxw::WaveArgs w;
     w.batch = batch; w.n_p = a.n_p; w.n_l = a.n_l; w.K_per_problem = a.K_per_problem;
     w.p2 = a.p2; w.p3 = a.p3; w.l2 = a.l2; w.l3 = a.l3; w.K = a.K;
@@ -399,8 +414,12 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     if (quad_iters > 16 && !rc && !minimal) quad_iters = 16; // (a caller's lane_iters: the quad phase is the YOUNG part of a solve, its slow survivors belong to the wave-per-problem phase.
     // Minimal problems and the rc variant run 24 / 36-48 iterations here, in single-precision sweeps by default -- inside the window of 64 that
     // opts.f32_sweeps_until allows and the host experiment covers; device A/B against float64 sweeps: profiles/r04/f32_phase_ab.txt)
+#ifdef CVXPNPL_EXPERIMENTS
     const bool lane_general = layout == 10; // experiment / A-B (tools/README.md): the lane schedule with the general scalar core (solve_lane_kernel)
     if (lane_general) layout = CVXPNPL_LAYOUT_LANE;
+#else
+    const bool lane_general = false;
+#endif
     // the REQUEST (five problems per wavefront) and the kernel that serves it are separate: with float64 sweeps the twelve-lane geometry
     // does not exist and the request runs the sixteen-lane quad kernel -- either way the layout from here on is QUAD (round-3 advisor:
     // a PENTA request with f32_sweeps_until = 0 used to fall through to the lane branch with a workspace fetched for another stride)
@@ -444,6 +463,15 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     int lane_iters = opts ? opts->lane_iters : -1;
     if (lane_iters <= 0) lane_iters = o.first_check;
     if (lane_iters > 6) lane_iters = 6; // (see the lane branch below)
+    // The register-budgeted lane kernel (lane_core.h) covers the schedule of the defaults: one attempt, right at the hand-off point, warm-started
+    // eigen-solves.  Any other combination of options (first_check != lane_iters, warm_start = 0) used to fall through to the general scalar
+    // core on lanes (solve_lane_kernel: 1 008-1 014 spilled registers, 2.2-2.7 KB of scratch per lane, a third of the speed) without saying
+    // so; since round 5 such a request runs the wave-per-problem layout, which honours every option, and the general lane kernel is
+    // compiled into experiment builds only (layout 10).
+    const bool lane_budgeted = !lane_general && o.first_check == lane_iters && lane_iters >= 2 && o.warm_start != 0;
+#ifndef CVXPNPL_EXPERIMENTS
+    if (layout == CVXPNPL_LAYOUT_LANE && !lane_budgeted) layout = CVXPNPL_LAYOUT_WAVE;
+#endif
     const bool lane_hybrid = layout == CVXPNPL_LAYOUT_LANE && o.max_iters > lane_iters;
     // The interior-point path comes in two builds.  Fused (cvxw::rescue_wave_kernel: the solve compiled into a resume kernel, one launch
     // behind the first kernel) where it is a safety net -- seven correspondences and more: its queue is empty in nearly every launch and
@@ -473,14 +501,15 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
         const int64_t qgrid = penta ? (batch + 4) / 5 : (batch + 3) / 4;
         cvxq::QuadArgs qa;
         qa.a = w; qa.o = o; qa.handoff_at = quad_iters; qa.qcount = count; qa.qentries = entries; qa.ws = ws;
-        if (opts && opts->layout == 9) hipLaunchKernelGGL((cvxq::solve_quad_kernel<1, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // experiment
-#ifdef CVXQ_TAIL_EXPERIMENTS // round 4, profiles/r04/tail_experiments.txt: survivors queued (layouts 11: three, 12: two wavefronts per SIMD), extras queued (13)
+#ifdef CVXPNPL_EXPERIMENTS // 9: iterations only (tools/phase_a_time.sh); round 4, profiles/r04/tail_experiments.txt: survivors queued (layouts 11: three, 12: two wavefronts per SIMD), extras queued (13)
+        if (opts && opts->layout == 9) hipLaunchKernelGGL((cvxq::solve_quad_kernel<1, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (opts && opts->layout == 11 && rc) hipLaunchKernelGGL((cvxq::solve_quad_kernel<2, 3, 16, false, cvx::VAR_RC>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (opts && opts->layout == 11) hipLaunchKernelGGL((cvxq::solve_quad_kernel<2, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (opts && opts->layout == 13) hipLaunchKernelGGL((cvxq::solve_quad_kernel<3, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (opts && opts->layout == 12) hipLaunchKernelGGL((cvxq::solve_quad_kernel<2, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
+        else
 #endif
-        else if (minimal_queued)
+        if (minimal_queued)
             // Four-correspondence problems: every survivor of the 24-iteration first phase goes to the queue of the launch behind this one
             // instead of being finished by its own wavefront -- 59 % of these wavefronts end with survivors, most of which are headed for
             // the interior-point path anyway, and without the wave-per-problem code the kernel runs three wavefronts per SIMD (168 registers).
@@ -515,12 +544,13 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
             // hybrid: lanes for the first lane_iters iterations, survivors resumed one per wavefront
             int32_t *count = wv.count, *entries = wv.entries;
             double *ws = wv.parked;
-            // the register-budgeted kernel covers the schedule of the defaults (one attempt, right at the hand-off point, single-precision sweeps)
-            const bool budgeted = !lane_general && o.first_check == lane_iters && lane_iters >= 2 && o.warm_start != 0;
+            const bool budgeted = lane_budgeted;
             if (budgeted && o.f32_sweeps_until >= lane_iters) hipLaunchKernelGGL(solve_lane2_kernel<false>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws);
             else if (budgeted) hipLaunchKernelGGL(solve_lane2_kernel<true>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws); // float64 sweeps
+#ifdef CVXPNPL_EXPERIMENTS
             else if (o.f32_sweeps_until < lane_iters) hipLaunchKernelGGL(solve_lane_kernel<true>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws); // float64 sweeps (A/B mode)
             else hipLaunchKernelGGL(solve_lane_kernel<false>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws);
+#endif
             const int64_t rgrid = batch < cvxw::RESUME_GRID_MAX ? batch : cvxw::RESUME_GRID_MAX;
             launch_resume(rgrid, s, w, o, count, entries, ws, false);
         } else {
@@ -686,11 +716,12 @@ __global__ void stream_write_value_kernel(unsigned long long *flag, unsigned lon
     // max, not store: write kernels enqueued on different streams may complete out of order and the flag must never move backwards
     __hip_atomic_fetch_max(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void stream_wait_value_kernel(unsigned long long *flag, unsigned long long value)
+__global__ void stream_wait_value_kernel(unsigned long long *flag, unsigned long long value, unsigned long long max_polls)
 {
-    // bounded: if the two streams share a hardware queue the producer's kernel sits BEHIND this one and the flag can never arrive --
-    // after ~0.25 s of polling the wait gives up and says so in flag[1] (the caller falls back to an event)
-    for (int spin = 0; spin < (1 << 18); ++spin) {
+    // bounded (max_polls > 0): if the two streams share a hardware queue the producer's kernel sits BEHIND this one and the flag can never
+    // arrive -- after max_polls polls of ~1 us (cvxpnpl_stream_wait_value: 2^18, ~0.25 s) the wait gives up and says so in flag[1]
+    // (the caller falls back to an event); max_polls = 0: wait for as long as it takes
+    for (unsigned long long spin = 0; max_polls == 0 || spin < max_polls; ++spin) {
         if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= value) return;
         __builtin_amdgcn_s_sleep(32);
     }
@@ -705,12 +736,26 @@ int cvxpnpl_stream_write_value(uint64_t *d_flag, uint64_t value, void *stream)
     return e == hipSuccess ? 0 : set_err("stream_write_value_kernel launch", e);
 }
 
-int cvxpnpl_stream_wait_value(uint64_t *d_flag, uint64_t value, void *stream)
+int cvxpnpl_stream_wait_value_bounded(uint64_t *d_flag, uint64_t value, uint64_t max_polls, void *stream)
 {
     if (!d_flag) { snprintf(g_err, sizeof(g_err), "cvxpnpl_stream_wait_value: null flag"); return -1; }
-    hipLaunchKernelGGL(stream_wait_value_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long *)d_flag, (unsigned long long)value);
+    hipLaunchKernelGGL(stream_wait_value_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long *)d_flag, (unsigned long long)value,
+                       (unsigned long long)max_polls);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : set_err("stream_wait_value_kernel launch", e);
+}
+
+int cvxpnpl_stream_wait_value(uint64_t *d_flag, uint64_t value, void *stream) { return cvxpnpl_stream_wait_value_bounded(d_flag, value, 1ull << 18, stream); }
+
+int cvxpnpl_stream_wait_gave_up(uint64_t *d_flag, int32_t clear, void *stream)
+{
+    if (!d_flag) { snprintf(g_err, sizeof(g_err), "cvxpnpl_stream_wait_gave_up: null flag"); return -1; }
+    unsigned long long w = 0;
+    hipError_t e = hipMemcpyAsync(&w, d_flag + 1, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e == hipSuccess && clear && w != 0) e = hipMemsetAsync(d_flag + 1, 0, sizeof(w), (hipStream_t)stream);
+    if (e != hipSuccess) return set_err("cvxpnpl_stream_wait_gave_up", e);
+    return w != 0 ? 1 : 0;
 }
 
 int cvxpnpl_pack_results(int64_t batch, const double *d_R, const double *d_t, const int32_t *d_status, double *d_packed, void *stream)
@@ -748,11 +793,11 @@ int cvxpnpl_score_hypotheses(int64_t n_hyp, const double *d_R, const double *d_t
 int cvxpnpl_sample_minimal_sets(int64_t n_hyp, int32_t n_corr, const double *d_scene_2d, const double *d_scene_3d, int32_t k, uint64_t seed,
                                 int32_t *d_idx, double *d_pts_2d, double *d_pts_3d, void *stream)
 {
+    if (n_hyp == 0) return 0; /* a no-op, as the header says: the (empty) outputs may be NULL */
     if (n_hyp < 0 || k < 1 || k > cvxs::SAMPLE_KMAX || n_corr < k || !d_scene_2d || !d_scene_3d || !d_pts_2d || !d_pts_3d) {
         snprintf(g_err, sizeof(g_err), "cvxpnpl_sample_minimal_sets: bad arguments (n_hyp=%lld n_corr=%d k=%d)", (long long)n_hyp, n_corr, k);
         return -1;
     }
-    if (n_hyp == 0) return 0;
     const int64_t grid = (n_hyp + 255) / 256;
     if (grid > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "cvxpnpl_sample_minimal_sets: too many hypotheses for one launch"); return -1; }
     cvxs::SampleArgs a;

@@ -174,7 +174,9 @@ CVX_HD bool certify_in_place(QV Qs, double *S, const double *vt, double delta, d
 // The bank: float64 slots in accumulation registers.  A put defines a fresh "a"-class value, a get reads it: a slot lives from its put
 // to its last get, and the asm statements are volatile so that the moves stay where they are written.  Host build: a plain array.
 constexpr int BANK_SLOTS = 55;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(CVXL_NO_PARK)
+// (accumulation registers that plain VALU code can park values in exist on gfx90a / gfx942 / gfx950 -- the unified 512-entry file; any other
+// target gets the plain array, like the host build)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CVXL_NO_PARK) && (defined(__gfx90a__) || defined(__gfx942__) || defined(__gfx950__))
 struct Bank { unsigned r[2 * BANK_SLOTS]; };
 CVX_HD void bank_put(Bank &b, int s, double x)
 {

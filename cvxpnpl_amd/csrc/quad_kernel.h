@@ -4,9 +4,13 @@
 // The 10x10 SDP is too small for 64 lanes: in the wave-per-problem layout most instructions are 3x3 /
 // scalar algebra replicated in every lane, and the kernel is VALU-issue bound on that redundancy.
 // Here a DPP row (16 lanes) owns one problem, so every replicated instruction serves four problems:
-//   * eigen-solve: lane j < 10 owns COLUMN j of G = (W + sigma I) V in registers.  A one-sided Jacobi
-//     rotation needs the partner's column: 22 ds_bpermute per round-robin round (no LDS memory, no
-//     barrier), then both lanes of a pair compute the same rotation and update their own column;
+//   * eigen-solve: lane j < 10 owns one COLUMN of G = (W + sigma I) V in registers.  A one-sided Jacobi rotation needs the partner's
+//     column.  Nine steps per sweep, every pair of columns exactly once (kATab): steps 0, 2, 4, 6, 8 pair lanes (2k, 2k + 1) and read
+//     the partner through DPP quad_perm [1,0,3,2] -- in single precision as an OPERAND of the FMAs themselves (v_fmac_f32_dpp: no
+//     exchange instruction at all), in double as 22 v_mov_b32_dpp; steps 1, 3, 5, 7 fetch it with ds_bpermute (11 / 22 per step, no LDS
+//     memory, no barrier) and may leave a lane with the PARTNER's rotated column, which is what lines the next DPP step up.  Both lanes
+//     of a pair compute the same rotation.  (Round 5; until then all nine steps went through ds_bpermute -- round-robin order --
+//     tools/microbench/eig16x.hip, profiles/r05/eig16x.txt: LDS round trips per sweep 9 -> 4);
 //   * entry work (affine projection, ADMM update, PSD reconstruction, LDL^T): the 55 entries of the
 //     symmetric iterate are dealt round-robin, entry e to lane e % 16 (3-4 entries per lane);
 //   * reductions over a problem are 4-step DPP butterflies inside the row (quad_perm, row_half_mirror,
@@ -78,27 +82,66 @@ constexpr ETab make_etab()
 }
 __device__ const ETab kETab = make_etab();
 
-// round-robin partner of column l at step st (cvx::rr_col), 4 bits per step; idle lanes pair with themselves
-struct PTab { unsigned long long packed[16]; };
-constexpr PTab make_ptab()
+// The alternating ordering of the sweeps (round 5).  A sweep is nine steps: A X A X A X A X A.  An A step pairs the columns held by lanes
+// (2k, 2k + 1) of the group (DPP quad_perm [1,0,3,2]).  An X step s = 0..3 pairs lane l with lane x_partner(s, l) through ds_bpermute and,
+// where x_take(s, l) is set, BOTH lanes of the pair keep the other one's rotated column (each has both columns in registers after the
+// exchange, so the swap is free) -- that is what makes the next A step's neighbours a set of pairs that have not met yet.  Found by search
+// (tools/microbench/jacobi_orderings.py: P1, M2, P3, ..., P9 a 1-factorisation of K10 with P(t+2) = f(P(t)), f a sub-involution of M(t+1));
+// the table is in terms of LANES, so it is a full sweep from any placement of the columns, in particular from the one the previous sweep
+// left.  Word l: bits 4s..4s+3 = partner lane of X step s, bit 16 + s = take.  Lanes 10..15 (and 10, 11 of a twelve-lane group) pair
+// with themselves.
+struct ATab { unsigned w[16]; };
+constexpr ATab make_atab()
 {
-    PTab t{};
-    for (int l = 0; l < 16; ++l) {
-        unsigned long long w = 0;
-        for (int st = 0; st < 9; ++st) {
-            int partner = l;
-            for (int k = 0; k < 5; ++k) {
-                const int p = cvx::rr_col(st, k), q = cvx::rr_col(st, k + 5);
-                if (p == l) partner = q;
-                if (q == l) partner = p;
+    // X steps as matchings of the COLUMNS (columns named by the lane that holds them at the start of the sweep) + which pairs swap
+    constexpr int M[4][5][2] = {{{0, 2}, {1, 3}, {4, 6}, {5, 8}, {7, 9}}, {{0, 4}, {1, 6}, {2, 9}, {3, 5}, {7, 8}},
+                                {{0, 9}, {1, 8}, {2, 4}, {3, 7}, {5, 6}}, {{0, 8}, {1, 5}, {2, 7}, {3, 6}, {4, 9}}};
+    constexpr unsigned SW[4] = {0xd, 0x1a, 0x1b, 0x1d};
+    int lane_of[10] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9};
+    ATab t{};
+    for (int l = 0; l < 16; ++l) t.w[l] = l >= 10 ? (unsigned)(l | (l << 4) | (l << 8) | (l << 12)) : 0u;
+    for (int s = 0; s < 4; ++s)
+        for (int k = 0; k < 5; ++k) {
+            const int a = M[s][k][0], b = M[s][k][1], la = lane_of[a], lb = lane_of[b];
+            t.w[la] |= (unsigned)lb << (4 * s);
+            t.w[lb] |= (unsigned)la << (4 * s);
+            if ((SW[s] >> k) & 1u) {
+                t.w[la] |= 1u << (16 + s);
+                t.w[lb] |= 1u << (16 + s);
+                lane_of[a] = lb;
+                lane_of[b] = la;
             }
-            w |= (unsigned long long)partner << (4 * st);
         }
-        t.packed[l] = w;
-    }
     return t;
 }
-__device__ const PTab kPTab = make_ptab();
+__device__ const ATab kATab = make_atab();
+// every pair of columns meets exactly once per sweep, whatever the placement (checked at compile time from the lane-level table)
+constexpr bool atab_is_a_sweep()
+{
+    const ATab t = make_atab();
+    int col[10] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9};
+    bool met[10][10] = {};
+    int n = 0;
+    for (int st = 0; st < 9; ++st) {
+        if ((st & 1) == 0) {
+            for (int k = 0; k < 5; ++k) { const int a = col[2 * k], b = col[2 * k + 1]; if (met[a][b]) return false; met[a][b] = met[b][a] = true; ++n; }
+        } else {
+            const int s = st >> 1;
+            for (int l = 0; l < 10; ++l) {
+                const int p = (int)((t.w[l] >> (4 * s)) & 15u);
+                if (p >= 10 || p == l || (int)((t.w[p] >> (4 * s)) & 15u) != l || ((t.w[l] >> (16 + s)) & 1u) != ((t.w[p] >> (16 + s)) & 1u)) return false;
+                if (p > l) {
+                    const int a = col[l], b = col[p];
+                    if (met[a][b]) return false;
+                    met[a][b] = met[b][a] = true; ++n;
+                    if ((t.w[l] >> (16 + s)) & 1u) { col[l] = b; col[p] = a; }
+                }
+            }
+        }
+    }
+    return n == 45;
+}
+static_assert(atab_is_a_sweep(), "kATab: a sweep must rotate every pair of columns exactly once");
 
 // x-vector table of the polish: element (v, i) of z / a_k as sign * R[src]  (cvxw::kXTab), 40 entries
 // dealt to lane idx % 16
@@ -219,35 +262,169 @@ __device__ __forceinline__ void quad_proj(double *L, const OWN &w, double *X, do
 }
 
 // Rotation of one one-sided Jacobi step seen from ONE of the two lanes of a pair: d = |other|^2 - |own|^2,
-// gam = own . other.  own' = c own - s other; the partner, with d -> -d, gets t -> -t: together the same
-// plane rotation as cvx::jacobi_cs.  tie_neg breaks d == 0 consistently (the pair must not both pick +t).
-// Single precision throughout (see the eigen-solve in solve_quad_kernel): v_rsq_f32 / v_rcp_f32 are good to 1 ulp.
+// gam = own . other.  own' = c own - s other; the partner, with d -> -d, gets s -> -s: together the same
+// plane rotation as cvx::jacobi_cs (the inner one, |angle| <= 45 degrees).  tie_neg breaks d == 0 consistently (the pair must not both
+// pick +s).  Half-angle form (round 5): with h = sqrt(d^2 + (2 gam)^2), cos^2 = (h + |d|) / 2h and sin cos = gam / h -- two v_rsq and no
+// v_rcp on the dependent chain (until round 5: t = 2 gam / (|d| + h) by v_rsq, v_rcp, then c = rsq(1 + t^2): three transcendentals in a
+// row; tools/microbench/eig16x.hip: -1 % / -6 % per sweep in single / double precision).  t = s / c is still returned: the norms are
+// updated incrementally, |own'|^2 = |own|^2 - t gam, |other'|^2 = |other|^2 + t gam.
+// Single precision throughout (see the eigen-solve in solve_quad_kernel): v_rsq_f32 is good to 1 ulp.
 __device__ __forceinline__ void pair_cs(float d, float gam, bool rot, bool tie_neg, float &c, float &s, float &t)
 {
     const float g2 = 2.0f * gam;
     const float h2 = d * d + g2 * g2 + 1e-37f;
-    const float hf = h2 * __builtin_amdgcn_rsqf(h2);
-    float tf = g2 * __builtin_amdgcn_rcpf(fabsf(d) + hf);
+    const float rh = __builtin_amdgcn_rsqf(h2);       // 1 / h
+    const float c2 = fmaf(0.5f * fabsf(d), rh, 0.5f);  // cos^2 in [1/2, 1]
+    const float rc = __builtin_amdgcn_rsqf(c2);       // 1 / cos
+    float sf = gam * rh * rc;                          // sin = (sin cos) / cos
     const bool neg = d < 0.0f || (d == 0.0f && tie_neg);
-    tf = neg ? -tf : tf;
-    t = rot ? tf : 0.0f;
-    c = __builtin_amdgcn_rsqf(1.0f + t * t);
-    s = t * c;
+    sf = neg ? -sf : sf;
+    c = rot ? c2 * rc : 1.0f;
+    s = rot ? sf : 0.0f;
+    t = s * rc;
 }
 
-// The same in float64 throughout (F64SW instantiation: Opts::f32_sweeps_until below the length of this phase -- the A/B mode
-// of the single-precision sweeps; seeds v_rsq_f64 / v_rcp_f64 + two Newton steps, <= 2 ulp)
+// The same in float64 throughout (F64SW instantiation: Opts::f32_sweeps_until below the length of this phase -- the reference's
+// precision; seeds v_rsq_f64 + Newton steps, <= 2 ulp)
 __device__ __forceinline__ void pair_cs_f64(double d, double gam, bool rot, bool tie_neg, double &c, double &s, double &t)
 {
     const double g2 = 2.0 * gam;
     const double h2 = d * d + g2 * g2 + 1e-290;
-    const double h = h2 * cvx::rsqrt_(h2);
-    double tf = g2 * cvx::rcp(fabs(d) + h);
+    const double rh = cvx::rsqrt_(h2);
+    const double c2 = fma(0.5 * fabs(d), rh, 0.5);
+    const double rc = cvx::rsqrt_(c2);
+    double sf = gam * rh * rc;
     const bool neg = d < 0.0 || (d == 0.0 && tie_neg);
-    tf = neg ? -tf : tf;
-    t = rot ? tf : 0.0;
-    c = cvx::rsqrt_(1.0 + t * t);
-    s = t * c;
+    sf = neg ? -sf : sf;
+    c = rot ? c2 * rc : 1.0;
+    s = rot ? sf : 0.0;
+    t = s * rc;
+}
+
+// ---- the steps of a sweep (see kATab).  real: this lane holds a column (gl < 10) and has a partner.
+// DPP as an OPERAND of the arithmetic (VOP2 DPP encoding): hipcc 7.2 does not fold v_mov_b32_dpp into the consuming FMA, so the two
+// blocks are written by hand.  s_nop 4 in front: the hazard recogniser does not look inside inline asm (VALU write -> DPP read of the
+// same VGPR needs 2 wait states, EXEC write -> DPP 5).
+#define CVXQ_DPP_XOR1 "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:0"
+// g0 + g1 = sum_i e_i * e_i[partner]
+#define CVXQ_DOT10_DPP(g0, g1, e)                                                                                                   \
+    asm volatile("s_nop 4\n\t"                                                                                                      \
+                 "v_mul_f32_dpp %0, %2, %2 " CVXQ_DPP_XOR1 "\n\tv_mul_f32_dpp %1, %3, %3 " CVXQ_DPP_XOR1 "\n\t"                     \
+                 "v_fmac_f32_dpp %0, %4, %4 " CVXQ_DPP_XOR1 "\n\tv_fmac_f32_dpp %1, %5, %5 " CVXQ_DPP_XOR1 "\n\t"                   \
+                 "v_fmac_f32_dpp %0, %6, %6 " CVXQ_DPP_XOR1 "\n\tv_fmac_f32_dpp %1, %7, %7 " CVXQ_DPP_XOR1 "\n\t"                   \
+                 "v_fmac_f32_dpp %0, %8, %8 " CVXQ_DPP_XOR1 "\n\tv_fmac_f32_dpp %1, %9, %9 " CVXQ_DPP_XOR1 "\n\t"                   \
+                 "v_fmac_f32_dpp %0, %10, %10 " CVXQ_DPP_XOR1 "\n\tv_fmac_f32_dpp %1, %11, %11 " CVXQ_DPP_XOR1                       \
+                 : "=&v"(g0), "=&v"(g1)                                                                                             \
+                 : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(e[4]), "v"(e[5]), "v"(e[6]), "v"(e[7]), "v"(e[8]), "v"(e[9]))
+// n_i += k * e_i[partner]
+#define CVXQ_AXPY10_DPP(n, e, k)                                                                                                    \
+    asm volatile("s_nop 4\n\t"                                                                                                      \
+                 "v_fmac_f32_dpp %0, %10, %20 " CVXQ_DPP_XOR1 "\n\tv_fmac_f32_dpp %1, %11, %20 " CVXQ_DPP_XOR1 "\n\t"               \
+                 "v_fmac_f32_dpp %2, %12, %20 " CVXQ_DPP_XOR1 "\n\tv_fmac_f32_dpp %3, %13, %20 " CVXQ_DPP_XOR1 "\n\t"               \
+                 "v_fmac_f32_dpp %4, %14, %20 " CVXQ_DPP_XOR1 "\n\tv_fmac_f32_dpp %5, %15, %20 " CVXQ_DPP_XOR1 "\n\t"               \
+                 "v_fmac_f32_dpp %6, %16, %20 " CVXQ_DPP_XOR1 "\n\tv_fmac_f32_dpp %7, %17, %20 " CVXQ_DPP_XOR1 "\n\t"               \
+                 "v_fmac_f32_dpp %8, %18, %20 " CVXQ_DPP_XOR1 "\n\tv_fmac_f32_dpp %9, %19, %20 " CVXQ_DPP_XOR1                        \
+                 : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]), "+v"(n[4]), "+v"(n[5]), "+v"(n[6]), "+v"(n[7]), "+v"(n[8]), "+v"(n[9]) \
+                 : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(e[4]), "v"(e[5]), "v"(e[6]), "v"(e[7]), "v"(e[8]), "v"(e[9]), "v"(k))
+
+// A step, single precision: lanes (2k, 2k + 1); no exchange instruction
+__device__ __forceinline__ void jstep_dpp(f2 (&q)[5], float &alf, bool real, bool tie_neg, bool active, float tol2, bool &coarse)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    float e[10], g0, g1;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { e[2 * i] = q[i].x; e[2 * i + 1] = q[i].y; }
+    CVXQ_DOT10_DPP(g0, g1, e);
+    const float gam = g0 + g1;
+    const float be = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(alf), 0xB1, 0xF, 0xF, true));
+    const float g2 = gam * gam, ab = alf * be;
+    coarse |= real && g2 > tol2 * ab;
+    float c, sn, t;
+    pair_cs(be - alf, gam, active && real && g2 > 1e-30f * ab, tie_neg, c, sn, t);
+    const f2 cc = {c, c};
+    const float ms = -sn;
+    float n[10];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { const f2 p = cc * q[i]; n[2 * i] = p.x; n[2 * i + 1] = p.y; }
+    CVXQ_AXPY10_DPP(n, e, ms);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { q[i].x = n[2 * i]; q[i].y = n[2 * i + 1]; }
+    alf = fmaf(-t, gam, alf);
+#endif
+}
+// X step, single precision: partner through ds_bpermute (11), take = keep the partner's rotated column
+__device__ __forceinline__ void jstep_bperm(f2 (&q)[5], float &alf, int addr, bool real, bool tie_neg, bool take, bool active, float tol2, bool &coarse)
+{
+    f2 oq[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { oq[i].x = bpermf(addr, q[i].x); oq[i].y = bpermf(addr, q[i].y); }
+    const float be = bpermf(addr, alf);
+    f2 acc = q[0] * oq[0];
+#pragma unroll
+    for (int i = 1; i < 5; ++i) acc = __builtin_elementwise_fma(q[i], oq[i], acc);
+    const float gam = acc.x + acc.y;
+    const float g2 = gam * gam, ab = alf * be;
+    coarse |= real && g2 > tol2 * ab;
+    float c, sn, t;
+    pair_cs(be - alf, gam, active && real && g2 > 1e-30f * ab, tie_neg, c, sn, t);
+    // own' = c own - s other ; other' = s own + c other
+    const float ka = take ? sn : c, kb = take ? c : -sn;
+    const f2 ka2 = {ka, ka}, kb2 = {kb, kb};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) q[i] = __builtin_elementwise_fma(ka2, q[i], kb2 * oq[i]);
+    alf = take ? fmaf(t, gam, be) : fmaf(-t, gam, alf);
+}
+// the same two steps in float64 (22 v_mov_b32_dpp / 22 ds_bpermute)
+__device__ __forceinline__ void jstep_dpp(double (&qd)[10], double &alq, bool real, bool tie_neg, bool active, double tol2, bool &coarse)
+{
+    double oq[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) oq[i] = dpp_mov<0xB1>(qd[i]);
+    const double be = dpp_mov<0xB1>(alq);
+    double gam = 0.0;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) gam = fma(qd[i], oq[i], gam);
+    const double g2 = gam * gam, ab = alq * be;
+    coarse |= real && g2 > tol2 * ab;
+    double c, sn, t;
+    pair_cs_f64(be - alq, gam, active && real && g2 > 1e-30 * ab, tie_neg, c, sn, t);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) qd[i] = c * qd[i] - sn * oq[i];
+    alq = fma(-t, gam, alq);
+}
+__device__ __forceinline__ void jstep_bperm(double (&qd)[10], double &alq, int addr, bool real, bool tie_neg, bool take, bool active, double tol2, bool &coarse)
+{
+    double oq[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) oq[i] = bperm(addr, qd[i]);
+    const double be = bperm(addr, alq);
+    double gam = 0.0;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) gam = fma(qd[i], oq[i], gam);
+    const double g2 = gam * gam, ab = alq * be;
+    coarse |= real && g2 > tol2 * ab;
+    double c, sn, t;
+    pair_cs_f64(be - alq, gam, active && real && g2 > 1e-30 * ab, tie_neg, c, sn, t);
+    const double ka = take ? sn : c, kb = take ? c : -sn;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) qd[i] = fma(ka, qd[i], kb * oq[i]);
+    alq = take ? fma(t, gam, be) : fma(-t, gam, alq);
+}
+// one sweep: A X A X A X A X A
+template <class COL, class T>
+__device__ __forceinline__ void jacobi_sweep(COL &q, T &al, unsigned atab, int gl, int lane_base4, bool active, T tol2, bool &coarse)
+{
+    const bool col_lane = gl < 10;
+#pragma unroll
+    for (int st = 0; st < 9; ++st) {
+        if ((st & 1) == 0) {
+            jstep_dpp(q, al, col_lane, (gl & 1) != 0, active, tol2, coarse);
+        } else {
+            const int xs = st >> 1;
+            const int partner = (int)((atab >> (4 * xs)) & 15u);
+            jstep_bperm(q, al, lane_base4 + (partner << 2), partner != gl, gl > partner, ((atab >> (16 + xs)) & 1u) != 0, active, tol2, coarse);
+        }
+    }
 }
 
 // In-place LDL^T of the symmetric matrix held 3-4 entries per lane, pivot rows broadcast through LDS;
@@ -325,9 +502,9 @@ __device__ __forceinline__ void finish_own(QuadArgsPtr kp, unsigned parked, doub
 // MODE 0: the schedule described above.  MODE 2 (experiment, round 4: layouts 11 / 12): the first phase with its certificate attempts, but
 // every survivor is queued for the resume kernel instead of being finished by its own wavefront -- the kernel then holds no
 // wave-per-problem code and can run three wavefronts per SIMD (one round of 3 072 slots for the 2 500 wavefronts of a 10 k launch).
-// MODE 1 (experiment, tools/phase_a_time.sh): the iterations only -- no
-// certificate code is compiled in, every problem is parked after handoff_at iterations -- to measure what the
-// iteration phase costs at the occupancy it gets without the certificate's registers.
+// MODE 1 (experiment builds, layout 9): the iterations only -- no certificate code is compiled in, every problem is parked after handoff_at
+// iterations and queued for the resume kernel behind the launch, which makes the first attempt: the "one-round geometry" of round 5
+// (146 registers, three wavefronts per SIMD, 3 072 slots for the 2 500 wavefronts of a 10 k launch; profiles/r05/one_round.txt).
 // F64SW: the Jacobi sweeps, G = (W + sigma I) V and the warm-start eigenvectors in float64 (see pair_cs_f64)
 template <int MODE, int OCC = 2, int LPP = 16, bool F64SW = false, int VAR = cvx::VAR_FULL>
 __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
@@ -360,7 +537,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
     w.gl = gl;
 #pragma unroll
     for (int m = 0; m < EPL; ++m) w.pk[m] = kETab.w[gl + LPP * m];
-    const unsigned long long ptab = kPTab.packed[gl];
+    const unsigned atab = kATab.w[gl];
     const int lane_base4 = (grp * LPP) << 2;
 
     // ---------------------------------------------------------------- assembly (cvxpnpl.py:20-153, :545-549)
@@ -625,7 +802,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
             float alf = 0.0f; // (single-precision path: squared norm of this lane's column)
             f2 q[5];
             if constexpr (F64SW) {
-                // float64 throughout: W to LDS as the full symmetric matrix (row stride 10), g = (W + sigma I) v, 22 ds_bpermute per step
+                // float64 throughout: W to LDS as the full symmetric matrix (row stride 10), g = (W + sigma I) v; 22 v_mov_b32_dpp / 22 ds_bpermute per step
 #pragma unroll
                 for (int m = 0; m < EPL; ++m)
                     if (w.ok(m)) { L[Q_WF + w.ei(m) * 10 + w.ej(m)] = W[m]; L[Q_WF + w.ej(m) * 10 + w.ei(m)] = W[m]; }
@@ -646,25 +823,7 @@ CVXQ_PH(0);
                 bool active = !done; // row-uniform
                 do {
                     bool coarse = false;
-#pragma unroll
-                    for (int st = 0; st < 9; ++st) {
-                        const int partner = (int)((ptab >> (4 * st)) & 15);
-                        const int addr = lane_base4 + (partner << 2);
-                        double oq[10];
-#pragma unroll
-                        for (int i = 0; i < 10; ++i) oq[i] = bperm(addr, qd[i]);
-                        const double be = bperm(addr, alq);
-                        double gam = 0.0;
-#pragma unroll
-                        for (int i = 0; i < 10; ++i) gam = fma(qd[i], oq[i], gam);
-                        const double g2 = gam * gam, ab = alq * be;
-                        coarse |= (partner != gl) && g2 > tol2 * ab;
-                        double c, sn, t;
-                        pair_cs_f64(be - alq, gam, active && (partner != gl) && g2 > 1e-30 * ab, gl > partner, c, sn, t);
-#pragma unroll
-                        for (int i = 0; i < 10; ++i) qd[i] = c * qd[i] - sn * oq[i];
-                        alq -= t * gam;
-                    }
+                    jacobi_sweep(qd, alq, atab, gl, lane_base4, active, tol2, coarse);
                     alq = 0.0; // exact norms once per sweep (the incremental update drifts)
 #pragma unroll
                     for (int i = 0; i < 10; ++i) alq = fma(qd[i], qd[i], alq);
@@ -715,32 +874,12 @@ CVXQ_PH(0); /* fro, LDS copy of W, g = (W + sigma I) v */
             // double, and this phase ends after handoff_at <= 16 iterations -- measured on the host build (10 k problems each
             // of PnP N=10 / N=6 sigma 5 / N=4, PnPL 5+5): iteration histograms identical to the double sweeps as long as
             // the first 7-16 iterations are concerned (single precision throughout only hurts tails of > 100 iterations,
-            // which are the wave-per-problem kernel's).  Half the exchange (11 ds_bpermute per step), half the arithmetic.
+            // which are the wave-per-problem kernel's).  Half the exchange (11 ds_bpermute per X step, none per A step), half the arithmetic.
             const float tol2f = (float)tol2;
             bool active = !done; // row-uniform
             do {
                 bool coarse = false;
-#pragma unroll
-                for (int st = 0; st < 9; ++st) {
-                    const int partner = (int)((ptab >> (4 * st)) & 15);
-                    const int addr = lane_base4 + (partner << 2);
-                    f2 oq[5];
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) { oq[i].x = bpermf(addr, q[i].x); oq[i].y = bpermf(addr, q[i].y); }
-                    const float be = bpermf(addr, alf);
-                    f2 acc = q[0] * oq[0];
-#pragma unroll
-                    for (int i = 1; i < 5; ++i) acc = __builtin_elementwise_fma(q[i], oq[i], acc);
-                    const float gam = acc.x + acc.y;
-                    const float g2 = gam * gam, ab = alf * be;
-                    coarse |= (partner != gl) && g2 > tol2f * ab;
-                    float c, sn, t;
-                    pair_cs(be - alf, gam, active && (partner != gl) && g2 > 1e-30f * ab, gl > partner, c, sn, t);
-                    const f2 cc = {c, c}, ss = {sn, sn};
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) q[i] = __builtin_elementwise_fma(cc, q[i], -(ss * oq[i]));
-                    alf -= t * gam;
-                }
+                jacobi_sweep(q, alf, atab, gl, lane_base4, active, tol2f, coarse);
                 { // exact norms once per sweep (the incremental update drifts)
                     f2 acc = q[0] * q[0];
 #pragma unroll
@@ -1103,8 +1242,7 @@ CVXQ_PH(7); /* projection + update */
     unsigned pmask = 0;
 #pragma unroll
     for (int g = 0; g < NPW; ++g) pmask |= (unsigned)((pm >> (LPP * g)) & 1ull) << g;
-    if (MODE == 1) { if (gvalid && gl == 0) a.status[b] = cvx::ST_UNCERTIFIED; return; }
-    if (MODE == 2) { // every survivor goes to the queue of the resume kernel launched behind this one: no wave-per-problem code in this kernel
+    if (MODE == 1 || MODE == 2) { // every survivor (MODE 1: every problem -- it makes no attempts) goes to the queue of the resume kernel launched behind this one: no wave-per-problem code in this kernel
         if (parked && gvalid && gl == 0) {
             const int q = atomicAdd(qcount, 1);
             qentries[q] = (int32_t)b;

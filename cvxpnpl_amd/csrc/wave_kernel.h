@@ -514,9 +514,6 @@ struct WaveArgs {
 // off the tail of every launch: the slowest problems are exactly the handed-over ones).
 constexpr int F32_SWEEPS_UNTIL = cvx::F32_SWEEPS_DEFAULT; // eigen-solve sweeps in single precision during the first iterations of a solve; Opts::f32_sweeps_until overrides (0: never)
 constexpr int RS_W = 0, RS_IT = 55, RS_LANE = 56;           // lane schedule: 56 doubles per problem
-#ifdef CVXW_ORACLE_SCHED
-__device__ int g_oracle_hint[1 << 20];
-#endif
 constexpr int RS_Q = 56, RS_B = 112, RS_NC = 139, RS_V = 140, RS_FULL = 240; // quad schedule: + Q (55, vech order, 0 outside the 9x9 block), B (27), the iteration of the next certificate attempt, V (100: [column][row])
 
 // Solve problem b with the wavefront that calls this.  resume (optional): 56 doubles written by
@@ -792,10 +789,6 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
         if (resume_full) { // the attempt schedule of the first phase goes on (an attempt costs two to three iterations)
             const int nc = (int)rd(RS_NC);
             next_check = nc > next_check ? nc : next_check;
-#ifdef CVXW_ORACLE_SCHED // experiment: the first attempt of the second phase at the iteration the previous launch certified at
-            const int h = g_oracle_hint[b & 0xfffff];
-            if (h > it && h < 200) next_check = h > next_check ? h : next_check;
-#endif
         }
         cold = true;
         if (resume_full && it > 0 && !canon) { // the eigenvectors of the last iterate come along: warm start
@@ -1333,9 +1326,6 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
         a.t[b * 3 + lane] = have_pose ? -tv : NAN;
     }
     if (lane == 0) {
-#ifdef CVXW_ORACLE_SCHED
-        g_oracle_hint[b & 0xfffff] = it;
-#endif
         a.status[b] = status;
         if (a.iters) a.iters[b] = it;
         if (a.cost) { a.cost[2 * b] = have_pose ? L[L_M + 25] : NAN; a.cost[2 * b + 1] = have_pose ? L[L_M + 26] : NAN; }

@@ -89,24 +89,75 @@ def gather_results(packed_local: torch.Tensor, batch: int, group=None, out: Opti
     return out
 
 
-def solve_sharded(pts_2d, line_2d, pts_3d, line_3d, K, group=None, solver: Optional[Callable] = None, **kw):
-    """Every rank holds (or can index) the full inputs; it solves its own slice and all ranks
-    end with the full R [B,3,3], t [B,3], status [B].  `solver` defaults to
-    cvxpnpl_amd.pnpl_batch (HIP); tests inject a CPU stand-in to exercise the sharding and
-    the collective on gloo."""
+def gather_to_root(packed_local: torch.Tensor, batch: int, group=None, out: Optional[torch.Tensor] = None, async_op: bool = False,
+                   root: int = 0):
+    """The exchange when ONE rank consumes the poses: `dist.gather` of equal [n, 13] slices to `root` (every other rank only sends:
+    1/N of the all-gather's bytes on its links, nothing received).  Returns (out, work): out is the [batch, 13] tensor on root, None
+    elsewhere; with async_op the caller waits on `work` before reading it.  Ragged shards: pad to the largest one first (as bench.py does)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = packed_local.shape[0]
+    assert n * world == batch, "gather_to_root needs equal (padded) shards"
+    chunks = None
+    if rank == root:
+        if out is None:
+            out = torch.empty((batch, PACK), dtype=torch.float64, device=packed_local.device)
+        chunks = list(out.split(n))
+    work = dist.gather(packed_local.contiguous(), chunks, dst=dist.get_global_rank(group, root) if group is not None else root, group=group,
+                       async_op=async_op)
+    return (out if rank == root else None), work
+
+
+def solve_sharded(pts_2d, line_2d, pts_3d, line_3d, K, group=None, solver: Optional[Callable] = None, inputs_are_shards: bool = False,
+                  to_root: bool = False, **kw):
+    """Solve a batch over the ranks of `group` and exchange the poses; returns (R [B,3,3], t [B,3], status [B]) of the WHOLE batch on
+    every rank (on rank 0 only, None elsewhere, with to_root).
+
+    inputs_are_shards=False: every rank holds (or can index) the full inputs and solves its own contiguous slice (shard_range).
+    inputs_are_shards=True: every rank passes ITS OWN slice only -- what a data loader per GPU produces; nothing but results crosses a
+    link.  Shard sizes are agreed with one small all_gather of the local counts and may be ragged; the result order is rank order.
+    `solver` defaults to cvxpnpl_amd.pnpl_batch (HIP); tests inject a CPU stand-in to exercise the sharding and the collective on gloo."""
     if solver is None:
         from .api import pnpl_batch as solver
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     ref = pts_3d if pts_3d is not None else line_3d
-    batch = ref.shape[0]
-    lo, hi = shard_range(batch, rank, world)
+    if inputs_are_shards:
+        res = solver(pts_2d, line_2d, pts_3d, line_3d, K, **kw)
+        n_local = int(ref.shape[0])
+    else:
+        batch = ref.shape[0]
+        lo, hi = shard_range(batch, rank, world)
 
-    def sl(x):
-        return None if x is None else x[lo:hi]
+        def sl(x):
+            return None if x is None else x[lo:hi]
 
-    Kl = K[lo:hi] if getattr(K, "ndim", 2) == 3 else K
-    res = solver(sl(pts_2d), sl(line_2d), sl(pts_3d), sl(line_3d), Kl, **kw)
+        Kl = K[lo:hi] if getattr(K, "ndim", 2) == 3 else K
+        res = solver(sl(pts_2d), sl(line_2d), sl(pts_3d), sl(line_3d), Kl, **kw)
+        n_local = hi - lo
     packed = pack_results(torch.as_tensor(res["R"]), torch.as_tensor(res["t"]), torch.as_tensor(res["status"]))
-    full = gather_results(packed, batch, group=group)
-    return unpack_results(full)
+    if not inputs_are_shards and not to_root:
+        return unpack_results(gather_results(packed, batch, group=group))
+    # shard sizes as the ranks report them (they need not follow shard_range), padded to the largest: one collective of equal slices
+    counts = torch.zeros(world, dtype=torch.int64, device=packed.device)
+    counts[rank] = n_local
+    dist.all_reduce(counts, group=group)
+    sizes = [int(c) for c in counts.tolist()]
+    nmax = max(sizes)
+    buf = packed
+    if n_local != nmax:
+        buf = torch.zeros((nmax, PACK), dtype=torch.float64, device=packed.device)
+        buf[:n_local] = packed
+    if to_root:
+        full_p, _ = gather_to_root(buf, nmax * world, group=group)
+        if full_p is None:
+            return None
+    else:
+        full_p = torch.empty((nmax * world, PACK), dtype=torch.float64, device=packed.device)
+        if dist.get_backend(group) == "nccl":
+            dist.all_gather_into_tensor(full_p, buf.contiguous(), group=group)
+        else:
+            dist.all_gather(list(full_p.split(nmax)), buf.contiguous(), group=group)
+    if all(sz == nmax for sz in sizes):
+        return unpack_results(full_p)
+    return unpack_results(torch.cat([full_p[r * nmax:r * nmax + sizes[r]] for r in range(world)]))

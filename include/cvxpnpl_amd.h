@@ -38,7 +38,7 @@ enum {
     CVXPNPL_REFLECTION = 4   /* uncertified and det(U V^T) < 0; returned as is, like the reference (:510-511) */
 };
 
-/* kernel layouts (A/B switch; all produce the same results) */
+/* kernel layouts (A/B switch; all produce the same results).  Any other value of opts.layout is refused ("bad options", -1). */
 enum {
     CVXPNPL_LAYOUT_AUTO = 0, /* by launch size: wave below 2560 problems, quad below 20000, lane (hybrid) from there; four-correspondence
                                 problems: quad from 2560 on, with a 24-iteration first phase and the first attempt after 7 */
@@ -263,6 +263,14 @@ int cvxpnpl_pack_results(int64_t batch, const double *d_R, const double *d_t, co
    checks after its warm-up and again after its timed region, and repeats a region in which a wait gave up. */
 int cvxpnpl_stream_write_value(uint64_t *d_flag, uint64_t value, void *stream);
 int cvxpnpl_stream_wait_value(uint64_t *d_flag, uint64_t value, void *stream);
+/* The same wait with the bound as a parameter: max_polls polls of ~1 us each before it gives up (cvxpnpl_stream_wait_value uses 2^18, about
+   0.25 s -- shorter than a legitimate large step can be); 0 = unbounded: never fails open, and hangs the consumer stream for good if the
+   two streams do share a hardware queue -- only for callers that have established (one bounded wait, checked) that they do not. */
+int cvxpnpl_stream_wait_value_bounded(uint64_t *d_flag, uint64_t value, uint64_t max_polls, void *stream);
+/* The check a consumer of bounded waits owes (see above), as a call that cannot be forgotten half-way: synchronises `stream` (the
+   consumer's: everything the waits ordered is then complete or known to be unusable), returns 1 if a wait on this flag has given up since the
+   word was last cleared, 0 if none has, negative for an error; clear != 0 resets the word (on `stream`) after reading it. */
+int cvxpnpl_stream_wait_gave_up(uint64_t *d_flag, int32_t clear, void *stream);
 
 /*
  * Consensus scoring of pose hypotheses against one scene (RANSAC on top of the solver: BASELINE config 5;

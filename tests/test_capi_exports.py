@@ -66,6 +66,29 @@ def test_opts_struct_is_size_guarded(L):
     assert rc == -1 and b"options block" in L.cvxpnpl_last_error()
 
 
+def test_unknown_layouts_are_refused(L):
+    """opts.layout outside the public enum (the experiment layouts 9-13 of rounds 2-4 live in experiment builds only) is a launch-level
+    error, not a silent fall-through to some kernel (round-4 advisor; argument check only: no launch, no GPU needed)"""
+    from cvxpnpl_amd import _lib
+
+    dummy = (C.c_double * 64)()
+    p = C.cast(dummy, C.c_void_p)
+    for bad in (-1, 5, 9, 10, 11, 12, 13, 99):
+        o = _lib.default_opts(layout=bad)
+        rc = L.cvxpnpl_solve_batch(1, 4, p, p, 0, None, None, p, 0, C.byref(o), p, p, p, None, None, None, None, None)
+        assert rc == -1 and b"layout" in L.cvxpnpl_last_error(), (bad, rc, L.cvxpnpl_last_error())
+        rc = L.cvxpnpl_solve_cost_batch(1, p, p, C.byref(o), p, p, p, None, None, None, None, None)
+        assert rc == -1 and b"layout" in L.cvxpnpl_last_error()
+
+
+def test_empty_sampling_call_is_a_no_op(L):
+    """n_hyp == 0 returns 0 whatever the (empty, possibly NULL) output pointers are (round-4 advisor: the null check used to come first)"""
+    dummy = (C.c_double * 64)()
+    p = C.cast(dummy, C.c_void_p)
+    assert L.cvxpnpl_sample_minimal_sets(0, 100, p, p, 4, 1, None, None, None, None) == 0
+    assert L.cvxpnpl_sample_minimal_sets(-1, 100, p, p, 4, 1, None, p, p, None) == -1
+
+
 def test_integration_doc_mirrors_the_opts_struct():
     """INTEGRATION.md's ctypes block is generated from _lib.Opts (tools/gen_integration_opts.py): field names, order, types"""
     from cvxpnpl_amd import _lib

@@ -134,3 +134,49 @@ def test_shard_range_partitions_the_batch():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _worker_shards(rank, world, port, sizes, out_dir):
+    """every rank brings ITS OWN slice only (what a per-GPU loader produces): uneven shard sizes that do not follow shard_range"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cvxpnpl_amd import dist as cd
+
+    batch = sum(sizes)
+    p2, p3, K = _big_inputs(batch)
+    lo = sum(sizes[:rank])
+    hi = lo + sizes[rank]
+    mine = (torch.as_tensor(p2[lo:hi]), None, torch.as_tensor(p3[lo:hi]), None, K)
+    R, t, st = cd.solve_sharded(*mine, solver=_cheap_solver, inputs_are_shards=True)
+    root = cd.solve_sharded(*mine, solver=_cheap_solver, inputs_are_shards=True, to_root=True)
+    assert (root is None) == (rank != 0)
+    if rank == 0:
+        assert torch.equal(root[0], R) and torch.equal(root[1], t) and torch.equal(root[2], st)
+    # gather_to_root with equal (padded) slices, overlapped form
+    n = max(sizes)
+    pk = torch.zeros((n, cd.PACK), dtype=torch.float64)
+    pk[: sizes[rank]] = cd.pack_results(R[lo:hi], t[lo:hi], st[lo:hi])
+    out, work = cd.gather_to_root(pk, n * world, async_op=True)
+    work.wait()
+    if rank == 0:
+        for r in range(world):
+            a = sum(sizes[:r])
+            assert torch.equal(out[r * n:r * n + sizes[r]], cd.pack_results(R[a:a + sizes[r]], t[a:a + sizes[r]], st[a:a + sizes[r]]))
+    else:
+        assert out is None
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), R=R.numpy(), t=t.numpy(), st=st.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_per_rank_input_shards_and_gather_to_root(tmp_path):
+    """solve_sharded(inputs_are_shards=True): ranks hold only their own problems (sizes 5, 0 is not allowed by the solver stand-in, so 5, 9, 2), every
+    rank ends with the whole result in rank order; to_root=True leaves it on rank 0 only; gather_to_root delivers every slice"""
+    sizes = [5, 9, 2]
+    mp.spawn(_worker_shards, args=(3, _free_port(), sizes, str(tmp_path)), nprocs=3, join=True)
+    p2, p3, K = _big_inputs(sum(sizes))
+    ref = _cheap_solver(p2, None, p3, None, K)
+    for r in range(3):
+        got = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        assert np.array_equal(got["R"], ref["R"]) and np.array_equal(got["t"], ref["t"]) and np.array_equal(got["st"], ref["status"])

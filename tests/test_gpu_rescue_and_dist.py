@@ -155,6 +155,7 @@ def test_bench_two_ranks_sharing_the_device(gpu):  # noqa: F811
     assert col["distinct_devices"] == 1 and "gloo" in col["backend"]
     g = col["gather_ms_per_step"]
     assert g["alone"] > 0 and g["exposed"] >= 0 and g["hidden"] >= 0 and g["bytes_received_per_rank_per_step"] == 2 * 10000 * 13 * 8, g
+    assert g["in_flight"] == 2 and col["gather_check"]["held_by"] == "every rank"
     assert "slowest rank" in col["value_is"] and col["handover"]
 
 
@@ -167,6 +168,40 @@ def test_bench_strong_scaling_with_ragged_shards(gpu):  # noqa: F811
     assert sorted(x["problems_per_step"] for x in col["per_rank"]) == [5000, 5001], col["per_rank"]
     assert col["gather_check"]["all_ranks_ok"] and col["gather_check"]["records"] == 2 * 5001, col
     assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 10001) < 1e-6 * 10001
+
+
+def test_bench_config4_eight_ranks_on_one_device(gpu):  # noqa: F811
+    """north-star config 4's shape end to end on the 1-GPU box: `--gpus 8 --scaling strong --total 1000000` = eight ranks (sharing the device,
+    records through gloo: RCCL needs a device per rank), 125 000 problems each, one exchange of 8 x 125 000 records per step with two in
+    flight; the line must prove all eight ranks took part and price the exchange"""
+    out = _run_bench(["--gpus", "8", "--backend", "gloo", "--scaling", "strong", "--total", "1000000", "--workload", "pnp_n10_125k", "--no-transfer"], timeout=1500)
+    col = out["config"]["collective"]
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and col["ranks"] == 8 and col["ranks_seen"] == 8, col
+    assert [x["rank"] for x in col["per_rank"]] == list(range(8)) and all(x["problems_per_step"] == 125000 for x in col["per_rank"])
+    assert col["gather_check"]["all_ranks_ok"] and col["gather_check"]["records"] == 1000000 and col["gather_check"]["held_by"] == "every rank"
+    g = col["gather_ms_per_step"]
+    assert g["bytes_received_per_rank_per_step"] == 1000000 * 13 * 8 and g["in_flight"] == 2 and g["alone"] > 0, g
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 1000000) < 1.0
+    assert out["dtype"] == "f64" and out["solver"]["certified_frac"] > 0.999
+
+
+def test_bench_gather_to_root(gpu):  # noqa: F811
+    """--collective gather: one consumer -- only rank 0 receives the records"""
+    out = _run_bench(["--gpus", "2", "--backend", "gloo", "--collective", "gather"], timeout=600)
+    col = out["config"]["collective"]
+    assert col["ranks_seen"] == 2 and col["gather_check"]["all_ranks_ok"] and col["gather_check"]["held_by"] == "rank 0", col
+    assert "gather to rank 0" in col["exchange"]
+    assert col["gather_ms_per_step"]["bytes_received_per_rank_per_step"] == {"rank 0": 2 * 10000 * 13 * 8, "other ranks": 0}
+
+
+def test_bench_headline_is_reference_precision(gpu):  # noqa: F811
+    """the default line is timed with every sweep in float64 (the reference's precision, cvxpnpl.py:475-513); the library's default mode is
+    reported beside it, with identical statuses and certified poses to 1e-9 rad"""
+    out = _run_bench(["--no-transfer"])
+    assert out["dtype"] == "f64" and out["value_all_f64"] == out["value"] and "mixed" in out and out["value_mixed"] == out["mixed"]["value"]
+    assert out["mixed"]["status_equal_to_timed_region_frac"] == 1.0 and out["mixed"]["max_rot_diff_vs_timed_region_rad"] < 1e-9
+    out = _run_bench(["--no-transfer", "--precision", "mixed"])
+    assert out["dtype"].startswith("f64 (f32") and "all_f64" in out and out["value_all_f64"] == out["all_f64"]["value"]
 
 
 def test_bench_config5_workload(gpu):  # noqa: F811

@@ -7,9 +7,8 @@
 //            steps 1, 3, 5, 7 are ds_bpermute steps in which a lane may take over the PARTNER's rotated column (a swap costs nothing:
 //            both lanes hold both columns).  Still 9 steps and every pair exactly once (the tables below come from a search,
 //            tools/microbench/jacobi_orderings.py), LDS round trips per sweep 9 -> 4.
-//   SCHED 2  (timing bound only, not an ordering) every step a DPP step: same partner every time
-//   SCHED 3  odd-even transposition ordering, no LDS at all: 10 steps, A = lanes (2k, 2k+1) as above, B = lanes (2k+1, 2k+2) by
-//            row_shl:1 / row_shr:1 (two DPP operands per element, the unwanted one weighted 0), columns swap at every step
+//   SCHED 2  (timing bound only, NOT an ordering: it does not converge) every step a DPP step, same partner every time -- what a sweep
+//            without any LDS round trip would cost; no such nine-step ordering exists (jacobi_orderings.py)
 //   CS 0     rotation from t = g2 / (|d| + h): v_rsq, v_rcp, v_rsq (pair_cs of quad_kernel.h)
 //   CS 1     rotation from the half-angle identities: c^2 = (h + |d|) / 2h, s c = g2 / 2h: two v_rsq, no v_rcp
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o eig16x eig16x.hip ; run: ./eig16x [batch] [max_sweeps] [tol] [waves_per_simd]
@@ -77,8 +76,6 @@ __device__ __forceinline__ float bpermf(int addr, float v) { return __int_as_flo
 // (GCNDPPCombine leaves all of them), so the two blocks are written by hand.  s_nop 4 in front: the hazard recogniser does not look
 // inside inline asm (VALU write -> DPP read of the same VGPR needs 2 wait states, EXEC write -> DPP 5).
 #define DPP_XOR1 "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:0"
-#define DPP_SHL1 "row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
-#define DPP_SHR1 "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
 // sum_i q_i * q_i[partner]
 #define DOT10_DPP(CTRL, g0, g1, e)                                                                                                  \
     asm volatile("s_nop 4\n\t"                                                                                                      \
@@ -266,94 +263,6 @@ template <int CS> __device__ __forceinline__ void step_dpp(Col<double> &x, doubl
     al = fma(-t, gam, al);
 }
 
-// ---- odd-even transposition, B step: lanes (2k+1, 2k+2); up = this lane pairs with lane + 1, dn = with lane - 1 (neither: idle)
-template <int CS> __device__ __forceinline__ void step_oe_b(Col<float> &x, float &al, bool up, bool dn, bool active, float tol2, bool &coarse)
-{
-    float e[10], u0, u1, d0, d1;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) { e[2 * i] = x.q[i].x; e[2 * i + 1] = x.q[i].y; }
-    DOT10_DPP(DPP_SHL1, u0, u1, e); // row_shl:1 = lane + 1
-    DOT10_DPP(DPP_SHR1, d0, d1, e); // row_shr:1 = lane - 1
-    const float gam = up ? u0 + u1 : d0 + d1;
-    const float be = up ? dppf<0x101>(al) : dppf<0x111>(al);
-    const bool real = up || dn;
-    const float g2 = gam * gam, ab = al * be;
-    coarse |= real && g2 > tol2 * ab;
-    float c, s, t;
-    pair_cs<CS>(be - al, gam, active && real && g2 > 1e-30f * ab, dn, c, s, t);
-    // columns swap: this lane takes the partner's rotated column s own + c other; idle lanes keep theirs
-    const float ka = real ? s : 1.0f, ku = up ? c : 0.0f, kd = dn ? c : 0.0f;
-    const f2 ka2 = {ka, ka};
-    float n[10];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) { const f2 p = ka2 * x.q[i]; n[2 * i] = p.x; n[2 * i + 1] = p.y; }
-    AXPY10_DPP(DPP_SHL1, n, e, ku);
-    AXPY10_DPP(DPP_SHR1, n, e, kd);
-#pragma unroll
-    for (int i = 0; i < 5; ++i) { x.q[i].x = n[2 * i]; x.q[i].y = n[2 * i + 1]; }
-    al = real ? fmaf(t, gam, be) : al;
-}
-template <int CS> __device__ __forceinline__ void step_oe_b(Col<double> &x, double &al, bool up, bool dn, bool active, double tol2, bool &coarse)
-{
-    double o[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) { const double a = dppd<0x101>(x.q[i]), b = dppd<0x111>(x.q[i]); o[i] = up ? a : b; }
-    const double be = up ? dppd<0x101>(al) : dppd<0x111>(al);
-    const bool real = up || dn;
-    double gam = 0.0;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) gam = fma(x.q[i], o[i], gam);
-    const double g2 = gam * gam, ab = al * be;
-    coarse |= real && g2 > tol2 * ab;
-    double c, s, t;
-    pair_cs<CS>(be - al, gam, active && real && g2 > 1e-30 * ab, dn, c, s, t);
-    const double ka = real ? s : 1.0, kb = real ? c : 0.0;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) x.q[i] = fma(ka, x.q[i], kb * o[i]);
-    al = real ? fma(t, gam, be) : al;
-}
-// A step of the odd-even ordering: the DPP step with the swap (take the partner's column)
-template <int CS> __device__ __forceinline__ void step_oe_a(Col<float> &x, float &al, bool real, bool tie_neg, bool active, float tol2, bool &coarse)
-{
-    float e[10], g0, g1;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) { e[2 * i] = x.q[i].x; e[2 * i + 1] = x.q[i].y; }
-    DOT10_DPP(DPP_XOR1, g0, g1, e);
-    const float gam = g0 + g1;
-    const float be = dppf<0xB1>(al);
-    const float g2 = gam * gam, ab = al * be;
-    coarse |= real && g2 > tol2 * ab;
-    float c, s, t;
-    pair_cs<CS>(be - al, gam, active && real && g2 > 1e-30f * ab, tie_neg, c, s, t);
-    const float ka = real ? s : 1.0f, kb = real ? c : 0.0f;
-    const f2 ka2 = {ka, ka};
-    float n[10];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) { const f2 p = ka2 * x.q[i]; n[2 * i] = p.x; n[2 * i + 1] = p.y; }
-    AXPY10_DPP(DPP_XOR1, n, e, kb);
-#pragma unroll
-    for (int i = 0; i < 5; ++i) { x.q[i].x = n[2 * i]; x.q[i].y = n[2 * i + 1]; }
-    al = real ? fmaf(t, gam, be) : al;
-}
-template <int CS> __device__ __forceinline__ void step_oe_a(Col<double> &x, double &al, bool real, bool tie_neg, bool active, double tol2, bool &coarse)
-{
-    double o[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) o[i] = dppd<0xB1>(x.q[i]);
-    const double be = dppd<0xB1>(al);
-    double gam = 0.0;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) gam = fma(x.q[i], o[i], gam);
-    const double g2 = gam * gam, ab = al * be;
-    coarse |= real && g2 > tol2 * ab;
-    double c, s, t;
-    pair_cs<CS>(be - al, gam, active && real && g2 > 1e-30 * ab, tie_neg, c, s, t);
-    const double ka = real ? s : 1.0, kb = real ? c : 0.0;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) x.q[i] = fma(ka, x.q[i], kb * o[i]);
-    al = real ? fma(t, gam, be) : al;
-}
-
 // W: [batch][55] packed upper triangle (row-major); lam_out [batch][10]; g_out [batch][10 lanes][10 rows] (the rotated columns)
 template <class T, int SCHED, int CS>
 __global__ __launch_bounds__(64) void eigx_kernel(const double *W, double *lam_out, int *sw_out, double *g_out, int batch, int max_sweeps, double tol2d)
@@ -414,15 +323,9 @@ __global__ __launch_bounds__(64) void eigx_kernel(const double *W, double *lam_o
                     step_bperm<CS>(x, al, base4 + (partner << 2), partner != gl, gl > partner, ((atab >> (16 + s)) & 1) != 0, active, tol2, coarse);
                 }
             }
-        } else if (SCHED == 2) {
-#pragma unroll
-            for (int st = 0; st < 9; ++st) step_dpp<CS>(x, al, col_lane, (gl & 1) != 0, active, tol2, coarse);
         } else {
 #pragma unroll
-            for (int st = 0; st < 10; ++st) {
-                if ((st & 1) == 0) step_oe_a<CS>(x, al, col_lane, (gl & 1) != 0, active, tol2, coarse);
-                else step_oe_b<CS>(x, al, (gl & 1) && gl < 9, !(gl & 1) && gl >= 2 && gl <= 8, active, tol2, coarse);
-            }
+            for (int st = 0; st < 9; ++st) step_dpp<CS>(x, al, col_lane, (gl & 1) != 0, active, tol2, coarse);
         }
         al = x.norm2(); // exact norm once per sweep
         const unsigned long long m = __ballot(coarse && active);
@@ -446,8 +349,7 @@ template <class T, int CS> static kern_t pick_sched(int sched)
     switch (sched) {
     case 0: return eigx_kernel<T, 0, CS>;
     case 1: return eigx_kernel<T, 1, CS>;
-    case 2: return eigx_kernel<T, 2, CS>;
-    default: return eigx_kernel<T, 3, CS>;
+    default: return eigx_kernel<T, 2, CS>;
     }
 }
 
@@ -474,7 +376,7 @@ int main(int argc, char **argv)
     CHECK(hipEventCreate(&e1));
     for (int prec = 0; prec < 2; ++prec)
         for (int cs = 0; cs < 2; ++cs)
-            for (int sched = 0; sched < 4; ++sched) {
+            for (int sched = 0; sched < 3; ++sched) {
                 kern_t k = prec == 0 ? (cs == 0 ? pick_sched<float, 0>(sched) : pick_sched<float, 1>(sched)) : (cs == 0 ? pick_sched<double, 0>(sched) : pick_sched<double, 1>(sched));
                 CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
                 for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(blocks), dim3(64), dyn_lds, 0, dW, dl, dsw, dg, batch, max_sweeps, tol * tol);
