@@ -255,6 +255,35 @@ def solve_cost_batch(Q45, B27, eps: float = 1e-9, max_iters: int = 2500, want_Z:
     return out
 
 
+def ipm_batch(Q45, variant: int = _lib.VARIANT_FULL, device=None):
+    """The interior-point solve of the relaxation alone (cvxpnpl_ipm_batch; four problems per wavefront, csrc/ipm_quad.h): Q45 [B,45]
+    packed A^T A (pack_cost / assemble_batch; any positive scale -- it is normalised to trace 1 here) -> Z [B,10,10], S [B,10,10]
+    (primal / dual iterates of  min <Q/tr Q, Z> s.t. the reference's equality rows, cvxpnpl.py:387-451), gap [B] = <Z, S>, iters [B].
+    No rounding, polish or certificate: what opts.rescue_from runs for a slow problem before the first-order iteration takes over again."""
+    _require_gpu()
+    L = _lib.lib()
+    if device is None:
+        device = Q45.device if isinstance(Q45, torch.Tensor) and Q45.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    Qd = _as_dev(Q45, device, (45,)).reshape(-1, 45)
+    batch = Qd.shape[0]
+    di = torch.as_tensor(np.flatnonzero(_IU9[0] == _IU9[1]), device=device)
+    Qn = Qd / Qd[:, di].sum(dim=1, keepdim=True)
+    iu10 = np.triu_indices(10)
+    sel = torch.as_tensor(np.flatnonzero((iu10[0] < 9) & (iu10[1] < 9)), device=device)
+    Qs = torch.zeros((batch, 55), dtype=torch.float64, device=device)
+    Qs[:, sel] = Qn  # (vech order of the 10 x 10 = the 9 x 9 rows with one more column each)
+    with torch.cuda.device(device):
+        Z = torch.empty((batch, 10, 10), dtype=torch.float64, device=device)
+        S = torch.empty((batch, 10, 10), dtype=torch.float64, device=device)
+        gap = torch.empty((batch,), dtype=torch.float64, device=device)
+        iters = torch.empty((batch,), dtype=torch.int32, device=device)
+        rc = L.cvxpnpl_ipm_batch(batch, _ptr(Qs), int(variant), _ptr(Z), _ptr(S), _ptr(gap), _ptr(iters), C.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"cvxpnpl_ipm_batch failed ({rc}): {_lib.last_error()}")
+    return Z, S, gap, iters  # (iters: iterations | reason << 8, see cvxpnpl_ipm_batch)
+
+
 def _poses_of_single(res, Bt, Qt, verbose, certify_warning=True) -> List[Tuple[np.ndarray, np.ndarray]]:
     """List[(R, t)] of a one-problem BatchResult, with the reference's NaN sentinel (cvxpnpl.py:493-498), rank > 1
     branch (:507) and "not certifiably optimal" warning (:516-519)."""

@@ -10,7 +10,7 @@ HOST_SRC = os.path.join(HERE, "csrc", "host_recover.cpp")
 OUT = os.path.join(HERE, "libcvxpnpl_amd.so")
 DEPS = [SRC, HOST_SRC, os.path.join(HERE, "csrc", "solver_core.h"), os.path.join(HERE, "csrc", "problem_io.h"),
         os.path.join(HERE, "csrc", "wave_kernel.h"), os.path.join(HERE, "csrc", "quad_kernel.h"), os.path.join(HERE, "csrc", "score_kernel.h"), os.path.join(HERE, "csrc", "assemble_kernel.h"), os.path.join(HERE, "csrc", "synth_kernel.h"), os.path.join(HERE, "csrc", "recover_core.h"), os.path.join(HERE, "csrc", "recover_kernel.h"),
-        os.path.join(HERE, "csrc", "ipm_core.h"), os.path.join(HERE, "csrc", "ipm_wave.h"), os.path.join(HERE, "csrc", "lane_core.h"),
+        os.path.join(HERE, "csrc", "ipm_core.h"), os.path.join(HERE, "csrc", "ipm_wave.h"), os.path.join(HERE, "csrc", "ipm_quad.h"), os.path.join(HERE, "csrc", "lane_core.h"),
         os.path.join(os.path.dirname(HERE), "include", "cvxpnpl_amd.h")]
 
 

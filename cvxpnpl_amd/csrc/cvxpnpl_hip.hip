@@ -16,6 +16,7 @@
 #include "lane_core.h"
 #include "wave_kernel.h"
 #include "quad_kernel.h"
+#include "ipm_quad.h"
 #include "score_kernel.h"
 #include "assemble_kernel.h"
 #include "synth_kernel.h"
@@ -245,20 +246,20 @@ void launch_rescue(int64_t batch, hipStream_t s, const cvxw::WaveArgs &w, const 
     else hipLaunchKernelGGL(cvxw::rescue_wave_kernel, dim3((unsigned)(count ? 2 * rgrid : rgrid)), dim3(64), 0, s, ra);
 }
 
-#ifdef CVXW_SPLIT_IPM
-// split interior-point path: the rescue queue through cvxw::ipm_wave_kernel into the resume queue (a launch of the resume kernel follows)
+// split interior-point path: the rescue queue through cvxi::ipm_quad_kernel (four solves per wavefront, ipm_quad.h) into the resume queue
+// (a launch of the resume kernel follows)
 void launch_ipm(int64_t batch, hipStream_t s, const cvxw::WaveArgs &w, const cvx::Opts &o, int32_t *count, int32_t *entries)
 {
-    const int64_t grid = batch < cvxw::IPM_GRID_MAX ? batch : cvxw::IPM_GRID_MAX;
-    cvxw::IpmArgs ia;
+    const int64_t groups = (batch + 3) / 4;
+    const int64_t grid = groups < cvxi::IPMQ_GRID_MAX ? groups : cvxi::IPMQ_GRID_MAX;
+    cvxi::IpmQuadArgs ia;
     ia.batch = batch; ia.rho = o.rho; ia.rho_tail = o.rho_tail; ia.tail_from = o.tail_from;
     ia.rq_count = w.rq_count; ia.rq_entries = w.rq_entries; ia.count = count; ia.entries = entries; ia.ws = w.rq_ws; ia.stride = w.rq_stride;
-    if (o.variant == cvx::VAR_RC) hipLaunchKernelGGL(cvxw::ipm_wave_kernel<cvx::VAR_RC>, dim3((unsigned)grid), dim3(64), 0, s, ia);
-    else hipLaunchKernelGGL(cvxw::ipm_wave_kernel<cvx::VAR_FULL>, dim3((unsigned)grid), dim3(64), 0, s, ia);
+    ia.entries_cap = (int)(batch + cvxw::RESUME_GRID_MAX < 0x7fffffffLL ? batch + cvxw::RESUME_GRID_MAX : 0x7fffffffLL);
+    ia.qs_in = nullptr; ia.z_out = nullptr; ia.s_out = nullptr; ia.gap_out = nullptr; ia.it_out = nullptr;
+    if (o.variant == cvx::VAR_RC) hipLaunchKernelGGL(cvxi::ipm_quad_kernel<cvx::VAR_RC>, dim3((unsigned)grid), dim3(64), 0, s, ia);
+    else hipLaunchKernelGGL(cvxi::ipm_quad_kernel<cvx::VAR_FULL>, dim3((unsigned)grid), dim3(64), 0, s, ia);
 }
-#else
-void launch_ipm(int64_t, hipStream_t, const cvxw::WaveArgs &, const cvx::Opts &, int32_t *, int32_t *) {}
-#endif
 
 int set_err(const char *what, hipError_t e)
 {
@@ -477,10 +478,10 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     // behind the first kernel) where it is a safety net -- seven correspondences and more: its queue is empty in nearly every launch and
     // one more (empty) launch would cost the 10 k-problem step 2 %.  Split (cvxw::ipm_wave_kernel + the plain resume kernel) where
     // problems really go through it -- at most six correspondences, the 16-equality variant: a fifth of the four-point problems.
-#ifdef CVXW_SPLIT_IPM
-    const bool split = rescue && (rc || (!a.Q45 && a.n_p + a.n_l <= 6));
+#ifndef CVXPNPL_FUSED_IPM
+    const bool split = rescue && (rc || (!a.Q45 && a.n_p + a.n_l <= 5)); // (measured, split / fused, M poses/s: N = 4 50 k 17.96 / 15.07, config 5 25.6 / 24.7, N = 5 100 k 37.3 / 35.8, N = 6 125 k 73.1 / 75.5: profiles/r05/ipm_quad_ab.txt)
 #else
-    const bool split = false; // measured (profiles/r04/split_ipm_experiment.txt): the split path loses -- see there and DESIGN.md section 9
+    const bool split = false; // (A/B builds: every workload through the fused kernel, as until round 4)
 #endif
     WsView wv = {nullptr, nullptr, nullptr, nullptr, nullptr};
     const int ws_stride = layout == CVXPNPL_LAYOUT_QUAD ? cvxw::RS_FULL : ((lane_hybrid || split) ? cvxw::RS_LANE : 0);
@@ -845,6 +846,24 @@ int cvxpnpl_release_workspace(void *stream, int32_t all_streams)
         g_ws.erase(it);
     }
     return 0;
+}
+
+int cvxpnpl_ipm_batch(int64_t batch, const double *d_Qs55, int32_t variant, double *d_Z100, double *d_S100, double *d_gap, int32_t *d_iters, void *stream)
+{
+    if (batch < 0 || !d_Qs55 || !d_Z100 || !d_S100 || !d_gap || !d_iters || (variant != CVXPNPL_VARIANT_FULL && variant != CVXPNPL_VARIANT_RC) || (batch + 3) / 4 > 0x7fffffffLL) {
+        snprintf(g_err, sizeof(g_err), "cvxpnpl_ipm_batch: bad arguments");
+        return -1;
+    }
+    if (batch == 0) return 0;
+    cvxi::IpmQuadArgs ia;
+    memset(&ia, 0, sizeof(ia));
+    ia.batch = batch; ia.rho = 1.0; ia.rho_tail = 1.0;
+    ia.qs_in = d_Qs55; ia.z_out = d_Z100; ia.s_out = d_S100; ia.gap_out = d_gap; ia.it_out = d_iters;
+    const unsigned grid = (unsigned)((batch + 3) / 4);
+    if (variant == CVXPNPL_VARIANT_RC) hipLaunchKernelGGL(cvxi::ipm_quad_kernel<cvx::VAR_RC>, dim3(grid), dim3(64), 0, (hipStream_t)stream, ia);
+    else hipLaunchKernelGGL(cvxi::ipm_quad_kernel<cvx::VAR_FULL>, dim3(grid), dim3(64), 0, (hipStream_t)stream, ia);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : set_err("ipm_quad_kernel launch", e);
 }
 
 int cvxpnpl_calibration_copy(const void *d_src, void *d_dst, int64_t nbytes, int32_t bytes_per_lane, void *stream)

@@ -555,11 +555,7 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
     // interior-point solution, ALREADY in the solver's frame, nothing else -- the problem is assembled again whatever the slot format,
     // the first eigen-solve is cold, the attempt comes one iteration later, and the problem neither goes back to the rescue queue nor
     // runs more than IPM_GRACE further iterations (what after_ipm means in the fused kernel).
-#ifdef CVXW_SPLIT_IPM // (experiment of round 4, measured and not built in: profiles/r04/split_ipm_experiment.txt)
     const bool post_ipm = !IPM && resume && __hip_atomic_load(resume + RS_IT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0.0; // wave-uniform
-#else
-    constexpr bool post_ipm = false;
-#endif
     const bool resume_full = resume_full_in && !post_ipm;
     // ---------------------------------------------------------------- assembly
     bool okK = true, okG = true;
@@ -1270,14 +1266,12 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
             it_io = it; sweeps_io = total_sweeps;
             return true;
         }
-#ifdef CVXW_SPLIT_IPM
         if (a.rq_ws) { // split path: the interior-point kernel runs nothing but the solve -- it finds the cost (solver's frame) in the slot
             double *slot = a.rq_ws + (int64_t)b * a.rq_stride;
             if (lane < 55) __hip_atomic_store(slot + RS_W + lane, ej < 9 ? Qs : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (lane == 0) __hip_atomic_store(slot + RS_IT, (double)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         }
-#endif
         if (lane == 0) {
             a.status[b] = cvx::ST_PENDING + (it << 8);
             if (a.work) a.work[2 * b + 1] = total_sweeps;
@@ -1524,76 +1518,5 @@ __global__ void __launch_bounds__(64, CVXW_OCC_RESCUE) rescue_wave_kernel_rc(Res
     resume_body<true, cvx::VAR_RC>((ResumeArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), first, lds_all);
 }
 
-#ifdef CVXW_SPLIT_IPM
-// ---------------------------------------------------------------------------------------
-// EXPERIMENT (round 4; -DCVXW_SPLIT_IPM; measured slower than the fused kernel at every occupancy, profiles/r04/split_ipm_experiment.txt).
-// The interior-point solve as a kernel of its own (the split path: workloads whose problems really go through it -- at most six
-// correspondences, the 16-equality variant).  It consumes the rescue queue (same self-cleaning discipline as resume_body), reads the
-// cost a first-order kernel left in the problem's slot, runs coop_ipm_body -- nothing else is compiled into it, so it needs neither the
-// 256 registers nor the 18 KB of LDS of the fused cvxw::rescue_wave_kernel: three wavefronts per SIMD instead of two on a solve
-// that is all dependent latency --, writes W = Z - S / rho (positive part Z, dual hint S) with a NEGATIVE iteration count into the slot
-// and appends the problem to the RESUME queue: the plain resume_wave_kernel launched behind it makes the attempt one iteration later
-// (solve_pass: post_ipm) with the code every other problem runs through.
-#ifndef CVXW_OCC_IPM
-#define CVXW_OCC_IPM 3
-#endif
-constexpr int IPM_GRID_MAX = 1024 * CVXW_OCC_IPM;
-struct IpmArgs {
-    int64_t batch;
-    double rho, rho_tail;
-    int tail_from;
-    int32_t *rq_count, *rq_entries; // consumed: the rescue queue
-    int32_t *count, *entries;       // produced: the resume queue
-    double *ws;
-    int stride;
-};
-template <int VAR>
-__global__ void __launch_bounds__(64, CVXW_OCC_IPM) ipm_wave_kernel(IpmArgs k)
-{
-    __shared__ __attribute__((aligned(16))) double L[IpmLayCompact::END];
-    int32_t b = k.rq_entries[blockIdx.x];
-    if (b < 0) return;
-    const int lane = threadIdx.x & 63;
-    const unsigned lw = kLanePack.w[lane];
-    const int ei = (int)(lw & 15), ej = (int)((lw >> 4) & 15);
-    const int gsz = (int)gridDim.x;
-    const int pushed = __hip_atomic_load(k.rq_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (stable until the last block resets it)
-    for (int64_t q = blockIdx.x;;) { // wave-uniform
-        if (lane == 0) k.rq_entries[q] = -1;
-        if (b < k.batch) {
-            double *slot = k.ws + (int64_t)b * k.stride;
-            const double qe = (lane < 55 && ej < 9) ? __hip_atomic_load(slot + RS_W + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-            const int it0 = (int)__hip_atomic_load(slot + RS_IT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            double gap;
-            const int nit = coop_ipm_body<VAR, IpmLayCompact>(L, lane, qe, ei, ej, 1e-10, 40, &gap);
-            const int it1 = it0 + nit;
-            const double rho = (k.tail_from > 0 && it1 >= k.tail_from) ? k.rho_tail : k.rho; // the penalty the resumed solve runs with
-            const double w = L[IpmLayCompact::Z + ei * 10 + ej] - L[IpmLayCompact::S + ei * 10 + ej] / rho;
-            if (lane < 55) slot[RS_W + lane] = w;
-            if (lane == 0) slot[RS_IT] = -(double)(it1 > 0 ? it1 : 1);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            if (lane == 0) {
-                const int p = atomicAdd(k.count, 1);
-                k.entries[p] = b;
-            }
-            CVXW_SYNC();
-        }
-        int pn = 0;
-        if (lane == 0) pn = atomicAdd(k.rq_count + 1, 1);
-        q = (int64_t)gsz + __builtin_amdgcn_readfirstlane(pn);
-        b = q < k.batch + RESUME_GRID_MAX ? k.rq_entries[q] : -1;
-        if (b < 0) break;
-    }
-    if (lane == 0) {
-        const int drawing = pushed < gsz ? pushed : gsz;
-        if (atomicAdd(k.rq_count + 2, 1) == drawing - 1) {
-            __hip_atomic_store(k.rq_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(k.rq_count + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(k.rq_count + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-#endif // CVXW_SPLIT_IPM
 
 } // namespace cvxw

@@ -315,6 +315,16 @@ int cvxpnpl_release_workspace(void *stream, int32_t all_streams);
  * widths.  DEVICE pointers.  Returns 0, -1 bad arguments, -2 HIP error. */
 int cvxpnpl_calibration_copy(const void *d_src, void *d_dst, int64_t nbytes, int32_t bytes_per_lane, void *stream);
 
+/* Diagnostics / building block: the interior-point solve of the relaxation alone (ipm_quad.h: four problems per wavefront), without
+ * rounding, polish or certificate -- what the solver's interior-point path (opts.rescue_from) runs for a slow problem before the
+ * first-order iteration takes over again.  d_Qs55 [batch][55]: the cost c = vech(Q) of cvxpnpl.py:475-484 WITHOUT the factor 2 on
+ * the off-diagonal entries, i.e. the upper triangle of Q row by row, scaled to trace 1 (entries outside the 9x9 block are ignored);
+ * variant: CVXPNPL_VARIANT_*.  Outputs (DEVICE, required): d_Z100 / d_S100 [batch][100] the primal / dual iterates as full
+ * symmetric matrices, d_gap [batch] = <Z, S>, d_iters [batch] = iterations | reason << 8 (why the solve ended: 0 iteration cap, 1 gap below
+ * 1e-10, 2 / 3 a factorisation failed in rounding, 4 no step keeps the iterates positive definite, 5 the gap stopped decreasing).  Returns 0, -1 bad arguments, -2 HIP error. */
+int cvxpnpl_ipm_batch(int64_t batch, const double *d_Qs55, int32_t variant, double *d_Z100, double *d_S100, double *d_gap, int32_t *d_iters,
+                      void *stream);
+
 /* HIP-event timing on the launch stream (for bench.py: torch.cuda.Event only sees torch's
  * current stream).  handles are opaque. */
 void *cvxpnpl_event_create(void);

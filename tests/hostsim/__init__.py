@@ -186,3 +186,19 @@ def proj_affine_homog(E55, variant=0):
     lib().hs_proj_affine_homog.argtypes = [_dp, C.c_int]
     lib().hs_proj_affine_homog(_p(E), int(variant))
     return E
+
+
+def ipm_solve(Qs55, variant=0):
+    """cvx::ipm_solve on trace-normalised costs [B, 55] -> Z [B,10,10], S [B,10,10], gap [B], iters [B]"""
+    Qs55 = np.ascontiguousarray(Qs55, dtype=np.float64)
+    Bn = len(Qs55)
+    Z, S, gap, it = np.zeros((Bn, 10, 10)), np.zeros((Bn, 10, 10)), np.zeros(Bn), np.zeros(Bn, dtype=np.int32)
+    lib().hs_ipm_solve(Bn, _p(Qs55), int(variant), _p(Z), _p(S), _p(gap), it.ctypes.data_as(_ip))
+    return Z, S, gap, it
+
+
+def ipm_rows(variant=0):
+    """the constraint rows A_i of the interior-point solve as dense [rows, 10, 10]"""
+    A = np.zeros((21, 10, 10))
+    nr = lib().hs_ipm_rows(int(variant), _p(A))
+    return A[:nr]

@@ -77,6 +77,39 @@ int hs_ipm_batch(int batch, int n_p, const double *pts_2d, const double *pts_3d,
     return 0;
 }
 
+// the interior-point solve alone (ipm_core.h: ipm_solve) on trace-normalised costs Qs (55, vech order, zero outside the 9x9 block):
+// iterates as full 10x10 matrices, gap, iterations -- the host statement tests/test_ipm_quad.py holds cvxpnpl_ipm_batch against
+int hs_ipm_solve(int batch, const double *Qs55, int variant, double *Z100, double *S100, double *gap_out, int *iters)
+{
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int b = 0; b < batch; ++b) {
+        double q[45], Z[10][10], S[10][10], y[cvx::IPM_M], gap;
+        for (int i = 0; i < 9; ++i)
+            for (int j = i; j < 9; ++j) q[cvx::qidx(i, j)] = Qs55[(size_t)b * 55 + cvx::sidx(i, j)];
+        const int nit = variant == cvx::VAR_RC ? cvx::ipm_solve<cvx::VAR_RC>(q, Z, S, y, 1e-10, 40, gap) : cvx::ipm_solve<cvx::VAR_FULL>(q, Z, S, y, 1e-10, 40, gap);
+        for (int i = 0; i < 10; ++i)
+            for (int j = 0; j < 10; ++j) { Z100[(size_t)b * 100 + i * 10 + j] = Z[i][j]; S100[(size_t)b * 100 + i * 10 + j] = S[i][j]; }
+        gap_out[b] = gap;
+        iters[b] = nit;
+    }
+    return 0;
+}
+// the constraint rows of the interior-point solve (ipm_core.h: ipm_term) as dense matrices A_i [rows][100]; returns the row count
+int hs_ipm_rows(int variant, double *A)
+{
+    const int nr = cvx::ipm_rows(variant);
+    for (int i = 0; i < nr; ++i) {
+        for (int e = 0; e < 100; ++e) A[i * 100 + e] = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            int r, c; double cf;
+            if (variant == cvx::VAR_RC) cvx::ipm_term<cvx::VAR_RC>(i, k, r, c, cf); else cvx::ipm_term<cvx::VAR_FULL>(i, k, r, c, cf);
+            if (r == c) A[i * 100 + r * 10 + r] += cf;
+            else { A[i * 100 + r * 10 + c] += 0.5 * cf; A[i * 100 + c * 10 + r] += 0.5 * cf; }
+        }
+    }
+    return nr;
+}
+
 // assembly only: B (27) and Q9 (45 packed)
 int hs_assemble(int n_p, const double *pts_2d, const double *pts_3d, int n_l, const double *line_2d, const double *line_3d,
                 const double *K, double *B, double *Q9)
