@@ -57,6 +57,25 @@ __device__ __forceinline__ double row_get(double v, int rb4, int src)
     const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
     return __hiloint2double(hi, lo);
 }
+// value of lane K (compile-time after unrolling) of the caller's row, in every lane of the row: DPP row_newbcast (gfx90a and later; two
+// v_mov_b32_dpp -- no LDS crossbar, no address register: 20-26 cycles on a dependent chain where the ds_bpermute round trip takes 78-87,
+// tools/microbench/lat_probe.hip)
+template <int K>
+__device__ __forceinline__ double row_bcast_k(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + K, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + K, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_bcast(double v, int k) // k: a constant once the calling loop is unrolled
+{
+    switch (k & 15) {
+    case 0: return row_bcast_k<0>(v);   case 1: return row_bcast_k<1>(v);   case 2: return row_bcast_k<2>(v);   case 3: return row_bcast_k<3>(v);
+    case 4: return row_bcast_k<4>(v);   case 5: return row_bcast_k<5>(v);   case 6: return row_bcast_k<6>(v);   case 7: return row_bcast_k<7>(v);
+    case 8: return row_bcast_k<8>(v);   case 9: return row_bcast_k<9>(v);   case 10: return row_bcast_k<10>(v); case 11: return row_bcast_k<11>(v);
+    case 12: return row_bcast_k<12>(v); case 13: return row_bcast_k<13>(v); case 14: return row_bcast_k<14>(v); default: return row_bcast_k<15>(v);
+    }
+}
 __device__ __forceinline__ double rcp_(double x) { return cvxw::fast_rcp(x); }
 
 #ifdef CVXI_CLOCK // diagnostic build (tools/ipmq_clock.py): shader-clock cycles per stage of the solve, summed per wavefront
@@ -116,10 +135,10 @@ __device__ __forceinline__ bool ldl_rows(double (&a)[N], int gl, int rb4, double
     dinv = 1.0;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-        const double d = row_get(a[j], rb4, j);
+        const double d = row_bcast(a[j], j);
         double c[N];
 #pragma unroll
-        for (int k = j + 1; k < N; ++k) c[k] = row_get(a[j], rb4, k);
+        for (int k = j + 1; k < N; ++k) c[k] = row_bcast(a[j], k);
         ok = ok && (d > 0.0);
         const double inv = rcp_(d > 0.0 ? d : 1.0);
         const double f = a[j] * inv;
@@ -141,10 +160,10 @@ __device__ __forceinline__ bool ldl_schur(double (&lo)[16], double (&hi)[21], in
     dinv_lo = 1.0; dinv_hi = 1.0;
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-        const double d = j < 16 ? row_get(lo[j < 16 ? j : 0], rb4, j) : row_get(hi[j], rb4, j - 16);
+        const double d = j < 16 ? row_bcast(lo[j < 16 ? j : 0], j) : row_bcast(hi[j], j - 16);
         double c[21];
 #pragma unroll
-        for (int k = j + 1; k < NR; ++k) c[k] = k < 16 ? row_get(lo[j < 16 ? j : 0], rb4, k) : row_get(hi[j], rb4, k - 16);
+        for (int k = j + 1; k < NR; ++k) c[k] = k < 16 ? row_bcast(lo[j < 16 ? j : 0], k) : row_bcast(hi[j], k - 16);
         ok = ok && (d > 0.0);
         const double inv = rcp_(d > 0.0 ? d : 1.0);
         if (j < 16) {
@@ -171,7 +190,7 @@ __device__ __forceinline__ void solve_schur(const double (&lo)[16], const double
 {
 #pragma unroll
     for (int i = 0; i < NR; ++i) { // L y = b: y_i is final once the steps before it are applied
-        const double yi = i < 16 ? row_get(xlo, rb4, i) : row_get(xhi, rb4, i - 16);
+        const double yi = i < 16 ? row_bcast(xlo, i) : row_bcast(xhi, i - 16);
         if (i < 16 && gl > i) xlo -= lo[i < 16 ? i : 0] * yi;
         if (NR > 16 && 16 + gl > i) xhi -= hi[i] * yi;
     }

@@ -90,20 +90,34 @@ __global__ void __launch_bounds__(64, 1) probe(double *out, long long *cyc, doub
     for (int i = 0; i < N / 2; ++i) s += (x + i) * y;
     x += s;
     t1 = now_(x); if (lane == 0) cyc[7] = t1 - t0;
+    // 8: dependent row_newbcast broadcasts of a double (two v_mov_b32_dpp, gfx90a+): lane 5 of every row to the whole row
+    t0 = now_(x);
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x155, 0xF, 0xF, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x155, 0xF, 0xF, true);
+        x = __hiloint2double(hi, lo) + 1e-9;
+    }
+    t1 = now_(x); if (lane == 0) cyc[8] = t1 - t0;
+    // semantic check of row_newbcast:3 : every lane must read lane (lane & 48) + 3
+    {
+        const int got = __builtin_amdgcn_update_dpp(-1, lane, 0x153, 0xF, 0xF, false);
+        if (blockIdx.x == 0) { const unsigned long long okm = __ballot(got == ((lane & 48) | 3)); if (lane == 0) cyc[9] = (long long)okm; }
+    }
     out[blockIdx.x * 64 + lane] = x + f + s;
 }
 
 int main()
 {
     double *out; long long *cyc;
-    hipMalloc(&out, 1024 * 64 * 8); hipMalloc(&cyc, 64);
+    hipMalloc(&out, 1024 * 64 * 8); hipMalloc(&cyc, 128);
     for (int blocks : {1, 1024}) {
         hipLaunchKernelGGL(probe, dim3(blocks), dim3(64), 0, 0, out, cyc, 1.0);
         hipDeviceSynchronize();
-        long long h[8];
-        hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost);
-        printf("{\"wavefronts\": %d, \"cycles_per\": {\"f64_fma_dependent\": %.1f, \"f64_fma_8_chains\": %.1f, \"bpermute_double_round_trip\": %.1f, \"lds_read_round_trip\": %.1f, \"rcp_newton2_chain\": %.1f, \"dpp_row_sum_f64\": %.1f, \"f32_fma_dependent\": %.1f, \"f64_dot_step\": %.1f}}\n",
-               blocks, h[0] / (double)N, h[1] / (double)N, h[2] / (double)(N / 4), h[3] / (double)(N / 4), h[4] / (double)(N / 8), h[5] / (double)(N / 8), h[6] / (double)N, h[7] / (double)(N / 2));
+        long long h[10];
+        hipMemcpy(h, cyc, 80, hipMemcpyDeviceToHost);
+        printf("{\"wavefronts\": %d, \"cycles_per\": {\"f64_fma_dependent\": %.1f, \"f64_fma_8_chains\": %.1f, \"bpermute_double_round_trip\": %.1f, \"lds_read_round_trip\": %.1f, \"rcp_newton2_chain\": %.1f, \"dpp_row_sum_f64\": %.1f, \"f32_fma_dependent\": %.1f, \"f64_dot_step\": %.1f, \"row_newbcast_double\": %.1f}, \"row_newbcast_3_ok_mask\": \"%llx\"}\n",
+               blocks, h[0] / (double)N, h[1] / (double)N, h[2] / (double)(N / 4), h[3] / (double)(N / 4), h[4] / (double)(N / 8), h[5] / (double)(N / 8), h[6] / (double)N, h[7] / (double)(N / 2), h[8] / (double)(N / 4), (unsigned long long)h[9]);
     }
     return 0;
 }
