@@ -62,9 +62,9 @@ def _kernel_name(layout, batch, blocked=False, n_corr=10):
         return "assemble_large_kernel (dominant: timed on its own) + assemble_finish_kernel + solve_wave_kernel"
     if layout == 0:
         layout = 2 if batch < 2560 else (3 if (batch < 20000 or n_corr <= 4) else 1)
-    return {1: "solve_lane2_kernel + resume_wave_kernel (+ rescue_wave_kernel: problems beyond opts.rescue_from iterations)",
+    return {1: "solve_lane2_kernel + resume_wave_kernel (+ rescue_wave_kernel / ipm_quad_kernel: problems beyond opts.rescue_from iterations)",
             2: "solve_wave_kernel (+ rescue_wave_kernel: problems beyond opts.rescue_from iterations)",
-            3: "solve_quad_kernel (+ rescue_wave_kernel: planar scenes and problems beyond opts.rescue_from iterations)",
+            3: "solve_quad_kernel (+ rescue_wave_kernel, or ipm_quad_kernel + resume_wave_kernel for at most five correspondences: planar scenes and problems beyond opts.rescue_from iterations)",
             4: "solve_quad_kernel<12 lanes per problem> (+ rescue_wave_kernel: planar scenes and problems beyond opts.rescue_from iterations)"}.get(layout, f"experimental layout {layout}")
 
 
@@ -939,7 +939,7 @@ def _measure_pmc(args):
                 res.setdefault(k, {}).update(d)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    solve = {k: v for k, v in res.items() if "solve_" in k or "resume_" in k or "rescue_" in k or "assemble_" in k}
+    solve = {k: v for k, v in res.items() if "solve_" in k or "resume_" in k or "rescue_" in k or "assemble_" in k or "ipm_quad_" in k}
     extra = {k: v for k, v in res.items() if "score_kernel" in k}  # (reported in by_kernel, not part of a solve step)
     calib = {k: v for k, v in res.items() if "calibration_copy" in k}
     if not solve:

@@ -1,24 +1,31 @@
 // ipm_quad.h -- the interior-point solve of ipm_core.h, FOUR problems per gfx950 wavefront (one per DPP row of sixteen lanes).
 //
-// Until round 5 the solve ran one problem per wavefront (ipm_wave.h, cvxw::coop_ipm): ~13 iterations of ~25 us, nearly all of it the
-// dependent chains of two Cholesky factorisations, four triangular solves and the step-length tests on 10-21 of the 64 lanes, plus a
-// Schur matrix built from ~17 000 scattered LDS reads per iteration (profiles/r04/split_ipm_experiment.txt: "what would help: two problems
-// per wavefront").  Here the same chains serve four problems, and the data-parallel parts are rewritten so that their operands are
-// registers addressed at compile time:
-//   * matrices: lane c < 10 of a row owns column c (= row c) of S, dS, dZ in registers; Z, S^-1 and the predictor's dZ also lie in the
-//     row's LDS slice as full 10 x 10 matrices (3.2 KB per problem, 12.9 KB per wavefront: three wavefronts per SIMD fit a CU's LDS);
+// Until round 5 the solve ran one problem per wavefront (ipm_wave.h, cvxw::coop_ipm -- still the safety net of the workloads that hardly
+// ever need it): ~13 iterations of ~25 us, nearly all of it the dependent chains of two factorisations, four triangular solves and the
+// step-length tests on 10-21 of the 64 lanes, plus a Schur matrix built from ~17 000 scattered LDS reads per iteration
+// (profiles/r04/split_ipm_experiment.txt: "what would help: two problems per wavefront").  Here the same chains serve four problems, the
+// data-parallel parts have their operands in registers addressed at compile time, and the broadcasts of the chains are DPP moves:
+//   * matrices: six full 10 x 10 matrices per problem (Z, S^-1, S, dZ, dS and a scratch matrix) in the row's LDS slice, row c (= column
+//     c) written by lane c; a lane re-reads its own row where it needs it.  20 KB per wavefront: two wavefronts per SIMD;
 //   * Schur matrix M_ij = <A_i, Z A_j S^-1>: lane l owns row l (and lanes 0..4 rows 16..20).  For each of the (at most three) terms
 //     (a, b) of ITS row a lane loads rows a, b of Z and of S^-1 (four contiguous 80-byte reads) and then runs the SAME straight-line
 //     code as every other lane: for every column j and term (p, q) of A_j -- all compile-time -- four multiply-adds on registers.
 //     ~900 multiply-adds per lane and iteration instead of 1 152 eight-byte gathers with bank conflicts;
 //   * dS = -sum dy_i A_i applied to a vector is straight-line code on the 21 multipliers (every off-diagonal entry belongs to one triple);
-//   * factorisations: LDL^T with one row (M: two rows) per lane, right-looking, pivot and column broadcast inside the row with
-//     ds_bpermute (no LDS memory, no barrier); triangular solves on the same layout (forward: broadcast, backward: DPP row reduction);
-//   * step lengths: three candidate steps {1, .7, .45} x scale of ONE matrix per call, each Cholesky-tested by five lanes that hold
-//     two rows each (rows r and 9 - r) -- the same candidate ladder as cvxw::coop_steps, Z and S one after the other.
-// Control flow is wave-uniform; a problem that has converged (or whose factorisation failed: the last good iterate stands, as in
-// ipm_core.h) idles until its three neighbours are done.  Mathematics: cvx::ipm_solve (HKM direction, Mehrotra predictor-corrector,
-// feasible start), constraint rows cvx::ipm_term<VAR> (cvxpnpl.py:387-451; VAR_RC: benchmarks/toolkit/methods/rc.py:9-64).
+//   * factorisations: LDL^T with one row (M: two rows) per lane, right-looking; pivot and column reach the other lanes of the row by
+//     DPP row_newbcast (gfx90a and later: two v_mov_b32_dpp per double, 20-26 cycles on a dependent chain where a ds_bpermute round trip
+//     takes 78-87 -- tools/microbench/lat_probe.hip); forward substitution the same way, backward substitution by DPP row reductions;
+//   * step lengths: three candidate steps {1, .7, .45} x scale of Z AND of S per call, each Cholesky-tested by five lanes that hold
+//     two rows (r and 9 - r) -- the candidate ladder of cvxw::coop_steps; the two eliminations run interleaved, their pivot columns
+//     travel through the scratch matrix;
+//   * right-hand sides b_i - <A_i, Z + Rc> (the residual of the equalities goes into every step) and, when the gap does not decrease
+//     although it is still large, one retry with EQUAL steps: the two changes to cvx::ipm_solve's rules, both measured (below).
+// Control flow is wave-uniform; a problem that has converged (or whose factorisation failed in rounding: the last good iterate stands,
+// as in ipm_core.h) idles until its three neighbours are done.  Mathematics: cvx::ipm_solve (HKM direction, Mehrotra
+// predictor-corrector, feasible start), constraint rows cvx::ipm_term<VAR> (cvxpnpl.py:387-451; VAR_RC: benchmarks/toolkit/methods/rc.py:9-64).
+// Measured (MI355X, profiles/r05/ipm_quad_*.txt): 8 192 solves of four-point problems in 0.79 ms (cvxw::coop_ipm: 2 048 in ~0.34 ms);
+// one wavefront alone: ~50 000 cycles per iteration for its four problems (step tests 21 %, triangular solves 19 %, dS / dZ 15 %,
+// Schur matrix 14 %, its factorisation 12 %).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -48,14 +55,6 @@ __device__ __forceinline__ double row_sum(double x)
     x += dpp_mov<0x141>(x);
     x += dpp_mov<0x140>(x);
     return x;
-}
-// value of lane `src` (0..15, may differ from lane to lane) of the caller's row; rb4 = 4 * (first lane of the row)
-__device__ __forceinline__ double row_get(double v, int rb4, int src)
-{
-    const int addr = rb4 + (src << 2);
-    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
-    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
-    return __hiloint2double(hi, lo);
 }
 // value of lane K (compile-time after unrolling) of the caller's row, in every lane of the row: DPP row_newbcast (gfx90a and later; two
 // v_mov_b32_dpp -- no LDS crossbar, no address register: 20-26 cycles on a dependent chain where the ds_bpermute round trip takes 78-87,
@@ -129,7 +128,7 @@ __device__ __forceinline__ void apply_dS(const double (&dy)[21], const double (&
 // LDL^T of a symmetric N x N matrix (N <= 16), row i on lane i of the DPP row: a[j] = A_ij for j <= i, 0 beyond.  On exit a[j] = L_ij
 // (j < i), lane i's a[i]... is returned as dinv = 1 / d_i.  Returns whether every pivot was positive (uniform over the row).
 template <int N>
-__device__ __forceinline__ bool ldl_rows(double (&a)[N], int gl, int rb4, double &dinv)
+__device__ __forceinline__ bool ldl_rows(double (&a)[N], int gl, double &dinv)
 {
     bool ok = true;
     dinv = 1.0;
@@ -154,7 +153,7 @@ __device__ __forceinline__ bool ldl_rows(double (&a)[N], int gl, int rb4, double
 // the slice -- one or two 8-byte writes per lane and 16-byte broadcast reads instead of two ds_bpermute per entry.  hipcc 7.2 then spills
 // 234 registers INSIDE the iteration loop, against none with the register exchange: not taken.)
 template <int NR>
-__device__ __forceinline__ bool ldl_schur(double (&lo)[16], double (&hi)[21], int gl, int rb4, double &dinv_lo, double &dinv_hi)
+__device__ __forceinline__ bool ldl_schur(double (&lo)[16], double (&hi)[21], int gl, double &dinv_lo, double &dinv_hi)
 {
     bool ok = true;
     dinv_lo = 1.0; dinv_hi = 1.0;
@@ -186,7 +185,7 @@ __device__ __forceinline__ bool ldl_schur(double (&lo)[16], double (&hi)[21], in
 
 // x <- M^-1 x with the factor of ldl_schur: xlo belongs to row gl, xhi to row 16 + gl
 template <int NR>
-__device__ __forceinline__ void solve_schur(const double (&lo)[16], const double (&hi)[21], int gl, int rb4, double dinv_lo, double dinv_hi, double &xlo, double &xhi)
+__device__ __forceinline__ void solve_schur(const double (&lo)[16], const double (&hi)[21], int gl, double dinv_lo, double dinv_hi, double &xlo, double &xhi)
 {
 #pragma unroll
     for (int i = 0; i < NR; ++i) { // L y = b: y_i is final once the steps before it are applied
@@ -265,7 +264,7 @@ __device__ __forceinline__ void step_tests(const double *L, int gl, int row_lane
 // slice and a lane re-reads its own row where it is used -- a spilled register costs this kernel a trip to scratch memory on a chain
 // that has nothing to hide it behind (first build: 848 B of scratch per lane, 2.3x slower).
 template <int VAR>
-__device__ __forceinline__ int ipm4_solve(double *L, const int gl_in, const int rb4_in, const int row_lane0, bool live, double tol, int max_iters, double &gap_out, long long *clk_)
+__device__ __forceinline__ int ipm4_solve(double *L, const int gl_in, const int row_lane0, bool live, double tol, int max_iters, double &gap_out, long long *clk_)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     using R = Rows<VAR>;
@@ -275,7 +274,7 @@ __device__ __forceinline__ int ipm4_solve(double *L, const int gl_in, const int 
     // it live across every phase (first build: ~90 scalar pairs and ~60 vector registers of invariants, 217 spilled registers).  So the
     // position is hidden behind an empty asm at the top of every phase: the derived values are recomputed where they are used (a
     // compare or a shift each) and die there.
-    int gl = gl_in, rb4 = rb4_in;
+    int gl = gl_in;
     int t_lo0, t_lo1, t_lo2, t_hi0, t_hi1, t_hi2;
     {
         const RowTab &tab = VAR == cvx::VAR_RC ? kRowTabRc : kRowTab;
@@ -283,7 +282,7 @@ __device__ __forceinline__ int ipm4_solve(double *L, const int gl_in, const int 
         t_lo0 = tab.w[rl][0]; t_lo1 = tab.w[rl][1]; t_lo2 = tab.w[rl][2];
         t_hi0 = tab.w[rh][0]; t_hi1 = tab.w[rh][1]; t_hi2 = tab.w[rh][2];
     }
-#define CVXI_REFRESH() asm volatile("" : "+v"(gl), "+v"(rb4), "+v"(t_lo0), "+v"(t_lo1), "+v"(t_lo2), "+v"(t_hi0), "+v"(t_hi1), "+v"(t_hi2))
+#define CVXI_REFRESH() asm volatile("" : "+v"(gl), "+v"(t_lo0), "+v"(t_lo1), "+v"(t_lo2), "+v"(t_hi0), "+v"(t_hi1), "+v"(t_hi2))
 #define col (gl < 10)
 #define cg (gl < 10 ? gl : 0)
 #define has_lo (gl < NR)
@@ -333,7 +332,7 @@ __device__ __forceinline__ int ipm4_solve(double *L, const int gl_in, const int 
             double a[10];
 #pragma unroll
             for (int k = 0; k < 10; ++k) a[k] = (col && k <= gl) ? L[P_S + cg * 10 + k] : 0.0;
-            const bool ok = ldl_rows<10>(a, gl, rb4, dinv_s);
+            const bool ok = ldl_rows<10>(a, gl, dinv_s);
             if (!ok && !done) { done = true; why = 2; } // (S is positive definite by construction: rounding only)
             if (col) {
 #pragma unroll
@@ -426,7 +425,7 @@ __device__ __forceinline__ int ipm4_solve(double *L, const int gl_in, const int 
         CVXI_CLK(1);
         CVXI_REFRESH();
         double dinv_lo, dinv_hi;
-        if (!ldl_schur<NR>(lo, hi, gl, rb4, dinv_lo, dinv_hi) && !done) { done = true; why = 3; }
+        if (!ldl_schur<NR>(lo, hi, gl, dinv_lo, dinv_hi) && !done) { done = true; why = 3; }
         CVXI_CLK(2);
         // ---- predictor (sigma = 0), then corrector
         double sig_mu = 0.0, ap = 0.0, ad = 0.0;
@@ -459,7 +458,7 @@ __device__ __forceinline__ int ipm4_solve(double *L, const int gl_in, const int 
             if (!has_lo) xlo = 0.0;
             if (!has_hi) xhi = 0.0;
             CVXI_REFRESH();
-            solve_schur<NR>(lo, hi, gl, rb4, dinv_lo, dinv_hi, xlo, xhi);
+            solve_schur<NR>(lo, hi, gl, dinv_lo, dinv_hi, xlo, xhi);
             if (has_lo) L[P_DY + gl] = xlo;
             if (has_hi) L[P_DY + 16 + gl] = xhi;
             CVXW_SYNC();
@@ -515,6 +514,9 @@ __device__ __forceinline__ int ipm4_solve(double *L, const int gl_in, const int 
                     CVXI_REFRESH();
                     double tp, td;
                     step_tests(L, gl, row_lane0, sz, ss, tp, td);
+#ifdef CVXI_CLOCK
+                    clk_[8 + pass] += 1;
+#endif
                     if (ap == 0.0) { ap = tp; sz *= 0.3; }
                     if (ad == 0.0) { ad = td; ss *= 0.3; }
                 }
@@ -593,7 +595,7 @@ __device__ __forceinline__ int ipm4_solve(double *L, const int gl_in, const int 
 #undef has_lo
 #undef has_hi
 #else
-    (void)L; (void)gl_in; (void)rb4_in; (void)row_lane0; (void)live; (void)tol; (void)max_iters; (void)clk_; gap_out = 0; return 0;
+    (void)L; (void)gl_in; (void)row_lane0; (void)live; (void)tol; (void)max_iters; (void)clk_; gap_out = 0; return 0;
 #endif
 }
 
@@ -629,7 +631,7 @@ __global__ void __launch_bounds__(64, CVXI_OCC) ipm_quad_kernel(IpmQuadArgs k)
 {
     __shared__ __attribute__((aligned(16))) double lds[4 * P_SLICE];
     const int lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
-    const int rb4 = (lane & 48) << 2, row_lane0 = lane & 48;
+    const int row_lane0 = lane & 48;
     double *L = lds + grp * P_SLICE;
     const bool direct = k.qs_in != nullptr;
     int64_t q = blockIdx.x;
@@ -655,8 +657,8 @@ __global__ void __launch_bounds__(64, CVXI_OCC) ipm_quad_kernel(IpmQuadArgs k)
         }
         const int it0 = (!direct && live) ? (int)__hip_atomic_load(k.ws + (int64_t)b * k.stride + cvxw::RS_IT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         double gap;
-        long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const int nit_why = ipm4_solve<VAR>(L, gl, rb4, row_lane0, live, 1e-10, 40, gap, clk);
+        long long clk[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const int nit_why = ipm4_solve<VAR>(L, gl, row_lane0, live, 1e-10, 40, gap, clk);
         const int nit = nit_why & 255;
         if (live && gl < 10) {
             if (direct) {
@@ -664,7 +666,7 @@ __global__ void __launch_bounds__(64, CVXI_OCC) ipm_quad_kernel(IpmQuadArgs k)
                 for (int i = 0; i < 10; ++i) { k.z_out[(int64_t)b * 100 + gl * 10 + i] = L[P_Z + gl * 10 + i]; k.s_out[(int64_t)b * 100 + gl * 10 + i] = L[P_S + gl * 10 + i]; }
                 if (gl == 0) { k.it_out[b] = nit_why; k.gap_out[b] = gap; } // (iterations | reason << 8)
 #ifdef CVXI_CLOCK
-                if (gl == 0) { for (int c = 0; c < 8; ++c) k.s_out[(int64_t)b * 100 + c] = (double)clk[c]; }
+                if (gl == 0) { for (int c = 0; c < 10; ++c) k.s_out[(int64_t)b * 100 + c] = (double)clk[c]; }
 #endif
             } else {
                 double *slot = k.ws + (int64_t)b * k.stride;

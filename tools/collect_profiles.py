@@ -52,7 +52,7 @@ for run in WORKLOAD_KEY:
     c = counters(run)
     json.dump(c, open(os.path.join(dst, run, "pmc_summary.json"), "w"), indent=1)
     # the kernels of one step; the known-size copies of the same passes calibrate the byte counters (bench.py does the same)
-    step = {k: v for k, v in c.items() if any(t in k for t in ("solve_", "resume_", "rescue_", "assemble_"))}  # (score_kernel: in pmc_summary.json, not part of a solve step)
+    step = {k: v for k, v in c.items() if any(t in k for t in ("solve_", "resume_", "rescue_", "assemble_", "ipm_quad_"))}  # (score_kernel: in pmc_summary.json, not part of a solve step)
     cal = [v for k, v in c.items() if "calibration_copy_kernel<8>" in k]
     nbytes = float(64 << 20)
     ff = cal[0]["FETCH_SIZE"]["mean_per_launch"] * 1024 / nbytes if cal and "FETCH_SIZE" in cal[0] else 1.0

@@ -22,9 +22,10 @@ for n in (4, 4096, 8192):
     for variant in (0, 1):
         Z, S, gap, it = ca.ipm_batch(Qt, variant=variant)
         torch.cuda.synchronize()
-        clk = S.cpu().numpy().reshape(n, 100)[::4, :8]   # one record per wavefront
+        rec = S.cpu().numpy().reshape(n, 100)[::4, :10]   # one record per wavefront
+        clk, calls = rec[:, :8], rec[:, 8:]
         itw = (it.cpu().numpy() & 255).reshape(-1, 4).max(axis=1) if n % 4 == 0 else (it.cpu().numpy() & 255)[:1]
         tot = clk.sum(axis=1)
         print(json.dumps({"problems": n, "variant": variant, "wave_iters_mean": round(float(itw.mean()), 2), "cycles_per_wave": round(float(tot.mean())),
                           "cycles_per_wave_iteration": round(float(tot.mean() / max(1.0, itw.mean() + 1))),
-                          "share": {nm: round(float(clk[:, i].mean() / tot.mean()), 3) for i, nm in enumerate(names)}}))
+                          "step_test_calls_per_iteration(predictor, corrector)": [round(float(calls[:, 0].mean() / max(1.0, itw.mean() + 1)), 2), round(float(calls[:, 1].mean() / max(1.0, itw.mean() + 1)), 2)], "share": {nm: round(float(clk[:, i].mean() / tot.mean()), 3) for i, nm in enumerate(names)}}))

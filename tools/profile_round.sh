@@ -4,7 +4,7 @@
 # Writes gpurun_out/<tag>/ ; `python tools/collect_profiles.py <tag>` (container) then condenses it into
 # profiles/<tag>/ and profiles/pmc_traffic.json.  Counter passes are separate runs with no tracing
 # (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950, MI355X guide).
-tag=${1:-r04}
+tag=${1:-r05}
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/$tag
 rm -rf $out; mkdir -p $out
