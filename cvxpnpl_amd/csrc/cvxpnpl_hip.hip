@@ -438,7 +438,9 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     // iterations' worth -- at three wavefronts per SIMD the certificate's code is the part that spills -- and these problems need 14-20
     // iterations on average: first attempt after 17 (profiles/r04/minimal_tune*.txt, 50 k problems / config 5, M per second: first attempt
     // after 7: 13.0 / 21.3, 9: 13.5 / 22.4, 13: 14.5 / 23.5, 17: 14.9 / 24.0, 21: 14.5 / 23.9; every third iteration instead of every second: same).
-    const bool minimal_queued = minimal && layout == CVXPNPL_LAYOUT_QUAD && !(o.f32_sweeps_until < quad_iters);
+    // (round 5: in both precision modes -- with float64 sweeps the kernel keeps two wavefronts per SIMD, solve_quad_kernel<2, 2, 16, true>)
+    const bool minimal_queued = minimal && layout == CVXPNPL_LAYOUT_QUAD;
+    const bool minimal_queued_f64 = minimal_queued && o.f32_sweeps_until < quad_iters;
     // (rc in the quad schedule: 19 instead of 11 -- profiles/r04/rc_tune_r04.txt: 50 k problems 18.3 -> 19.3 M poses/s, 10 k 9.0 -> 9.3 M; the same effect, smaller)
     if (o.first_check <= 0) o.first_check = rc ? (layout == CVXPNPL_LAYOUT_QUAD ? 19 : 11) : (minimal_queued ? 17 : (minimal ? 7 : (layout == CVXPNPL_LAYOUT_LANE ? 6 : 5))); // (rc: nothing certifies before ~10 iterations; 5 ... 15 within 3 %)
     // interior-point path for the problems still open after rescue_from iterations (ipm_wave.h): its queue lives in the workspace
@@ -510,7 +512,8 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
         else if (opts && opts->layout == 12) hipLaunchKernelGGL((cvxq::solve_quad_kernel<2, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else
 #endif
-        if (minimal_queued)
+        if (minimal_queued_f64) hipLaunchKernelGGL((cvxq::solve_quad_kernel<2, 2, 16, true>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
+        else if (minimal_queued)
             // Four-correspondence problems: every survivor of the 24-iteration first phase goes to the queue of the launch behind this one
             // instead of being finished by its own wavefront -- 59 % of these wavefronts end with survivors, most of which are headed for
             // the interior-point path anyway, and without the wave-per-problem code the kernel runs three wavefronts per SIMD (168 registers).
