@@ -13,7 +13,7 @@ for f in glob.glob("$out/t/**/*kernel_trace.csv", recursive=True):
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 # the last complete step: from the last but one launch of the first solver kernel
-first = [i for i, n in enumerate(names) if "solve_quad_kernel" in n or "solve_lane2_kernel" in n or "solve_wave_kernel" in n]
+first = [i for i, n in enumerate(names) if ("solve_quad_kernel" in n and "solve_quad_kernel<4" not in n) or "solve_lane2_kernel" in n or "solve_wave_kernel" in n]
 if len(first) >= 2:
     a, b = first[-2], first[-1]
     t0 = int(rows[a]["Start_Timestamp"])
