@@ -1269,7 +1269,9 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
         if (a.rq_ws) { // split path: the interior-point kernel runs nothing but the solve -- it finds the cost (solver's frame) in the slot
             double *slot = a.rq_ws + (int64_t)b * a.rq_stride;
             if (lane < 55) __hip_atomic_store(slot + RS_W + lane, ej < 9 ? Qs : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lane == 0) __hip_atomic_store(slot + RS_IT, (double)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (+ 0.5: the problem is solved in the canonical frame of a planar scene -- its finish after the interior-point solve belongs to
+            //  this kernel's twin logic, not to the four-per-wavefront finish of the quad schedule: cvxi::ipm_quad_kernel routes by it)
+            if (lane == 0) __hip_atomic_store(slot + RS_IT, (double)it + (canon ? 0.5 : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         }
         if (lane == 0) {

@@ -41,7 +41,8 @@ def counters(run):
 
 import hashlib
 
-LIB_SHA = hashlib.sha256(open(os.path.join(ROOT, "cvxpnpl_amd", "libcvxpnpl_amd.so"), "rb").read()).hexdigest()[:16]
+_sha_file = os.path.join(src, "lib_sha16.txt")  # written on the GPU box by profile_round.sh: the build that was profiled
+LIB_SHA = open(_sha_file).read().strip() if os.path.exists(_sha_file) else hashlib.sha256(open(os.path.join(ROOT, "cvxpnpl_amd", "libcvxpnpl_amd.so"), "rb").read()).hexdigest()[:16]
 traffic = {}
 for run in WORKLOAD_KEY:
     if not os.path.isdir(os.path.join(src, run)):

@@ -8,6 +8,7 @@ tag=${1:-r05}
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/$tag
 rm -rf $out; mkdir -p $out
+sha256sum $root/cvxpnpl_amd/libcvxpnpl_amd.so | cut -c1-16 > $out/lib_sha16.txt   # the build that is profiled (collect_profiles.py stamps it)
 export TMPDIR=/tmp
 cd /tmp
 prof() { # name, bench args...
