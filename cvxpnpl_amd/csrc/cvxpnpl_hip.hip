@@ -164,7 +164,7 @@ std::mutex &launch_mutex(int dev, void *stream)
 }
 
 size_t queue_entries_bytes(int64_t cap) { return ((size_t)(cap + cvxw::RESUME_GRID_MAX) * sizeof(int32_t) + 255) & ~(size_t)255; }
-size_t hybrid_queue_bytes(int64_t cap) { return 256 + 3 * queue_entries_bytes(cap); } // resume queue, rescue queue, continue queue (round 5)
+size_t hybrid_queue_bytes(int64_t cap) { return 256 + 2 * queue_entries_bytes(cap); }
 size_t hybrid_ws_bytes(int64_t cap) { return hybrid_queue_bytes(cap) + (size_t)cap * cvxw::RS_FULL * sizeof(double); } // any schedule
 int64_t hybrid_capacity(size_t bytes) // largest capacity whose layout fits (any schedule)
 {
@@ -181,7 +181,7 @@ bool init_workspace(void *p, int64_t cap, void *stream)
     return hipMemsetAsync(p, 0, 256, (hipStream_t)stream) == hipSuccess;
 }
 
-struct WsView { int32_t *count, *entries, *rq_count, *rq_entries, *cq_count, *cq_entries; double *parked; };
+struct WsView { int32_t *count, *entries, *rq_count, *rq_entries; double *parked; };
 
 bool get_workspace(int64_t batch, int stride, void *stream, WsView &v)
 {
@@ -213,8 +213,6 @@ bool get_workspace(int64_t batch, int stride, void *stream, WsView &v)
     v.entries = (int32_t *)((char *)w.ptr + 256);
     v.rq_count = v.count + 16;
     v.rq_entries = (int32_t *)((char *)w.ptr + 256 + queue_entries_bytes(w.cap));
-    v.cq_count = v.count + 32;
-    v.cq_entries = (int32_t *)((char *)w.ptr + 256 + 2 * queue_entries_bytes(w.cap));
     v.parked = (double *)((char *)w.ptr + hybrid_queue_bytes(w.cap));
     return true;
 }
@@ -250,8 +248,7 @@ void launch_rescue(int64_t batch, hipStream_t s, const cvxw::WaveArgs &w, const 
 
 // split interior-point path: the rescue queue through cvxi::ipm_quad_kernel (four solves per wavefront, ipm_quad.h) into the resume queue
 // (a launch of the resume kernel follows)
-void launch_ipm(int64_t batch, hipStream_t s, const cvxw::WaveArgs &w, const cvx::Opts &o, int32_t *count, int32_t *entries, int32_t *fcount = nullptr,
-                int32_t *fentries = nullptr)
+void launch_ipm(int64_t batch, hipStream_t s, const cvxw::WaveArgs &w, const cvx::Opts &o, int32_t *count, int32_t *entries)
 {
     const int64_t groups = (batch + 3) / 4;
     const int64_t grid = groups < cvxi::IPMQ_GRID_MAX ? groups : cvxi::IPMQ_GRID_MAX;
@@ -259,7 +256,6 @@ void launch_ipm(int64_t batch, hipStream_t s, const cvxw::WaveArgs &w, const cvx
     ia.batch = batch; ia.rho = o.rho; ia.rho_tail = o.rho_tail; ia.tail_from = o.tail_from;
     ia.rq_count = w.rq_count; ia.rq_entries = w.rq_entries; ia.count = count; ia.entries = entries; ia.ws = w.rq_ws; ia.stride = w.rq_stride;
     ia.entries_cap = (int)(batch + cvxw::RESUME_GRID_MAX < 0x7fffffffLL ? batch + cvxw::RESUME_GRID_MAX : 0x7fffffffLL);
-    ia.fcount = fcount; ia.fentries = fentries;
     ia.qs_in = nullptr; ia.z_out = nullptr; ia.s_out = nullptr; ia.gap_out = nullptr; ia.it_out = nullptr;
     if (o.variant == cvx::VAR_RC) hipLaunchKernelGGL(cvxi::ipm_quad_kernel<cvx::VAR_RC>, dim3((unsigned)grid), dim3(64), 0, s, ia);
     else hipLaunchKernelGGL(cvxi::ipm_quad_kernel<cvx::VAR_FULL>, dim3((unsigned)grid), dim3(64), 0, s, ia);
@@ -489,7 +485,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
 #else
     const bool split = false; // (A/B builds: every workload through the fused kernel, as until round 4)
 #endif
-    WsView wv = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    WsView wv = {nullptr, nullptr, nullptr, nullptr, nullptr};
     const int ws_stride = layout == CVXPNPL_LAYOUT_QUAD ? cvxw::RS_FULL : ((lane_hybrid || split) ? cvxw::RS_LANE : 0);
     if (rescue || layout == CVXPNPL_LAYOUT_QUAD || lane_hybrid) {
         if (!get_workspace(batch, ws_stride, stream, wv)) return -2;
@@ -508,11 +504,6 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
         const int64_t qgrid = penta ? (batch + 4) / 5 : (batch + 3) / 4;
         cvxq::QuadArgs qa;
         qa.a = w; qa.o = o; qa.handoff_at = quad_iters; qa.qcount = count; qa.qentries = entries; qa.ws = ws;
-        // Four-correspondence problems with the split interior-point path (round 5): what comes out of the interior-point kernel is
-        // finished FOUR PER WAVEFRONT (solve_quad_kernel<4>: one cold eigen-solve, the attempt, two more iterations) instead of one per
-        // wavefront; what that does not certify -- and the planar scenes -- goes to the wave-per-problem kernel as before.
-        const bool quad_finish = minimal_queued && split;
-        qa.ccount = nullptr; qa.centries = nullptr;
 #ifdef CVXPNPL_EXPERIMENTS // 9: iterations only (tools/phase_a_time.sh); round 4, profiles/r04/tail_experiments.txt: survivors queued (layouts 11: three, 12: two wavefronts per SIMD), extras queued (13)
         if (opts && opts->layout == 9) hipLaunchKernelGGL((cvxq::solve_quad_kernel<1, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (opts && opts->layout == 11 && rc) hipLaunchKernelGGL((cvxq::solve_quad_kernel<2, 3, 16, false, cvx::VAR_RC>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
@@ -538,15 +529,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
             // the wavefronts' own slow survivors (rescue queue) through the interior-point kernel into the resume queue, behind the planar
             // scenes parked there; a parked problem that reaches rescue_from in the resume kernel takes the second round
             for (int round = 0; round < 2; ++round) {
-                const bool fin = quad_finish && round == 1; // (round 0 of this schedule: the rescue queue is still empty)
-                launch_ipm(batch, s, w, o, count, entries, fin ? wv.cq_count : nullptr, fin ? wv.cq_entries : nullptr);
-                if (fin) {
-                    cvxq::QuadArgs qc = qa;
-                    qc.handoff_at = 3;
-                    qc.ccount = wv.cq_count; qc.centries = wv.cq_entries;
-                    if (minimal_queued_f64) hipLaunchKernelGGL((cvxq::solve_quad_kernel<4, 2, 16, true>), dim3((unsigned)qgrid), dim3(64), 0, s, qc);
-                    else hipLaunchKernelGGL((cvxq::solve_quad_kernel<4, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, qc);
-                }
+                launch_ipm(batch, s, w, o, count, entries);
                 launch_resume(rgrid, s, w, o, count, entries, ws, true);
             }
         } else if (rescue) launch_rescue(batch, s, w, o, count, entries, ws); // (both queues in one launch)

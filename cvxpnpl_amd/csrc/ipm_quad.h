@@ -617,7 +617,6 @@ struct IpmQuadArgs {
     int tail_from;
     int32_t *rq_count, *rq_entries; // consumed: the rescue queue
     int32_t *count, *entries;       // produced: the resume queue
-    int32_t *fcount, *fentries;     // (or null) produced instead, for problems in the caller's frame: the queue of the quad schedule's finish kernel
     double *ws;
     int stride;
     int entries_cap;                // positions of rq_entries that may be read
@@ -656,9 +655,7 @@ __global__ void __launch_bounds__(64, CVXI_OCC) ipm_quad_kernel(IpmQuadArgs k)
                 L[P_S + gl * 10 + i] = qv + ((i == gl) ? 1.0 : 0.0);
             }
         }
-        const double it0d = (!direct && live) ? __hip_atomic_load(k.ws + (int64_t)b * k.stride + cvxw::RS_IT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-        const int it0 = (int)it0d;
-        const bool canon_frame = it0d != (double)it0; // (cvxw::solve_pass marks a problem solved in the canonical frame of a planar scene with + 0.5)
+        const int it0 = (!direct && live) ? (int)__hip_atomic_load(k.ws + (int64_t)b * k.stride + cvxw::RS_IT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         double gap;
         long long clk[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         const int nit_why = ipm4_solve<VAR>(L, gl, row_lane0, live, 1e-10, 40, gap, clk);
@@ -686,9 +683,8 @@ __global__ void __launch_bounds__(64, CVXI_OCC) ipm_quad_kernel(IpmQuadArgs k)
         if (direct) return;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if (live && gl == 0) {
-            const bool to_finish = k.fcount != nullptr && !canon_frame;
-            const int p = atomicAdd(to_finish ? k.fcount : k.count, 1);
-            (to_finish ? k.fentries : k.entries)[p] = b;
+            const int p = atomicAdd(k.count, 1);
+            k.entries[p] = b;
         }
         CVXW_SYNC();
         int pn = 0;

@@ -480,9 +480,6 @@ struct QuadArgs {
     int handoff_at;
     int32_t *qcount, *qentries;
     double *ws;
-    // MODE 4 (finish of the interior-point path, four problems per wavefront): the queue cvxi::ipm_quad_kernel fills, consumed four entries
-    // per wavefront (see solve_quad_kernel); handoff_at = the iterations a problem gets here before it goes to the wave-per-problem kernel
-    int32_t *ccount, *centries;
 };
 typedef const __attribute__((address_space(4))) QuadArgs *QuadArgsPtr;
 
@@ -525,26 +522,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
     const int gl = lane - grp * LPP;
     double *L = lds_all + grp * SLICE;
     double2 *L2 = reinterpret_cast<double2 *>(L);
-    int64_t b_raw = (int64_t)blockIdx.x * NPW + grp;
-    if constexpr (MODE == 4) {
-        // finish mode: block i owns positions 4 i .. 4 i + 3 of the queue that cvxi::ipm_quad_kernel filled (the grid covers every position it can have).
-        // Same self-cleaning discipline as cvxw::resume_body, without draws: an empty first position -> leave without touching anything;
-        // otherwise put -1 back over the four entries, and the last block to leave zeroes the counter.
-        int32_t *const centries = k.centries;
-        if (centries[4 * (int64_t)blockIdx.x] < 0) return;
-        const int32_t e = centries[4 * (int64_t)blockIdx.x + (grp < 4 ? grp : 0)];
-        b_raw = (grp < NPW && e >= 0) ? (int64_t)e : a.batch; // (an empty position of the last group: no problem in this row)
-        __builtin_amdgcn_wave_barrier();
-        if (gl == 0 && grp < 4 && e >= -1) centries[4 * (int64_t)blockIdx.x + grp] = -1; // (the test ties the store to the load above)
-        if (lane == 0) {
-            int32_t *const ccount = k.ccount;
-            const int pushed = __hip_atomic_load(ccount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (atomicAdd(ccount + 2, 1) == (pushed + 3) / 4 - 1) {
-                __hip_atomic_store(ccount, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(ccount + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
+    const int64_t b_raw = (int64_t)blockIdx.x * NPW + grp;
     const bool gvalid = grp < NPW && b_raw < a.batch;
     const int64_t b = gvalid ? b_raw : a.batch - 1; // surplus rows redo the last problem, outputs suppressed
 #ifdef CVXQ_TIMELINE // diagnostics build (tools/timeline.py): shader-clock stamps of this wavefront, written over cost[] at the end
@@ -565,16 +543,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
     // ---------------------------------------------------------------- assembly (cvxpnpl.py:20-153, :545-549)
     bool okK = true, okG = true;
     double Qs[EPL];
-    if (MODE == 4) {
-        // finish mode: cost and translation map as the first phase parked them (the interior-point kernel overwrote the iterate and the
-        // iteration count only; device-coherent loads: the slots are reused by every launch)
-        const double *slot = ws + b * cvxw::RS_FULL;
-#pragma unroll
-        for (int m = 0; m < EPL; ++m) Qs[m] = (w.ok(m) && w.ej(m) < 9) ? __hip_atomic_load(slot + cvxw::RS_Q + w.e(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-#pragma unroll
-        for (int m = 0; m < G_::M27; ++m)
-            if (gl + LPP * m < 27) L[Q_B + gl + LPP * m] = __hip_atomic_load(slot + cvxw::RS_B + gl + LPP * m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (a.Q45) {
+    if (a.Q45) {
         // cost entry (the seam of cvxpnpl.py:454-460): A^T A (packed 9x9) and B come from the caller
 #pragma unroll
         for (int m = 0; m < EPL; ++m) Qs[m] = (w.ok(m) && w.ej(m) < 9) ? a.Q45[b * 45 + cvx::qidx(w.ei(m), w.ej(m))] : 0.0;
@@ -774,22 +743,6 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
     for (int i = 0; i < 10; ++i) vd[i] = (gl == i) ? 1.0 : 0.0;
     auto vrow = [&](int i) -> double { if constexpr (F64SW) return vd[i]; else return (double)((i & 1) ? v[i >> 1].y : v[i >> 1].x); };
     int it = 0, total_sweeps = 0, next_check = o.first_check;
-    constexpr int FINISH_IT0 = 64; // (beyond opts.tail_from and the sweep caps of young solves)
-    int it_off = 0;
-    if constexpr (MODE == 4) {
-        const double *slot = ws + b * cvxw::RS_FULL;
-        auto rd = [&](int i) { return __hip_atomic_load(slot + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-#pragma unroll
-        for (int m = 0; m < EPL; ++m) { W[m] = w.ok(m) ? rd(cvxw::RS_W + w.e(m)) : 0.0; Wp[m] = W[m]; }
-        // The four problems of a wavefront come with different iteration counts (first-order + interior-point iterations), and `it` steers
-        // wave-uniform control flow: it counts from FINISH_IT0 for all four and the problem's own count travels as an offset.
-        it_off = -(int)rd(cvxw::RS_IT) - FINISH_IT0; // (a slot of the interior-point kernel: the count is stored negative)
-        it = FINISH_IT0;
-        next_check = it + 1;         // W = Z - S / rho of the interior-point solution: the attempt of the first iteration certifies from it
-        total_sweeps = a.work ? a.work[2 * b + 1] : 0;
-        if (o.tail_from > 0) { rho = o.rho_tail; irho = 1.0 / rho; } // (a problem is past opts.tail_from long before it gets here)
-    }
-    const int my_handoff = MODE == 4 ? FINISH_IT0 + handoff_at : handoff_at; // (finish mode: handoff_at further iterations)
     bool have_prev = false;
     int reused = 0; // consecutive checks that took over the previous check's pose (cvx::REUSE_MAX, see cvx::solve_sdp)
     double fprev = 0.0;
@@ -844,8 +797,7 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
             for (int m = 0; m < EPL; ++m) fro += w.wgt(m) * W[m] * W[m];
             sigma = 1.5 * cvx::sqrt_fast(grp_sum<LPP>(L, gl, fro)) + 1e-300;
             int sweeps = 0;
-            const int sw_cap = (MODE == 4 && it == FINISH_IT0) ? o.jacobi_sweeps // (finish mode: the first eigen-solve starts cold)
-                                                               : (o.sweep_schedule ? cvx::sweep_cap(it + 1, false, o.jacobi_sweeps) : o.jacobi_sweeps); // (the wavefront pays the maximum over its problems)
+            const int sw_cap = o.sweep_schedule ? cvx::sweep_cap(it + 1, false, o.jacobi_sweeps) : o.jacobi_sweeps; // (the wavefront pays the maximum over its problems)
             double g[10];
             float alf = 0.0f; // (single-precision path: squared norm of this lane's column)
             f2 q[5];
@@ -1207,7 +1159,7 @@ CVXQ_PH(5); /* dual fit + correction */
                 }
                 if (gl == 0) {
                     a.status[b] = cvx::ST_CERTIFIED;
-                    if (a.iters) a.iters[b] = it + it_off;
+                    if (a.iters) a.iters[b] = it;
                     if (a.cost) { a.cost[2 * b] = tr * pobj; a.cost[2 * b + 1] = tr * (pobj - zSz - 4.0 * delta); }
                     if (a.work) { a.work[2 * b] = 1; a.work[2 * b + 1] = total_sweeps; }
                 }
@@ -1244,7 +1196,7 @@ CVXQ_PH(6); /* LDL + outputs (or nothing when no check) */
                 if (gl < 3) a.t[b * 3 + gl] = NAN;
                 if (gl == 0) {
                     a.status[b] = cvx::ST_NONFINITE;
-                    if (a.iters) a.iters[b] = it + it_off;
+                    if (a.iters) a.iters[b] = it;
                     if (a.cost) { a.cost[2 * b] = NAN; a.cost[2 * b + 1] = NAN; }
                     if (a.work) { a.work[2 * b] = 0; a.work[2 * b + 1] = total_sweeps; }
                 }
@@ -1257,27 +1209,9 @@ CVXQ_PH(6); /* LDL + outputs (or nothing when no check) */
             }
         }
 CVXQ_PH(7); /* projection + update */
-        if (it >= my_handoff) {
+        if (it >= handoff_at) {
             // ---- hand the unfinished problems to the wave-per-problem kernel
-            if (!done && MODE == 4) {
-                // finish mode: not certified from the interior-point solution within handoff_at iterations -- a relaxation that is not tight, a
-                // twin pair, a solve that stalled: the wave-per-problem kernel's business (twin logic, rank > 1 exits, the grace period of
-                // cvxw::solve_pass: post_ipm).  It goes on the resume queue as a slot of the interior-point kernel would: the iterate and a
-                // NEGATIVE iteration count.
-                double *slot = ws + b * cvxw::RS_FULL;
-#pragma unroll
-                for (int m = 0; m < EPL; ++m)
-                    if (w.ok(m)) park(slot + cvxw::RS_W + w.e(m), W[m]);
-                if (gl == 0) {
-                    park(slot + cvxw::RS_IT, -(double)(it + it_off));
-                    if (a.work) a.work[2 * b + 1] = total_sweeps;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                if (gl == 0) {
-                    const int q = atomicAdd(qcount, 1);
-                    qentries[q] = (int32_t)b;
-                }
-            } else if (!done) {
+            if (!done) {
                 // the iterate, and what this wavefront has that the next one would otherwise rebuild: cost, B, eigenvectors
                 double *slot = ws + b * cvxw::RS_FULL;
 #pragma unroll
@@ -1308,7 +1242,6 @@ CVXQ_PH(7); /* projection + update */
     unsigned pmask = 0;
 #pragma unroll
     for (int g = 0; g < NPW; ++g) pmask |= (unsigned)((pm >> (LPP * g)) & 1ull) << g;
-    if (MODE == 4) return; // (its survivors are on the rescue queue already)
     if (MODE == 1 || MODE == 2) { // every survivor (MODE 1: every problem -- it makes no attempts) goes to the queue of the resume kernel launched behind this one: no wave-per-problem code in this kernel
         if (parked && gvalid && gl == 0) {
             const int q = atomicAdd(qcount, 1);

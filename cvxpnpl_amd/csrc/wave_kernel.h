@@ -815,7 +815,10 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
     // first-order iterations has a relaxation that is not tight (or one whose interior-point solve stalled), and exits through the
     // reference's recovery from the Z it has instead of crawling to the rank-stall rule (measured: one of 50 000 rc problems ran 1 625
     // iterations that way and held the launch for 8 ms; the slowest problem that does certify after a hand-over takes 47).
-    constexpr int IPM_GRACE = 64;
+#ifndef CVXW_IPM_GRACE
+#define CVXW_IPM_GRACE 64
+#endif
+    constexpr int IPM_GRACE = CVXW_IPM_GRACE;
     const int ipm_deadline = (IPM && after_ipm) ? it_io + IPM_GRACE : (post_ipm ? it + IPM_GRACE : 0x7fffffff);
     while (!done && it < rescue_cap) {
         double sigma = 0.0;
@@ -1269,9 +1272,7 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
         if (a.rq_ws) { // split path: the interior-point kernel runs nothing but the solve -- it finds the cost (solver's frame) in the slot
             double *slot = a.rq_ws + (int64_t)b * a.rq_stride;
             if (lane < 55) __hip_atomic_store(slot + RS_W + lane, ej < 9 ? Qs : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // (+ 0.5: the problem is solved in the canonical frame of a planar scene -- its finish after the interior-point solve belongs to
-            //  this kernel's twin logic, not to the four-per-wavefront finish of the quad schedule: cvxi::ipm_quad_kernel routes by it)
-            if (lane == 0) __hip_atomic_store(slot + RS_IT, (double)it + (canon ? 0.5 : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(slot + RS_IT, (double)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         }
         if (lane == 0) {
