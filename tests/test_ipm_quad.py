@@ -98,3 +98,27 @@ def test_four_per_wavefront_solve(variant, n, n_pts, sigma):
     tight = (lam[:, -2] < 1e-6) & both
     if tight.any():
         assert np.abs(Z[tight] - Zh[tight]).max() < 1e-3, np.abs(Z[tight] - Zh[tight]).max()
+
+
+@pytest.mark.gpu
+def test_degenerate_costs_end_the_solve_without_hanging():
+    """a NaN cost, a zero cost, an empty batch: the kernel's loops are bounded by iteration counts, never by the data"""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import cvxpnpl_amd as ca
+    from cvxpnpl_amd import _lib
+
+    Q45, _ = _costs(8, 4, 2.0, 9)
+    Q45[1] = np.nan                     # NaN: no factorisation succeeds -> the solve ends at once
+    Q45[2, 1:] = 0.0                    # a rank-one cost e0 e0^T
+    Z, S, gap, it = [x.cpu().numpy() for x in ca.ipm_batch(torch.as_tensor(Q45, device="cuda"))]
+    assert (it[1] & 255) == 0 and (it[1] >> 8) in (2, 3, 4, 5)          # stopped by a failed factorisation / no step / no progress
+    ok = np.array([0, 2, 3, 4, 5, 6, 7])
+    assert np.isfinite(Z[ok]).all() and np.isfinite(S[ok]).all() and (gap[ok] < 1e-6).all()
+    L = _lib.lib()
+    assert L.cvxpnpl_ipm_batch(0, None, 0, None, None, None, None, None) == -1     # (null pointers are refused even for an empty batch)
+    z = torch.empty((1, 100), dtype=torch.float64, device="cuda")
+    assert L.cvxpnpl_ipm_batch(0, z.data_ptr(), 0, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), None) == 0
+    assert L.cvxpnpl_ipm_batch(4, z.data_ptr(), 7, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), None) == -1   # unknown variant

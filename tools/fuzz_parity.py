@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity campaign: HIP path (every layout) vs the CPU oracle over many problem shapes and noise
-levels (GPU box, repo root):  python tools/fuzz_parity.py [n_configs] [problems_per_config] [f64]
-("f64": every layout with opts.f32_sweeps_until = 0 -- the float64 instantiations, round 4: cvxl::lane_phase_f64 among them)
+levels (GPU box, repo root):  python tools/fuzz_parity.py [n_configs] [problems_per_config] [f64] [minimal]
+("minimal": four to six correspondences only -- the configurations whose slow problems go through the interior-point path, csrc/ipm_quad.h;
+ "f64": every layout with opts.f32_sweeps_until = 0 -- the float64 instantiations, round 4: cvxl::lane_phase_f64 among them)
 One line per configuration + a summary; certified GPU poses are compared with the oracle's converged solve
 (rotation geodesic, relative translation).  Diagnostics / evidence tool (uses the oracle: not product code)."""
 import os
@@ -20,6 +21,7 @@ from cvxpnpl_amd import synth  # noqa: E402
 ncfg = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 nprob = int(sys.argv[2]) if len(sys.argv) > 2 else 192
 extra = {"f32_sweeps_until": 0} if "f64" in sys.argv[3:] else {}
+minimal = "minimal" in sys.argv[3:]
 rs = np.random.RandomState(2026)
 dev = torch.device("cuda:0")
 worst = {"rot": 0.0, "t": 0.0}
@@ -31,6 +33,13 @@ for c in range(ncfg):
     n_l = int(rs.randint(4, 13)) if kind == "pnl" else (int(rs.randint(1, 9)) if kind == "pnpl" else 0)
     if kind == "pnpl":
         n_p = int(rs.randint(2, 13))
+    if minimal:  # at most six correspondences (a line counts as one)
+        if kind == "pnp":
+            n_p = int(rs.randint(4, 7))
+        elif kind == "pnl":
+            n_l = int(rs.randint(4, 7))
+        else:
+            n_p = int(rs.randint(2, 4)); n_l = int(rs.randint(2, 4))
     sigma = float(rs.choice([0.0, 0.5, 1.0, 2.0, 5.0]))
     d = synth.make_pnpl(nprob, n_p, n_l, sigma, seed=5000 + c)
     tt = lambda x: torch.as_tensor(x, device=dev)  # noqa: E731
@@ -51,6 +60,6 @@ for c in range(ncfg):
         tot += nprob; cert += int((st == 0).sum()); cmp_ += int(ok.sum()); mism += bad
         line += f" {name} cert {np.mean(st == 0):.3f} rot {g:.1e} t {e:.1e}" + (f" MISMATCH {bad}" if bad else "")
     print(line, flush=True)
-print(("float64 sweeps (f32_sweeps_until = 0) -- " if extra else "") + f"summary: {ncfg} configurations x {nprob} problems x 4 layouts = {tot} solves, {cert} certified, {cmp_} compared with a "
+print(("float64 sweeps (f32_sweeps_until = 0) -- " if extra else "") + ("minimal configurations (4-6 correspondences) -- " if minimal else "") + f"summary: {ncfg} configurations x {nprob} problems x 4 layouts = {tot} solves, {cert} certified, {cmp_} compared with a "
       f"converged single-pose oracle solve, {mism} beyond 1e-6; worst rotation {worst['rot']:.2e} rad, worst relative "
       f"translation {worst['t']:.2e}; {time.time() - t0:.0f} s")
