@@ -453,6 +453,31 @@ def score_hypotheses(R, t, K, pts_2d, pts_3d, thresh: float = 2.0, status=None, 
     return (count, mask) if want_mask else count
 
 
+def assemble_subsets(pts_2d, pts_3d, K, mask):
+    """Constraint assembly for subsets of ONE scene (cvxpnpl_assemble_subsets): pts_2d [M,2], pts_3d [M,3], mask [B,M] (non-zero = taken, e.g.
+    the mask of score_hypotheses) -> (B27 [B,27], Q45 [B,45], count [B] int32) on the device; feed solve_cost_batch.  The refit of a RANSAC
+    consensus set without a host round trip for its size."""
+    _require_gpu()
+    L = _lib.lib()
+    dev = mask.device if isinstance(mask, torch.Tensor) and mask.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    x = _as_dev(pts_2d, dev, (2,)).reshape(-1, 2)
+    X = _as_dev(pts_3d, dev, (3,)).reshape(-1, 3)
+    Kd = _as_dev(K, dev, (3, 3)).reshape(3, 3)
+    M = X.shape[0]
+    mk = torch.as_tensor(mask).to(device=dev).ne(0).to(torch.uint8).reshape(-1, M).contiguous()
+    Bn = mk.shape[0]
+    if x.shape[0] != M:
+        raise ValueError(f"{x.shape[0]} 2D points for {M} 3D points")
+    with torch.cuda.device(dev):
+        Bt = torch.empty((Bn, 27), dtype=torch.float64, device=dev)
+        Qt = torch.empty((Bn, 45), dtype=torch.float64, device=dev)
+        cnt = torch.empty((Bn,), dtype=torch.int32, device=dev)
+        rc = L.cvxpnpl_assemble_subsets(Bn, M, _ptr(x), _ptr(X), _ptr(mk), _ptr(Kd), _ptr(Bt), _ptr(Qt), _ptr(cnt), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"cvxpnpl_assemble_subsets failed ({rc}): {_lib.last_error()}")
+    return Bt, Qt, cnt
+
+
 def sample_minimal_sets(pts_2d, pts_3d, n_hyp: int, k: int = 4, seed: int = 0, want_idx: bool = False):
     """k distinct correspondences of the scene per hypothesis, drawn uniformly and gathered into the inputs of a minimal solve
     (cvxpnpl_sample_minimal_sets: one HIP launch; counter-based Philox stream, reproducible per (seed, hypothesis)).

@@ -133,6 +133,38 @@ __global__ void __launch_bounds__(64) assemble_kernel(BatchArgs a, double *Bout,
         for (int i = 0; i < 45; ++i) Qout[b * 45 + i] = ok ? Q9[i] : NAN;
 }
 
+// Assembly for subsets of ONE scene: problem b takes the correspondences m with mask[b][m] != 0 (the refit of a RANSAC consensus set:
+// the mask is what cvxs::score_kernel wrote, so that the size of the set never has to travel to the host).  One lane per problem; the
+// Gram sums are the ones of cvx::assemble, taken about the same kind of centre (median of the scene's first three points: any centre is
+// exact).  Fewer than three correspondences give a singular N^T N: NaN, as cvx::assemble reports it.
+__global__ void __launch_bounds__(64) assemble_subsets_kernel(int64_t batch, int n_corr, const double *s2, const double *s3, const uint8_t *mask, const double *K,
+                                                              double *Bout, double *Qout, int32_t *count)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    double Kc[9], Ki[9], det;
+    for (int i = 0; i < 9; ++i) Kc[i] = K[i];
+    cvx::inv3(Kc, Ki, det);
+    cvx::Gram g;
+    cvx::gram_zero(g);
+    double c[3];
+    cvx::shift_centre(n_corr, s3, 0, nullptr, c);
+    const uint8_t *mk = mask + b * n_corr;
+    int n = 0;
+    for (int m = 0; m < n_corr; ++m) {
+        if (!mk[m]) continue;
+        cvx::gram_add_point(g, Ki, s2[2 * m], s2[2 * m + 1], s3[3 * m] - c[0], s3[3 * m + 1] - c[1], s3[3 * m + 2] - c[2]);
+        ++n;
+    }
+    double B[27], Q9[45];
+    bool ok = n >= 3 && cvx::gram_finish(g, B, Q9) && (det == det) && det != 0.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) B[i * 9 + 3 * j + i] += c[j];
+    for (int i = 0; i < 27; ++i) Bout[b * 27 + i] = ok ? B[i] : NAN;
+    for (int i = 0; i < 45; ++i) Qout[b * 45 + i] = ok ? Q9[i] : NAN;
+    if (count) count[b] = n;
+}
+
 // Scratch of the hybrid schedules, one per (device, stream): [0, 256) the counters of the two queues (resume: ints 0..2,
 // rescue: ints 16..18), then the entries of the resume queue and of the rescue queue
 // (int32, -1 = empty; batch + RESUME_GRID_MAX of them each) and the parked iterates [batch][56] doubles (only the
@@ -615,6 +647,20 @@ int cvxpnpl_assemble_batch(int64_t batch, int32_t n_p, const double *d_pts_2d, c
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err("assemble_kernel launch", e);
     return 0;
+}
+
+int cvxpnpl_assemble_subsets(int64_t batch, int32_t n_corr, const double *d_scene_2d, const double *d_scene_3d, const uint8_t *d_mask, const double *d_K,
+                             double *d_B, double *d_Q45, int32_t *d_count, void *stream)
+{
+    if (batch < 0 || n_corr < 1 || (batch + 63) / 64 > 0x7fffffffLL || (batch > 0 && (!d_scene_2d || !d_scene_3d || !d_mask || !d_K || !d_B || !d_Q45))) {
+        snprintf(g_err, sizeof(g_err), "cvxpnpl_assemble_subsets: bad arguments");
+        return -1;
+    }
+    if (batch == 0) return 0;
+    hipLaunchKernelGGL(assemble_subsets_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, (hipStream_t)stream, batch, (int)n_corr, d_scene_2d, d_scene_3d,
+                       d_mask, d_K, d_B, d_Q45, d_count);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : set_err("assemble_subsets_kernel launch", e);
 }
 
 size_t cvxpnpl_assemble_large_scratch_bytes(int64_t batch, int32_t n_p, int32_t n_l)

@@ -2,15 +2,15 @@
 
 The reference has no RANSAC; this is the natural consumer of tens of thousands of minimal
 hypotheses per frame: sample 4-subsets, solve them all in one launch, score every hypothesis by
-reprojection inliers over the whole scene, refit the best consensus set with one more (N = #inliers)
-solve.  Sampling, the solves and the scoring are the HIP path (cvxpnpl_sample_minimal_sets, cvxpnpl_solve_batch,
-cvxpnpl_score_hypotheses); torch takes the arg-max.
+reprojection inliers over the whole scene, refit the best consensus set (assembled on the device from scene + inlier mask,
+solved at the cost seam: no host round trip inside a frame).  Sampling, the solves and the scoring are the HIP path (cvxpnpl_sample_minimal_sets, cvxpnpl_solve_batch,
+cvxpnpl_score_hypotheses, cvxpnpl_assemble_subsets, cvxpnpl_solve_cost_batch); torch takes the arg-max.
 """
 from typing import Optional
 
 import torch
 
-from .api import pnp_batch, sample_minimal_sets, score_hypotheses
+from .api import assemble_subsets, pnp_batch, sample_minimal_sets, score_hypotheses, solve_cost_batch
 
 
 def reprojection_inliers(R: torch.Tensor, t: torch.Tensor, K: torch.Tensor, pts_3d: torch.Tensor, pts_2d: torch.Tensor,
@@ -21,11 +21,12 @@ def reprojection_inliers(R: torch.Tensor, t: torch.Tensor, K: torch.Tensor, pts_
 
 
 def ransac_pnp(pts_2d, pts_3d, K, n_hyp: int = 4096, thresh: float = 2.0, max_iters: int = 100, eps: float = 1e-6,
-               seed: Optional[int] = 0, refit: bool = True, device=None):
+               seed: Optional[int] = 0, refit: bool = True, device=None, refit_rounds: int = 1):
     """Robust PnP for one scene with outliers.
 
     pts_2d [M,2], pts_3d [M,3] (numpy or torch), K [3,3].  Returns dict with R [3,3], t [3],
-    inliers [M] bool, n_inliers, status of the final solve, n_certified hypotheses.
+    inliers [M] bool, n_inliers, status of the final solve, n_certified hypotheses.  refit_rounds: refits of the consensus set (each one
+    assembly + solve + scoring launch; no host synchronisation inside a frame, whatever the count).
     """
     if device is None:  # like pnpl_batch: the device of a CUDA input, else the current device
         for a in (pts_3d, pts_2d, K):
@@ -46,23 +47,29 @@ def ransac_pnp(pts_2d, pts_3d, K, n_hyp: int = 4096, thresh: float = 2.0, max_it
     x4, X4 = sample_minimal_sets(x, X, n_hyp, 4, seed)
     res = pnp_batch(x4, X4, Kd, eps=eps, max_iters=max_iters)
     score = score_hypotheses(res.R, res.t, Kd, x, X, thresh, status=res.status, usable=(0, 2))
-    # From here on the host needs a few integers (the size of the consensus set is the N of the refit, a host argument of the solve); each
-    # read-back is a synchronisation of ~40 us, so they are batched: ONE per stage instead of one per number.
-    best = torch.argmax(score).reshape(1)                      # stays on the device
-    R, t = res.R.index_select(0, best)[0], res.t.index_select(0, best)[0]
-    mask = reprojection_inliers(R[None], t[None], Kd, X, x, thresh)[0]
-    head = torch.stack([res.status.index_select(0, best)[0].to(torch.int64), mask.sum(), (res.status == 0).sum()]).cpu()   # sync 1
-    final_status, n_inl, n_cert = int(head[0]), int(head[1]), int(head[2])
-    if refit and n_inl >= 4:
-        for _ in range(2):  # refit on the consensus set, re-evaluate it once
-            sel = torch.argsort((~mask).to(torch.int8), stable=True)[:n_inl]   # the inliers' indices, in order, without a host round trip
-            fit = pnp_batch(x.index_select(0, sel)[None], X.index_select(0, sel)[None], Kd, eps=1e-9, max_iters=2500)
-            new = reprojection_inliers(fit.R, fit.t, Kd, X, x, thresh)[0]
-            st_new = torch.stack([fit.status[0].to(torch.int64), new.sum()]).cpu()   # sync 2 (3)
-            if int(st_new[0]) not in (0, 2):
-                break
-            R, t, final_status = fit.R[0], fit.t[0], int(st_new[0])
-            if int(st_new[1]) <= n_inl:
-                break
-            mask, n_inl = new, int(st_new[1])
-    return {"R": R, "t": t, "inliers": mask, "n_inliers": n_inl, "status": final_status, "n_certified": n_cert, "n_hyp": n_hyp}
+    # From here on everything stays on the device until the one read-back at the end (round 5): the consensus set of the best hypothesis
+    # is a MASK (cvxpnpl_score_hypotheses), the refit assembles straight from scene + mask (cvxpnpl_assemble_subsets -- the size of the
+    # set, which used to be the N of a second cvxpnpl_solve_batch call and so a host argument, never leaves the device) and solves at the
+    # cost seam; the refit's pose is taken (torch.where) when it is usable and keeps at least the consensus it was fitted to.
+    best = torch.argmax(score).reshape(1)
+    R, t = res.R.index_select(0, best), res.t.index_select(0, best)          # [1,3,3], [1,3]
+    status = res.status.index_select(0, best).to(torch.int64)               # [1]
+    n_inl, mask = score_hypotheses(R, t, Kd, x, X, thresh, want_mask=True)   # [1], [1,M]
+    n_inl = n_inl.to(torch.int64)
+    if refit:
+        for _ in range(max(1, int(refit_rounds))):  # refit on the consensus set (a second round re-fits the set the first one found)
+            Bt, Qt, cnt = assemble_subsets(x, X, Kd, mask)
+            fit = solve_cost_batch(Qt, Bt, eps=1e-9, max_iters=2500, device=device)
+            n_new, mask_new = score_hypotheses(fit.R, fit.t, Kd, x, X, thresh, want_mask=True)
+            n_new = n_new.to(torch.int64)
+            st_new = fit.status.to(torch.int64)
+            usable = ((st_new == 0) | (st_new == 2)) & (cnt.to(torch.int64) >= 4)
+            take = usable & (n_new >= n_inl)          # (the refit of the same set is the better pose for it; a smaller set is not taken)
+            grow = usable & (n_new > n_inl)
+            R = torch.where(take[:, None, None], fit.R, R)
+            t = torch.where(take[:, None], fit.t, t)
+            status = torch.where(take, st_new, status)
+            mask = torch.where(grow[:, None], mask_new, mask)
+            n_inl = torch.where(grow, n_new, n_inl)
+    head = torch.stack([status[0], n_inl[0], (res.status == 0).sum()]).cpu()   # the frame's one synchronisation
+    return {"R": R[0], "t": t[0], "inliers": mask[0].bool(), "n_inliers": int(head[1]), "status": int(head[0]), "n_certified": int(head[2]), "n_hyp": n_hyp}

@@ -287,6 +287,16 @@ int cvxpnpl_score_hypotheses(int64_t n_hyp, const double *d_R, const double *d_t
                              int32_t *d_count, uint8_t *d_mask, void *stream);
 
 /*
+ * Constraint assembly for SUBSETS of one scene (same row of SURVEY.md section 8(f); the refit of a RANSAC consensus set without a host
+ * round trip for its size): problem b takes the correspondences m of d_scene_2d [n_corr][2], d_scene_3d [n_corr][3] with
+ * d_mask[b * n_corr + m] != 0 -- e.g. the mask cvxpnpl_score_hypotheses wrote.  Outputs as cvxpnpl_assemble_batch (d_B [batch][27],
+ * d_Q45 [batch][45]: feed cvxpnpl_solve_cost_batch) and, if not NULL, d_count [batch] = correspondences taken.  A subset of fewer than
+ * three correspondences gives NaN (-> status 3 in the solve).  DEVICE pointers.  Returns 0, -1 bad arguments, -2 HIP error.
+ */
+int cvxpnpl_assemble_subsets(int64_t batch, int32_t n_corr, const double *d_scene_2d, const double *d_scene_3d, const uint8_t *d_mask, const double *d_K,
+                             double *d_B, double *d_Q45, int32_t *d_count, void *stream);
+
+/*
  * Minimal sets for the hypotheses of a RANSAC frame (same row of SURVEY.md section 8(f) as the scoring above; no reference counterpart):
  * for every hypothesis k (1 ... 8) DISTINCT correspondences of the scene d_scene_2d [n_corr][2], d_scene_3d [n_corr][3], uniformly at
  * random (partial Fisher-Yates on a counter-based stream, Philox4x32-10 keyed by `seed` with counter (hypothesis, draw): every hypothesis

@@ -169,3 +169,41 @@ def test_device_minimal_set_sampler_matches_numpy_restatement(gpu):
         assert np.array_equal(p2.cpu().numpy(), x[idx]) and np.array_equal(p3.cpu().numpy(), X[idx])
     with pytest.raises(ValueError):
         ca.sample_minimal_sets(torch.zeros((3, 2), device=gpu), torch.zeros((3, 3), device=gpu), 10, 4)
+
+
+@pytest.mark.gpu
+def test_subset_assembly_equals_the_assembly_of_the_gathered_subset():
+    """cvxpnpl_assemble_subsets (the device-side refit of a RANSAC consensus set): B, Q of scene + mask against cvxpnpl_assemble_batch on the
+    gathered correspondences -- same cost (1e-12 relative; the centres of the Gram sums differ) and the same solved pose; counts; a subset of
+    two correspondences gives NaN."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import cvxpnpl_amd as ca
+    from cvxpnpl_amd import synth
+
+    d = synth.make_ransac(8, n_corr=60, outlier_frac=0.3, sigma=0.5, seed=11)
+    x, X, K = (torch.as_tensor(d[k], device="cuda") for k in ("scene_2d", "scene_3d", "K"))
+    rs = np.random.RandomState(5)
+    mask = (rs.rand(6, 60) < 0.5).astype(np.uint8)
+    mask[4] = 0; mask[4, [3, 17]] = 1            # two correspondences: singular
+    mask[5] = 1                                  # the whole scene
+    Bt, Qt, cnt = ca.assemble_subsets(x, X, K, torch.as_tensor(mask, device="cuda"))
+    assert (cnt.cpu().numpy() == mask.sum(axis=1)).all()
+    assert torch.isnan(Bt[4]).all() and torch.isnan(Qt[4]).all()
+    for b in (0, 1, 2, 3, 5):
+        sel = np.flatnonzero(mask[b])
+        Bg, Qg = ca.assemble_batch(x[sel][None], None, X[sel][None], None, K)
+        scale = float(Qg.abs().max())
+        assert float((Qt[b] - Qg[0]).abs().max()) <= 1e-11 * scale
+        assert float((Bt[b] - Bg[0]).abs().max()) <= 1e-9 * max(1.0, float(Bg.abs().max()))
+    fit = ca.solve_cost_batch(Qt[[0, 1, 2, 3, 5]], Bt[[0, 1, 2, 3, 5]])
+    ref = [ca.pnp_batch(x[np.flatnonzero(mask[b])][None], X[np.flatnonzero(mask[b])][None], K) for b in (0, 1, 2, 3, 5)]
+    for i, r in enumerate(ref):
+        assert int(fit.status[i]) == int(r.status[0])
+        assert synth.geodesic(fit.R[i].cpu().numpy(), r.R[0].cpu().numpy()) < 1e-8
+        assert float((fit.t[i] - r.t[0]).abs().max()) < 1e-8
+    L = __import__("cvxpnpl_amd._lib", fromlist=["lib"]).lib()
+    assert L.cvxpnpl_assemble_subsets(0, 60, None, None, None, None, None, None, None, None) == 0
+    assert L.cvxpnpl_assemble_subsets(4, 0, None, None, None, None, None, None, None, None) == -1
