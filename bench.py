@@ -603,8 +603,8 @@ def main():
         ransac_frame = {
             "frames_per_s": 1.0 / dtf, "ms_per_frame": 1e3 * dtf, "hypotheses_per_s_whole_frame": batch / dtf, "frames": nf,
             "what": "cvxpnpl_amd.ransac.ransac_pnp: draw 4-subsets on the device, cvxpnpl_solve_batch, cvxpnpl_score_hypotheses (2 px), arg-max, "
-                    "refit on the consensus set (up to two more solves with N = #inliers), reference defaults eps / max_iters; wall clock incl. "
-                    "the host round trip the refit needs (its N is a host argument)",
+                    "refit on the consensus set assembled on the device from scene + inlier mask (cvxpnpl_assemble_subsets -> cvxpnpl_solve_cost_batch -> one "
+                    "more scoring launch), reference defaults eps / max_iters; wall clock, one host synchronisation per frame (at its end)",
             "score_kernel": {"ms": score_ms, "hypotheses_per_s": batch / (1e-3 * score_ms), "scene_correspondences": M_,
                              "bound": "compute: H x M x ~30 flop (projection + divide + compare) against 100 B per hypothesis -- "
                                       f"{batch * M_ * 30 / (1e-3 * score_ms) / 1e12:.2f} TFLOP/s f64 of 78.6; HBM {batch * 104 / (1e-3 * score_ms) / 1e9:.1f} GB/s"},
