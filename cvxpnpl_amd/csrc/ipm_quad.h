@@ -82,8 +82,6 @@ __device__ __forceinline__ double rcp_(double x) { return cvxw::fast_rcp(x); }
 #else
 #define CVXI_CLK(k) do { } while (0)
 #endif
-// keeps the scheduler from hoisting every LDS read of a long unrolled block to its top (and spilling what it fetched early)
-#define CVXI_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // constraint rows as compile-time data: term k of row i is coef * sym(E_rc)
 template <int VAR> struct Rows {
@@ -116,7 +114,6 @@ __device__ __forceinline__ void apply_dS(const double (&dy)[21], const double (&
     for (int i = 0; i < R::NR; ++i)
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            constexpr int dummy = 0; (void)dummy;
             const int a = R::r(i, k), b = R::c(i, k), s = R::s(i, k);
             if (s == 0) continue;
             const double v = s > 0 ? -dy[i] : dy[i];
