@@ -460,7 +460,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     const bool penta = penta_req && !(o.f32_sweeps_until < quad_iters); // (float64 sweeps: built for the sixteen-lane geometry only)
     if (layout == 9 || layout == 11 || layout == 12 || layout == 13 || penta_req) layout = CVXPNPL_LAYOUT_QUAD; // (9: experiment (tools/README.md): quad iterations only, 3 waves/SIMD, solve_quad_kernel<1>)
     if (layout == CVXPNPL_LAYOUT_QUAD && !(quad_iters >= 1 && o.max_iters > quad_iters)) layout = CVXPNPL_LAYOUT_WAVE;
-    if (layout == CVXPNPL_LAYOUT_QUAD && rc && o.f32_sweeps_until < quad_iters) layout = CVXPNPL_LAYOUT_WAVE; // (rc quad kernel: single-precision sweeps only)
+    // (rc with float64 sweeps: solve_quad_kernel<0, 2, 16, true, VAR_RC> since round 5 -- until then such a request ran the wave layout)
     // First certificate attempt (0 = by layout): after 5 iterations 94 % of N = 10 problems certify, after 6 99 %.  In the lane-hybrid
     // schedule every problem that fails the first attempt is parked and resumed one per wavefront, so the later attempt pays for its
     // extra iteration: 125 k problems 157 -> 164 M poses/s, PnPL 100 k 116 -> 126 M.  The quad and wave layouts keep 5 (quad with 6, launch
@@ -553,6 +553,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
             // hypotheses/s (with the first attempt after 17 iterations, above: 14.9 / 24.0 M); the same schedule LOSES on the N = 10 launches, whose few survivors then start late (tail_experiments.txt).
             hipLaunchKernelGGL((cvxq::solve_quad_kernel<2, 3>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (penta) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 12>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
+        else if (rc && o.f32_sweeps_until < quad_iters) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 16, true, cvx::VAR_RC>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (rc) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 16, false, cvx::VAR_RC>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
         else if (o.f32_sweeps_until < quad_iters) hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2, 16, true>), dim3((unsigned)qgrid), dim3(64), 0, s, qa); // float64 sweeps (A/B mode)
         else hipLaunchKernelGGL((cvxq::solve_quad_kernel<0, 2>), dim3((unsigned)qgrid), dim3(64), 0, s, qa);
