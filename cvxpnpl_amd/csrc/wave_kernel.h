@@ -531,25 +531,35 @@ template <int VAR, bool IPM>
 __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o, const int64_t b, double *L, const double *resume, const bool resume_full_in,
                                            const bool after_ipm, int &it_io, int &sweeps_io)
 {
-    const int lane = threadIdx.x & 63;
+    int lane_ = threadIdx.x & 63;
     double2 *L2 = reinterpret_cast<double2 *>(L);
 
     // ---------------------------------------------------------------- lane roles
-    const unsigned lw = kLanePack.w[lane];
-    const int ei = (int)(lw & 15), ej = (int)((lw >> 4) & 15);
-    const int el = lane < 55 ? lane : lane - 55;      // entry index (lanes 55..63 alias 0..8, weight 0)
-    const double wgt = lane < 55 ? (ei == ej ? 1.0 : 2.0) : 0.0;
-    const bool is_diag = ((lw >> 23) & 1) != 0;
-    const int p1 = (int)((lw >> 8) & 63), p2 = (int)((lw >> 14) & 63);
-    const double s0 = ((lw >> 20) & 1) ? -1.0 : 1.0, s1 = ((lw >> 21) & 1) ? -1.0 : 1.0, s2 = ((lw >> 22) & 1) ? -1.0 : 1.0;
-    Roles roles;
-    roles.lane = lane; roles.el = el; roles.ei = ei; roles.ej = ej; roles.p1 = p1; roles.p2 = p2;
-    roles.is_diag = is_diag; roles.s0 = s0; roles.s1 = s1; roles.s2 = s2;
-    roles.xsrc = (int)((lw >> 24) & 15);
-    roles.xsgn = ((lw >> 28) & 3) == 0 ? 0.0 : (((lw >> 28) & 3) == 1 ? 1.0 : -1.0);
+    // Everything below is derived from the lane index and one packed word -- loop-invariant, so LLVM hoists it all out of the iteration
+    // loop and keeps ~25 registers of it live across every phase (the kernel's spills, reloaded from scratch inside the loop: a round
+    // trip to L2 on a chain that has nothing to hide it behind).  CVXW_ROLES declares the set; it is instantiated here and again at the
+    // top of every iteration from copies that an empty asm hides (cf. cvxq::Own::refresh, cvxi::ipm4_solve), so that the values are
+    // recomputed where they are used (a bit-field extract each) and die there.
+    unsigned lw_ = kLanePack.w[lane_];
+#define CVXW_ROLES(LANE, LW)                                                                                                                          \
+    const int lane = (LANE);                                                                                                                          \
+    const unsigned lw = (LW);                                                                                                                         \
+    const int ei = (int)(lw & 15), ej = (int)((lw >> 4) & 15);                                                                                        \
+    const int el = lane < 55 ? lane : lane - 55; /* entry index (lanes 55..63 alias 0..8, weight 0) */                                                \
+    const double wgt = lane < 55 ? (ei == ej ? 1.0 : 2.0) : 0.0;                                                                                      \
+    const bool is_diag = ((lw >> 23) & 1) != 0;                                                                                                       \
+    const int p1 = (int)((lw >> 8) & 63), p2 = (int)((lw >> 14) & 63);                                                                                \
+    const double s0 = ((lw >> 20) & 1) ? -1.0 : 1.0, s1 = ((lw >> 21) & 1) ? -1.0 : 1.0, s2 = ((lw >> 22) & 1) ? -1.0 : 1.0;                          \
+    Roles roles;                                                                                                                                      \
+    roles.lane = lane; roles.el = el; roles.ei = ei; roles.ej = ej; roles.p1 = p1; roles.p2 = p2;                                                     \
+    roles.is_diag = is_diag; roles.s0 = s0; roles.s1 = s1; roles.s2 = s2;                                                                             \
+    roles.xsrc = (int)((lw >> 24) & 15);                                                                                                              \
+    roles.xsgn = ((lw >> 28) & 3) == 0 ? 0.0 : (((lw >> 28) & 3) == 1 ? 1.0 : -1.0);                                                                  \
+    const int jl = lane < 50 ? lane : lane - 50; /* jacobi lane (50..63 alias 0..13) */                                                               \
+    const int ji = jl % 10, jk = jl / 10;                                                                                                             \
+    (void)wgt; (void)ji; (void)jk; (void)p1; (void)p2; (void)s0; (void)s1; (void)s2; (void)is_diag; (void)el
+    CVXW_ROLES(lane_, lw_);
     CVXW_PH_DECL;
-    const int jl = lane < 50 ? lane : lane - 50;      // jacobi lane (50..63 alias 0..13)
-    const int ji = jl % 10, jk = jl / 10;
 
     // A slot whose iteration count is NEGATIVE comes from cvxw::ipm_wave_kernel (split interior-point path): W = Z - S / rho of the
     // interior-point solution, ALREADY in the solver's frame, nothing else -- the problem is assembled again whatever the slot format,
@@ -821,6 +831,10 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
     constexpr int IPM_GRACE = CVXW_IPM_GRACE;
     const int ipm_deadline = (IPM && after_ipm) ? it_io + IPM_GRACE : (post_ipm ? it + IPM_GRACE : 0x7fffffff);
     while (!done && it < rescue_cap) {
+#ifndef CVXW_NO_ROLE_REFRESH
+        asm volatile("" : "+v"(lane_), "+v"(lw_));
+        CVXW_ROLES(lane_, lw_); // (shadows the set of the function scope for the body of the loop)
+#endif
         double sigma = 0.0;
         if (it == 0 && !resume && o.first_check > 1 && o.max_iters > 1) {
             // W0 = e9 e9^T is diagonal and PSD: Wp = W0, eigenvectors = unit vectors, no eigen-solve
