@@ -285,20 +285,30 @@ __device__ __forceinline__ void pair_cs(float d, float gam, bool rot, bool tie_n
 }
 
 // The same in float64 throughout (F64SW instantiation: Opts::f32_sweeps_until below the length of this phase -- the reference's
-// precision; seeds v_rsq_f64 + Newton steps, <= 2 ulp)
-__device__ __forceinline__ void pair_cs_f64(double d, double gam, bool rot, bool tie_neg, double &c, double &s, double &t)
+// precision).  ONE full-precision reciprocal root on the chain instead of two: with h ~ sqrt(d^2 + 4 gam^2) from the raw hardware seed
+// (v_rsq_f64, ~2^-23) and u = h + |d|,
+//     c = u / sqrt(u^2 + 4 gam^2),   s = +-2 gam / sqrt(u^2 + 4 gam^2)
+// is a rotation to the precision of that one root WHATEVER the error of h (c^2 + s^2 = 1 identically); the error of h only moves the angle
+// by ~1e-7 of itself, i.e. leaves 1e-7 of the pair's inner product standing -- the sweeps end at |cos| < jacobi_tol = 6e-2 and start from
+// the previous iteration's vectors.  dl: the change of the squared norms under the rotation that is actually applied,
+// |own'|^2 = |own|^2 + dl, |other'|^2 = |other|^2 - dl (exact for any angle; the norms are recomputed once per sweep as before).
+__device__ __forceinline__ void pair_cs_f64(double d, double gam, bool rot, bool tie_neg, double &c, double &s, double &dl)
 {
     const double g2 = 2.0 * gam;
-    const double h2 = d * d + g2 * g2 + 1e-290;
-    const double rh = cvx::rsqrt_(h2);
-    const double c2 = fma(0.5 * fabs(d), rh, 0.5);
-    const double rc = cvx::rsqrt_(c2);
-    double sf = gam * rh * rc;
+    const double g22 = g2 * g2;
+    const double h2 = fma(d, d, g22) + 1e-290;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double h = h2 * __builtin_amdgcn_rsq(h2);
+#else
+    const double h = sqrt(h2);
+#endif
+    const double u = h + fabs(d);
+    const double w = cvx::rsqrt_(fma(u, u, g22));
     const bool neg = d < 0.0 || (d == 0.0 && tie_neg);
-    sf = neg ? -sf : sf;
-    c = rot ? c2 * rc : 1.0;
+    const double sf = (neg ? -g2 : g2) * w;
+    c = rot ? u * w : 1.0;
     s = rot ? sf : 0.0;
-    t = s * rc;
+    dl = s * fma(s, d, -(c * g2));
 }
 
 // ---- the steps of a sweep (see kATab).  real: this lane holds a column (gl < 10) and has a partner.
@@ -375,22 +385,29 @@ __device__ __forceinline__ void jstep_bperm(f2 (&q)[5], float &alf, int addr, bo
     alf = take ? fmaf(t, gam, be) : fmaf(-t, gam, alf);
 }
 // the same two steps in float64 (22 v_mov_b32_dpp / 22 ds_bpermute)
+// (the ten products on two accumulators: a dependent float64 FMA takes 8 cycles, tools/microbench/lat_probe.hip -- one chain of ten sits on
+//  the critical path of every step between the exchange and the rotation parameters)
+__device__ __forceinline__ double dot10_f64(const double (&a)[10], const double (&b)[10])
+{
+    double s0 = a[0] * b[0], s1 = a[1] * b[1];
+#pragma unroll
+    for (int i = 2; i < 10; i += 2) { s0 = fma(a[i], b[i], s0); s1 = fma(a[i + 1], b[i + 1], s1); }
+    return s0 + s1;
+}
 __device__ __forceinline__ void jstep_dpp(double (&qd)[10], double &alq, bool real, bool tie_neg, bool active, double tol2, bool &coarse)
 {
     double oq[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) oq[i] = dpp_mov<0xB1>(qd[i]);
     const double be = dpp_mov<0xB1>(alq);
-    double gam = 0.0;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) gam = fma(qd[i], oq[i], gam);
+    const double gam = dot10_f64(qd, oq);
     const double g2 = gam * gam, ab = alq * be;
     coarse |= real && g2 > tol2 * ab;
     double c, sn, t;
     pair_cs_f64(be - alq, gam, active && real && g2 > 1e-30 * ab, tie_neg, c, sn, t);
 #pragma unroll
     for (int i = 0; i < 10; ++i) qd[i] = c * qd[i] - sn * oq[i];
-    alq = fma(-t, gam, alq);
+    alq += t; // (t: pair_cs_f64's dl)
 }
 __device__ __forceinline__ void jstep_bperm(double (&qd)[10], double &alq, int addr, bool real, bool tie_neg, bool take, bool active, double tol2, bool &coarse)
 {
@@ -398,9 +415,7 @@ __device__ __forceinline__ void jstep_bperm(double (&qd)[10], double &alq, int a
 #pragma unroll
     for (int i = 0; i < 10; ++i) oq[i] = bperm(addr, qd[i]);
     const double be = bperm(addr, alq);
-    double gam = 0.0;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) gam = fma(qd[i], oq[i], gam);
+    const double gam = dot10_f64(qd, oq);
     const double g2 = gam * gam, ab = alq * be;
     coarse |= real && g2 > tol2 * ab;
     double c, sn, t;
@@ -408,7 +423,7 @@ __device__ __forceinline__ void jstep_bperm(double (&qd)[10], double &alq, int a
     const double ka = take ? sn : c, kb = take ? c : -sn;
 #pragma unroll
     for (int i = 0; i < 10; ++i) qd[i] = fma(ka, qd[i], kb * oq[i]);
-    alq = take ? fma(t, gam, be) : fma(-t, gam, alq);
+    alq = take ? be - t : alq + t; // (t: pair_cs_f64's dl)
 }
 // one sweep: A X A X A X A X A
 template <class COL, class T>
@@ -816,21 +831,18 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
                     for (int kk = 0; kk < 5; ++kk) { const double2 r = row[kk]; a = fma(r.x, vd[2 * kk], a); a = fma(r.y, vd[2 * kk + 1], a); }
                     qd[i] = fma(sigma, vd[i], a);
                 }
-                double alq = 0.0;
-#pragma unroll
-                for (int i = 0; i < 10; ++i) alq = fma(qd[i], qd[i], alq);
+                double alq = dot10_f64(qd, qd);
 CVXQ_PH(0);
                 bool active = !done; // row-uniform
                 do {
                     bool coarse = false;
                     jacobi_sweep(qd, alq, atab, gl, lane_base4, active, tol2, coarse);
-                    alq = 0.0; // exact norms once per sweep (the incremental update drifts)
-#pragma unroll
-                    for (int i = 0; i < 10; ++i) alq = fma(qd[i], qd[i], alq);
+                    alq = dot10_f64(qd, qd); // exact norms once per sweep (the incremental update drifts)
                     const bool grp_more = grp_bits<LPP>(__ballot(coarse && active), grp) != 0;
                     if (active) ++sweeps;
                     active = active && grp_more && sweeps < sw_cap;
                 } while (__any(active));
+CVXQ_PH(1); /* jacobi (float64) */
 #pragma unroll
                 for (int i = 0; i < 10; ++i) g[i] = qd[i];
                 al = alq;

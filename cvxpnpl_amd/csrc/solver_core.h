@@ -456,20 +456,10 @@ CVX_HD void eig_norms(Eig &e)
 // The rotation is exactly orthogonal (c^2 + s^2 = 1 to rounding) for ANY t, so t may be
 // approximate; c is refined to full double precision.  Device build: v_rsq_f64 /
 // v_rcp_f64 seeds + Newton steps instead of the IEEE sqrt / divide expansions.
-CVX_HD void jacobi_cs(double al, double be, double gam, bool rot, double &c, double &s, double &t, bool exact = false)
+CVX_HD void jacobi_cs(double al, double be, double gam, bool rot, double &c, double &s, double &t)
 {
     const double d = be - al, g2 = 2.0 * gam;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (exact) { // (uniform) everything in float64: Opts::f32_sweeps_until == 0, the A/B mode of the single-precision sweeps
-        const double h2 = d * d + g2 * g2 + 1e-290;
-        const double h = h2 * rsqrt_(h2);
-        double tt = g2 * rcp(fabs(d) + h);
-        tt = d < 0 ? -tt : tt;
-        t = rot ? tt : 0.0;
-        c = rsqrt_(1.0 + t * t);
-        s = t * c;
-        return;
-    }
     // tan(theta) in single precision (one v_rsq_f32 + one v_rcp_f32): an angle that is right to
     // ~1e-7 still annihilates g_p . g_q to 1e-7 of its size per rotation, far below the
     // sweep tolerance.  cos(theta) then comes from a float seed refined by one double Newton
@@ -494,6 +484,36 @@ CVX_HD void jacobi_cs(double al, double be, double gam, bool rot, double &c, dou
     s = t * c;
 }
 
+// The same with the change of the squared norms under the rotation in place of tan(theta): |g_p'|^2 = al + dl, |g_q'|^2 = be - dl.
+// exact (uniform; device build only -- the host build is float64 anyway): everything in float64, Opts::f32_sweeps_until == 0, the
+// reference's precision.  One full-precision reciprocal root on the dependent chain (until round 5: v_rsq -> v_rcp -> v_rsq, each with its
+// Newton steps): with h ~ sqrt(d^2 + 4 gam^2) from the raw v_rsq_f64 seed (~2^-23) and u = h + |d|,
+//     c = u / sqrt(u^2 + 4 gam^2),   s = +-2 gam / sqrt(u^2 + 4 gam^2)
+// is a rotation to the precision of that one root whatever the error of h (c^2 + s^2 = 1 identically); the error of h moves the angle by
+// ~1e-7 of itself, i.e. leaves 1e-7 of the pair's inner product standing (sweep tolerance: 6e-2).  dl = s (s d - 2 c gam) holds for any angle.
+CVX_HD void jacobi_cs_dl(double al, double be, double gam, bool rot, double &c, double &s, double &dl, bool exact)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (exact) {
+        const double d = be - al, g2 = 2.0 * gam;
+        const double g22 = g2 * g2;
+        const double h2 = fma(d, d, g22) + 1e-290;
+        const double u = fma(h2, __builtin_amdgcn_rsq(h2), fabs(d));
+        const double w = rsqrt_(fma(u, u, g22));
+        const double sf = (d < 0 ? -g2 : g2) * w;
+        c = rot ? u * w : 1.0;
+        s = rot ? sf : 0.0;
+        dl = s * fma(s, d, -(c * g2));
+        return;
+    }
+#else
+    (void)exact;
+#endif
+    double t;
+    jacobi_cs(al, be, gam, rot, c, s, t);
+    dl = -(t * gam);
+}
+
 // Round-robin (circle method) pairing: 9 steps of 5 disjoint pairs cover all 45 pairs.  Positions
 // a0..a4 / b0..b4 start as columns 2k / 2k+1; after every step a0 stays and the others move one
 // place along the ring a1 > a2 > a3 > a4 > b4 > b3 > b2 > b1 > b0 > a1 -- the same schedule the
@@ -515,22 +535,28 @@ CVX_HD constexpr int rr_col(int step, int pos /* 0..4 = a_k, 5..9 = b_k */)
 // dependency chains, and in this order consecutive instructions belong to different chains, so the
 // in-order SIMD overlaps their latencies (a lane-per-problem wave has no other wave to hide behind).
 template <int ST>
-CVX_HD double eig_step5(Eig &e)
+CVX_HD double eig_step5(Eig &e, double tol2)
 {
     constexpr int P[5] = {rr_col(ST, 0), rr_col(ST, 1), rr_col(ST, 2), rr_col(ST, 3), rr_col(ST, 4)};
     constexpr int Q[5] = {rr_col(ST, 5), rr_col(ST, 6), rr_col(ST, 7), rr_col(ST, 8), rr_col(ST, 9)};
     double gam[5] = {0, 0, 0, 0, 0};
     CVX_UNROLL for (int i = 0; i < 10; ++i)
         CVX_UNROLL for (int k = 0; k < 5; ++k) gam[k] += e.G[P[k]][i] * e.G[Q[k]][i];
-    double c[5], s[5], t[5], worst = 0;
+    double c[5], s[5], worst = 0;
     CVX_UNROLL for (int k = 0; k < 5; ++k) {
         const double al = e.n2[P[k]], be = e.n2[Q[k]];
         const double g2 = gam[k] * gam[k], ab = al * be;
-        jacobi_cs(al, be, gam[k], g2 > 1e-30 * ab, c[k], s[k], t[k], e.exact);
+        double dl;
+        jacobi_cs_dl(al, be, gam[k], g2 > 1e-30 * ab, c[k], s[k], dl, e.exact);
+#if defined(__HIP_DEVICE_COMPILE__)
+        const double r = g2 > tol2 * ab ? 1.0 : 0.0; // (all the caller asks is whether a pair exceeds the tolerance: no IEEE division -- twelve instructions -- per pair)
+#else
         const double r = g2 / ab;
+        (void)tol2;
+#endif
         worst = r > worst ? r : worst;
-        e.n2[P[k]] = al - t[k] * gam[k];
-        e.n2[Q[k]] = be + t[k] * gam[k];
+        e.n2[P[k]] = al + dl;
+        e.n2[Q[k]] = be - dl;
     }
     CVX_UNROLL for (int i = 0; i < 10; ++i)
         CVX_UNROLL for (int k = 0; k < 5; ++k) {
@@ -549,15 +575,15 @@ CVX_HD int eig_solve(Eig &e, int max_sweeps, double tol2)
     for (; sweeps < max_sweeps;) {
         eig_norms(e);
         double worst = 0, r;
-        r = eig_step5<0>(e); worst = r > worst ? r : worst;
-        r = eig_step5<1>(e); worst = r > worst ? r : worst;
-        r = eig_step5<2>(e); worst = r > worst ? r : worst;
-        r = eig_step5<3>(e); worst = r > worst ? r : worst;
-        r = eig_step5<4>(e); worst = r > worst ? r : worst;
-        r = eig_step5<5>(e); worst = r > worst ? r : worst;
-        r = eig_step5<6>(e); worst = r > worst ? r : worst;
-        r = eig_step5<7>(e); worst = r > worst ? r : worst;
-        r = eig_step5<8>(e); worst = r > worst ? r : worst;
+        r = eig_step5<0>(e, tol2); worst = r > worst ? r : worst;
+        r = eig_step5<1>(e, tol2); worst = r > worst ? r : worst;
+        r = eig_step5<2>(e, tol2); worst = r > worst ? r : worst;
+        r = eig_step5<3>(e, tol2); worst = r > worst ? r : worst;
+        r = eig_step5<4>(e, tol2); worst = r > worst ? r : worst;
+        r = eig_step5<5>(e, tol2); worst = r > worst ? r : worst;
+        r = eig_step5<6>(e, tol2); worst = r > worst ? r : worst;
+        r = eig_step5<7>(e, tol2); worst = r > worst ? r : worst;
+        r = eig_step5<8>(e, tol2); worst = r > worst ? r : worst;
         ++sweeps;
         if (!(worst > tol2)) break;
     }

@@ -947,11 +947,11 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
                 for (int step = 0; step < 9; ++step) {
                     const double g2 = gam * gam, ab = al * be;
                     coarse |= g2 > tol2 * ab;
-                    double c, s, t;
-                    cvx::jacobi_cs(al, be, gam, g2 > 1e-30 * ab, c, s, t, o.f32_sweeps_until == 0);
+                    double c, s, dl;
+                    cvx::jacobi_cs_dl(al, be, gam, g2 > 1e-30 * ab, c, s, dl, o.f32_sweeps_until == 0);
                     L[CA + jl] = c * ca - s * cb;
                     L[CB + jl] = s * ca + c * cb;
-                    if (ji == 0) { L[NA + jk] = al - t * gam; L[NB + jk] = be + t * gam; }
+                    if (ji == 0) { L[NA + jk] = al + dl; L[NB + jk] = be - dl; }
                     CVXW_SYNC();
                     const double2 *ra = L2 + src_a / 2, *rb = L2 + src_b / 2;
                     const double2 a0 = ra[0], a1 = ra[1], a2 = ra[2], a3 = ra[3], a4 = ra[4];
