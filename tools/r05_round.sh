@@ -16,3 +16,7 @@ timeout 1200 python tools/accuracy_sweep.py --out-dir gpurun_out/r05/accuracy > 
 timeout 1500 bash tools/scalability_sweep.sh > gpurun_out/r05/scalability.jsonl 2>/dev/null; wc -l gpurun_out/r05/scalability.jsonl
 bash tools/kseq.sh --workload pnp_n4_50k --precision mixed > gpurun_out/r05/kseq_n4_50k.txt 2>&1
 bash tools/kseq.sh --workload ransac_n4_50k --precision mixed 2>&1 | head -8 > gpurun_out/r05/kseq_ransac.txt
+if [ -f tools/diag/libcvxpnpl_phases.so ]; then # shader cycles per phase of the quad kernel (-DCVXQ_PHASES build of the same sources), one wavefront alone and the judged launch, both precision modes
+  P=gpurun_out/r05/quad_phases.jsonl; : > $P
+  for m in "" f64; do for b in 4 10000; do CVXPNPL_AMD_LIB=$GRAFT_REPO_ROOT/tools/diag/libcvxpnpl_phases.so python tools/quad_phases.py $b $m >> $P 2>/dev/null; done; done
+fi
