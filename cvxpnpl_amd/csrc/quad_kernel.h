@@ -802,7 +802,24 @@ __global__ void __launch_bounds__(64, OCC) solve_quad_kernel(QuadArgs k)
         }
     }
 
+    int lane_h = lane;
+    unsigned atab_h = atab;
     while (__any(!done)) {
+#ifndef CVXQ_NO_ROLE_REFRESH
+        // Everything derived from the lane index (the row's LDS slice, the problem index and the output addresses that hang on it, the exchange
+        // partners) is re-derived HERE from a copy the compiler cannot see through: as loop invariants these values were hoisted in front of the
+        // loop, a few dozen registers of them, and spilled (cf. cvxw::solve_pass, CVXW_ROLES).  The names shadow the function scope's.
+        asm volatile("" : "+v"(lane_h), "+v"(atab_h));
+        const int grp = LPP == 16 ? lane_h >> 4 : (lane_h * 43) >> 9;
+        const int gl = lane_h - grp * LPP;
+        double *const L = lds_all + grp * SLICE;
+        double2 *const L2 = reinterpret_cast<double2 *>(L);
+        const int64_t b_raw = (int64_t)blockIdx.x * NPW + grp;
+        const int64_t b = (grp < NPW && b_raw < a.batch) ? b_raw : a.batch - 1;
+        const unsigned atab = atab_h;
+        const int lane_base4 = (grp * LPP) << 2;
+        w.gl = gl;
+#endif
         w.refresh();
         double al = 0.0, sigma = 0.0;
         if (!(it == 0 && o.first_check > 1)) {
