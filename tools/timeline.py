@@ -17,11 +17,12 @@ from cvxpnpl_amd import synth  # noqa: E402
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 layout = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 li = int(sys.argv[3]) if len(sys.argv) > 3 else -1  # hand-off iteration of the quad schedule (-1: default)
+kw = {"f32_sweeps_until": 0} if "f64" in sys.argv[4:] else {}  # (f64: every sweep in float64, bench.py's headline mode)
 dev = torch.device("cuda:0")
 d = synth.make_pnp(batch, 10, 2.0, seed=42)
 p2, p3, K = (torch.as_tensor(d[k], device=dev) for k in ("pts_2d", "pts_3d", "K"))
 for _ in range(3):
-    res = ca.pnp_batch(p2, p3, K, layout=layout, lane_iters=li)
+    res = ca.pnp_batch(p2, p3, K, layout=layout, lane_iters=li, **kw)
 torch.cuda.synchronize()
 pit = res.iters.cpu().numpy()
 c = res.cost.cpu().numpy().reshape(-1)
