@@ -296,7 +296,7 @@ __device__ __forceinline__ void pair_cs_f64(double d, double gam, bool rot, bool
 {
     const double g2 = 2.0 * gam;
     const double g22 = g2 * g2;
-    const double h2 = fma(d, d, g22) + 1e-290;
+    const double h2 = fma(d, d, g22); // (zero only where rot is false: the NaN it breeds is selected away below)
 #if defined(__HIP_DEVICE_COMPILE__)
     const double h = h2 * __builtin_amdgcn_rsq(h2);
 #else
