@@ -14,6 +14,7 @@
 #include "problem_io.h"
 #include "solver_core.h"
 #include "lane_core.h"
+#include "batch_args.h"
 #include "wave_kernel.h"
 #include "quad_kernel.h"
 #include "ipm_quad.h"
@@ -24,14 +25,7 @@
 
 namespace {
 
-struct BatchArgs {
-    int64_t batch;
-    int n_p, n_l, K_per_problem;
-    const double *p2, *p3, *l2, *l3, *K;
-    double *R, *t, *cost, *Z;
-    int32_t *status, *iters, *work;
-    const double *Q45, *B27; // cost entry (cvxpnpl_solve_cost_batch)
-};
+using cvxb::BatchArgs; // (batch_args.h: shared with lane_kernel.hip)
 
 #ifdef CVXPNPL_EXPERIMENTS // the general scalar core on lanes: experiment builds only (layout 10) since round 5 -- see the lane branch of launch_solve
 // ---------------------------------------------------------------------------------------
@@ -75,41 +69,7 @@ __global__ void __launch_bounds__(64) solve_lane_kernel(BatchArgs a, cvx::Opts o
 
 #endif // CVXPNPL_EXPERIMENTS
 
-// Lane-per-problem, the first phase of the lane-hybrid schedule: each lane owns one problem (assembly -> ADMM -> one certificate attempt ->
-// pose) for the first handoff_at (2..6) iterations; 64 independent problems per wavefront, no cross-lane traffic.  A lane that is not
-// finished by then parks its iterate in ws[b] and queues b for resume_wave_kernel, so that one slow problem cannot hold the other 63 lanes.
-// The register-budgeted restatement of the scalar core (lane_core.h): the schedule the launch policy
-// actually uses -- handoff_at iterations, one certificate attempt after the last, single-precision sweeps -- written straight
-// line with streamed projections.  512 registers (256 + 256), ~20 spilled, 60 B of scratch per lane; the general core above needs
-// 2 640 B per lane (1 006 spilled registers, 1.1 GB of HBM traffic per 125 k launch) and stays for every other combination of
-// options (float64 sweeps, hand-off point != first attempt).
-// F64SW: every sweep, the product that starts them and the rotation angles in float64 (opts.f32_sweeps_until below the length of the
-// phase) -- cvxl::lane_phase_f64, the positive part streamed row by row instead of stored.
-template <bool F64SW>
-__global__ void __launch_bounds__(64) solve_lane2_kernel(BatchArgs a, cvx::Opts o, int handoff_at, int32_t *qcount, int32_t *qentries, double *ws)
-{
-    __shared__ double lds_const[72 * 64];
-    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.batch) return;
-    cvx::ProblemView pv = cvx::make_view(b, a.n_p, a.p2, a.p3, a.n_l, a.l2, a.l3, a.K, a.K_per_problem);
-    if (a.Q45) { pv.Q45 = a.Q45 + b * 45; pv.B27 = a.B27 + b * 27; }
-    cvx::Solution sol;
-    if (F64SW) cvxl::lane_phase_f64(pv, o, sol, a.Z ? a.Z + b * 55 : nullptr, handoff_at, ws + b * 56, cvx::LdsStore{lds_const + threadIdx.x});
-    else cvxl::lane_phase(pv, o, sol, a.Z ? a.Z + b * 55 : nullptr, handoff_at, ws + b * 56, cvx::LdsStore{lds_const + threadIdx.x});
-    if (sol.status == -1) {
-        const int q = atomicAdd(qcount, 1);
-        qentries[q] = (int32_t)b;
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 9; ++i) a.R[b * 9 + i] = sol.R[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) a.t[b * 3 + i] = sol.t[i];
-    a.status[b] = sol.status;
-    if (a.iters) a.iters[b] = sol.iters;
-    if (a.cost) { a.cost[2 * b] = sol.cost; a.cost[2 * b + 1] = sol.dobj; }
-    if (a.work) { a.work[2 * b] = sol.rank; a.work[2 * b + 1] = sol.sweeps; }
-}
+// (solve_lane2_kernel, the first phase of the lane-hybrid schedule: lane_kernel.hip, a translation unit of its own -- cvxb::launch_lane2)
 
 // results of one shard as the 13-doubles-per-pose records the multi-GPU gather exchanges: R (9, row-major), t (3), status
 __global__ void __launch_bounds__(256) pack_kernel(int64_t batch, const double *R, const double *t, const int32_t *status, double *out)
@@ -582,8 +542,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
             int32_t *count = wv.count, *entries = wv.entries;
             double *ws = wv.parked;
             const bool budgeted = lane_budgeted;
-            if (budgeted && o.f32_sweeps_until >= lane_iters) hipLaunchKernelGGL(solve_lane2_kernel<false>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws);
-            else if (budgeted) hipLaunchKernelGGL(solve_lane2_kernel<true>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws); // float64 sweeps
+            if (budgeted) cvxb::launch_lane2(!(o.f32_sweeps_until >= lane_iters), (unsigned)grid, (unsigned)block, (void *)s, a, o, lane_iters, count, entries, ws); // (true: float64 sweeps)
 #ifdef CVXPNPL_EXPERIMENTS
             else if (o.f32_sweeps_until < lane_iters) hipLaunchKernelGGL(solve_lane_kernel<true>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws); // float64 sweeps (A/B mode)
             else hipLaunchKernelGGL(solve_lane_kernel<false>, dim3((unsigned)grid), dim3(block), 0, s, a, o, lane_iters, count, entries, ws);

@@ -167,9 +167,17 @@ CVX_HD double rcp(double x)
 #if defined(__HIP_DEVICE_COMPILE__)
     // hardware seed (2^-24.4, tools/microbench/rsq_probe.hip) and ONE third-order step r (1 + e + e^2), e = 1 - x r: three operations where two Newton
     // steps take four (round 5; float64 operations issue at half rate on this part, every one of them counts)
+#if defined(CVX_REFINE_NEWTON2) // (lane_kernel.hip: the sequences that unit was tuned with)
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+#else
     const double r = __builtin_amdgcn_rcp(x);
     const double e = fma(-x, r, 1.0);
     return fma(r, fma(e, e, e), r);
+#endif
 #else
     return 1.0 / x;
 #endif
@@ -181,9 +189,16 @@ CVX_HD double rsqrt_(double x)
     // Newton steps take seven / six; maximum relative error over 4 M arguments 1.38e-16 either way (tools/microbench/rsq_probe.hip,
     // profiles/r05/rsq_probe.txt).  Round 5, same-box A/B (profiles/r05/rsq_c3_ab.txt): judged launch +1.8 % / +1 %, wave layout +3 %, the lane-layout
     // launches -0.2 ... -2 % (their instruction count does not change: register allocation) -- taken for the former.
+#if defined(CVX_REFINE_NEWTON2)
+    double y = __builtin_amdgcn_rsq(x);
+    { double h = 0.5 * x * y; double e = fma(-h, y, 0.5); y = fma(y, e, y); }
+    { double h = 0.5 * x * y; double e = fma(-h, y, 0.5); y = fma(y, e, y); }
+    return y;
+#else
     const double y = __builtin_amdgcn_rsq(x);
     const double r = fma(-(x * y), y, 1.0);
     return fma(y * r, fma(0.375, r, 0.5), y);
+#endif
 #else
     return 1.0 / sqrt(x);
 #endif
@@ -500,7 +515,11 @@ CVX_HD void jacobi_cs_dl(double al, double be, double gam, bool rot, double &c, 
     if (exact) {
         const double d = be - al, g2 = 2.0 * gam;
         const double g22 = g2 * g2;
+#if defined(CVX_REFINE_NEWTON2)
+        const double h2 = fma(d, d, g22) + 1e-290;
+#else
         const double h2 = fma(d, d, g22); // (zero only where rot is false: the NaN it breeds is selected away below)
+#endif
         const double u = fma(h2, __builtin_amdgcn_rsq(h2), fabs(d));
         const double w = rsqrt_(fma(u, u, g22));
         const double sf = (d < 0 ? -g2 : g2) * w;
