@@ -6,4 +6,4 @@
 cd "$(dirname "$0")/../.."
 mkdir -p tools/diag
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value -mllvm -enable-ipra=0 -DCVXPNPL_EXPERIMENTS "$@" \
-      -o tools/diag/libcvxpnpl_exp.so cvxpnpl_amd/csrc/cvxpnpl_hip.hip cvxpnpl_amd/csrc/host_recover.cpp
+      -o tools/diag/libcvxpnpl_exp.so cvxpnpl_amd/csrc/cvxpnpl_hip.hip cvxpnpl_amd/csrc/lane_kernel.hip cvxpnpl_amd/csrc/host_recover.cpp

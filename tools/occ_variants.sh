@@ -7,7 +7,7 @@ if [ "$1" = build ]; then
   mkdir -p $root/tools/diag
   for v in $variants; do
     name=${v%%:*}; flags=$(echo ${v#*:} | tr ',' ' ')
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value -mllvm -enable-ipra=0 $flags -o $root/tools/diag/libcvxpnpl_$name.so $root/cvxpnpl_amd/csrc/cvxpnpl_hip.hip $root/cvxpnpl_amd/csrc/host_recover.cpp &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value -mllvm -enable-ipra=0 $flags -o $root/tools/diag/libcvxpnpl_$name.so $root/cvxpnpl_amd/csrc/cvxpnpl_hip.hip $root/cvxpnpl_amd/csrc/lane_kernel.hip $root/cvxpnpl_amd/csrc/host_recover.cpp &
   done
   wait; ls -la $root/tools/diag
 else

@@ -25,7 +25,7 @@ COUNTS = {20: "newton_iters", 21: "polish_calls", 22: "dual_calls"}
 def build():
     src = os.path.join(ROOT, "cvxpnpl_amd", "csrc")
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           "-DCVXW_PROFILE", "-o", PROF, os.path.join(src, "cvxpnpl_hip.hip"), os.path.join(src, "host_recover.cpp")]
+           "-DCVXW_PROFILE", "-o", PROF, os.path.join(src, "cvxpnpl_hip.hip"), os.path.join(src, "lane_kernel.hip"), os.path.join(src, "host_recover.cpp")]
     subprocess.check_call(cmd)
     print(PROF)
 
