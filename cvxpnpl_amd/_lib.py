@@ -36,7 +36,7 @@ class Opts(C.Structure):
         ("jacobi_sweeps", C.c_int32), ("jacobi_tol", C.c_double), ("warm_start", C.c_int32), ("rho_tail", C.c_double), ("tail_from", C.c_int32), ("lane_iters", C.c_int32), ("layout", C.c_int32),
         ("variant", C.c_int32), ("adapt_every", C.c_int32), ("adapt_from", C.c_int32), ("adapt_mu", C.c_double), ("adapt_tau", C.c_double),
         ("stall_from", C.c_int32), ("stall_lam", C.c_double), ("stall_res", C.c_double), ("stall_drop", C.c_double), ("rescue_from", C.c_int32),
-        ("f32_sweeps_until", C.c_int32), ("sweep_schedule", C.c_int32), ("dual_shift", C.c_double),
+        ("f32_sweeps_until", C.c_int32), ("sweep_schedule", C.c_int32), ("dual_shift", C.c_double), ("dual_refine", C.c_int32),
     ]
 
 

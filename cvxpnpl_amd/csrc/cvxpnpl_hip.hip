@@ -273,6 +273,7 @@ cvx::Opts to_core(const cvxpnpl_opts_t *opts)
         o.f32_sweeps_until = opts->f32_sweeps_until;
         o.sweep_schedule = opts->sweep_schedule != 0;
         o.dual_shift = opts->dual_shift < 0.0 ? (opts->variant == CVXPNPL_VARIANT_RC ? 0.006 : cvx::DUAL_SHIFT_DEFAULT) : opts->dual_shift; // (rc, 50 k problems: 17.3 M poses/s without, 17.3 / 18.4 / 18.3 M with 0.015 / 0.006 / 0.001)
+        o.dual_refine = opts->dual_refine != 0;
     }
     if (o.f32_sweeps_until < 0) o.f32_sweeps_until = cvx::F32_SWEEPS_DEFAULT;
     return o;
@@ -309,6 +310,7 @@ void cvxpnpl_default_opts(cvxpnpl_opts_t *opts)
     opts->f32_sweeps_until = -1;
     opts->sweep_schedule = 1;
     opts->dual_shift = -1.0; /* by variant */
+    opts->dual_refine = -1;
     opts->struct_size = (uint32_t)sizeof(cvxpnpl_opts_t);
 }
 
@@ -337,7 +339,7 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     }
     if (opts && (opts->max_iters < 1 || opts->f32_sweeps_until < -1 || opts->f32_sweeps_until > cvx::F32_SWEEPS_DEFAULT || !(opts->rho > 0) || !(opts->eps > 0) || opts->check_every < 1 || opts->first_check < 0 ||
                  (opts->variant != CVXPNPL_VARIANT_FULL && opts->variant != CVXPNPL_VARIANT_RC) || opts->adapt_every < 0 ||
-                 (opts->adapt_every > 0 && !(opts->adapt_mu >= 1.0 && opts->adapt_tau > 1.0)) || opts->rescue_from < -1 || !((opts->dual_shift >= 0.0 && opts->dual_shift <= 1.0) || opts->dual_shift == -1.0))) {
+                 (opts->adapt_every > 0 && !(opts->adapt_mu >= 1.0 && opts->adapt_tau > 1.0)) || opts->rescue_from < -1 || !((opts->dual_shift >= 0.0 && opts->dual_shift <= 1.0) || opts->dual_shift == -1.0) || opts->dual_refine < -1 || opts->dual_refine > 1)) {
         snprintf(g_err, sizeof(g_err), "cvxpnpl: bad options");
         return -1;
     }

@@ -80,10 +80,18 @@ struct Opts {
     int sweep_schedule;   // kernels: 1 (default) caps the sweeps of the YOUNG eigen-solves by iteration (sweep_cap below); 0: jacobi_sweeps only
     double dual_shift;    // a certificate attempt whose recovered dual S fails the PSD test is repeated once with S + dual_shift D(R) (dual_retry_entry
                           // below); 0: no second try
+    int dual_refine;      // 1 (default): a dual that still fails gets one eigen-gradient step inside the family of complementary duals
+                          // (dual_refine_step below); 0: never
 };
 constexpr int F32_SWEEPS_DEFAULT = 64;
 constexpr double DUAL_SHIFT_DEFAULT = 0.015;
 constexpr int DUAL_RETRY_RUNGS = 2; // second tries of a failed dual: dual_shift, dual_shift / 4
+constexpr double DUAL_REFINE_SIGMA = 0.005; // dual_refine_step: shift of the inverse iteration (the failed duals of the judged problem set have lambda_min ~ -3e-4,
+                                            // the next eigenvalue ~ 3e-2: two iterations with this shift resolve the bottom eigenvector to ~1e-3)
+constexpr int DUAL_REFINE_INVITS = 2;
+constexpr double DUAL_REFINE_GAIN = 2.0;    // the step raises the bottom Rayleigh quotient by this multiple of its distance from zero (first order)
+constexpr int DUAL_REFINE_ATTEMPTS = 3;     // ... at the first this many attempts of a phase: a dual it has not repaired by then is far from the cone (the long chains of a launch: their
+                                            // problems would pay for it at every attempt)
 constexpr int DUAL_RETRY_ATTEMPTS = 10; // ... in the first this many attempts that may use them: a problem they have not rescued by then is not
                                         // one they rescue (same iteration counts with 6 / 10 / 16 / no limit on four workloads), and its long
                                         // chain stops paying for them (N = 8, 125 k problems, slowest 99 iterations: 160.4 -> 162.6 M poses/s)
@@ -119,6 +127,7 @@ CVX_HD Opts default_opts()
     o.f32_sweeps_until = -1;
     o.sweep_schedule = 1;
     o.dual_shift = DUAL_SHIFT_DEFAULT;
+    o.dual_refine = 1;
     return o;
 }
 
@@ -1181,12 +1190,86 @@ CVX_HD double dual_retry_entry6(const double *R, int a, int b)
     const int i = a % 3, j = a / 3, k = b % 3, l = b / 3;
     return (a == b ? 1.0 : 0.0) + R[k * 3 + j] * R[i * 3 + l] - R[i * 3 + j] * R[k * 3 + l];
 }
+// Third try of a certificate attempt: ONE eigen-gradient step inside the dual family (round 6).
+// The certifying duals of the pose z are the PSD members of S1 + U (above).  A failed S1 of an N >= 6 problem typically has ONE eigenvalue
+// just below zero (median -3e-4 on the judged set; its eigenvector n is close to the runner-up eigenvector of Z: these are the problems whose
+// Z is still a mixture) while the others sit at 3e-2 and more.  d/dv lambda_min(S1 + U(v)) = n^T U_k n, so the steepest ascent direction of
+// the bottom eigenvalue inside the family is G = P_U(n n^T); moving by tau = gain |lambda_1| / <G, n n^T> raises n^T S n to (gain - 1) |lambda_1|
+// to first order at a cost of O(tau |G|) ~ 1e-3 to the other eigenvalues.  n: two inverse iterations with LDL^T(S1 + sigma I) from the
+// runner-up eigenvector of Z (projected off z); P_U: the two closed forms of dual_certificate (projection onto span A_i, then the
+// minimum-norm correction onto { X z = 0 }).  Cost: two LDL^T, two triangular solves, one P_U.  Host experiments on the judged problem set
+// (tools/experiments/dual_refine/, 655 failed attempts of 10 000 problems): the shift tries rescue 48 %, this step 87 % (with the exact n:
+// 90 %; a log-det barrier Newton step on (v, t): 93 %, two: 96 % = every attempt whose pose is already the final one); problems needing >= 9
+// iterations 66 -> 15, >= 7 (with the step at the first attempt too) 576 -> 115.  The certificate that is reported is the usual float64
+// statement about the S that passed (S z = 0 and z^T S z are re-measured on it).
+// S: the failed dual + delta I (packed 55); on success it holds the refined dual + delta I.  Returns the smallest pivot of its LDL^T
+// (<= 0: no luck), res / zSz re-measured.
+CVX_HD void ldl_solve10(const double *T, double *x) // (L D L^T) x = b with the factor ldl_min_pivot leaves (pivot rows unnormalised)
+{
+    double id[10];
+    CVX_UNROLL for (int i = 0; i < 10; ++i) id[i] = rcp(T[sidx(i, i)]);
+    CVX_UNROLL for (int i = 1; i < 10; ++i) {
+        double a = x[i];
+        CVX_UNROLL for (int k = 0; k < i; ++k) a -= T[sidx(k, i)] * id[k] * x[k];
+        x[i] = a;
+    }
+    CVX_UNROLL for (int i = 0; i < 10; ++i) x[i] *= id[i];
+    CVX_UNROLL for (int i = 8; i >= 0; --i) {
+        double a = x[i];
+        CVX_UNROLL for (int j = i + 1; j < 10; ++j) a -= T[sidx(i, j)] * id[i] * x[j];
+        x[i] = a;
+    }
+}
+template <int VAR = VAR_FULL>
+CVX_HD double dual_refine_step(double *S, const double *z, const double *R, const double *v2, double delta, double &res, double &zSz)
+{
+    double x[10], T[55];
+    CVX_UNROLL for (int i = 0; i < 55; ++i) T[i] = S[i];
+    CVX_UNROLL for (int i = 0; i < 10; ++i) T[sidx(i, i)] += DUAL_REFINE_SIGMA;
+    if (!(ldl_min_pivot(T) > 0)) return -1.0;
+    CVX_UNROLL for (int i = 0; i < 10; ++i) x[i] = v2[i];
+    for (int itn = 0; itn <= DUAL_REFINE_INVITS; ++itn) { // (pass 0 only projects the start vector off z and normalises it)
+        if (itn > 0) ldl_solve10(T, x);
+        double zx = 0;
+        CVX_UNROLL for (int i = 0; i < 10; ++i) zx += z[i] * x[i];
+        double n2 = 0;
+        CVX_UNROLL for (int i = 0; i < 10; ++i) { x[i] -= 0.25 * zx * z[i]; n2 += x[i] * x[i]; }
+        const double in = rsqrt_(n2 > 1e-300 ? n2 : 1e-300);
+        CVX_UNROLL for (int i = 0; i < 10; ++i) x[i] *= in;
+    }
+    double Sx[10];
+    sym_mul10(S, x, Sx);
+    double ray = -delta;
+    CVX_UNROLL for (int i = 0; i < 10; ++i) ray += x[i] * Sx[i];
+    if (!(ray < 0)) return -1.0;
+    // G = P_U(x x^T)
+    double G[55], N[55];
+    CVX_UNROLL for (int i = 0; i < 10; ++i) CVX_UNROLL for (int j = i; j < 10; ++j) { G[sidx(i, j)] = x[i] * x[j]; N[sidx(i, j)] = G[sidx(i, j)]; }
+    proj_affine<VAR>(N, true);
+    CVX_UNROLL for (int i = 0; i < 55; ++i) G[i] -= N[i];
+    double rhs[10], lam[10];
+    sym_mul10(G, z, rhs);
+    dual_lambda<VAR>(R, rhs, false, lam);
+    sub_range_of_rank2<VAR>(G, lam, z, false);
+    double Gx[10];
+    sym_mul10(G, x, Gx);
+    double g2 = 0;
+    CVX_UNROLL for (int i = 0; i < 10; ++i) g2 += x[i] * Gx[i];
+    if (!(g2 > 1e-6)) return -1.0;
+    const double tau = DUAL_REFINE_GAIN * (-ray) * rcp(g2);
+    CVX_UNROLL for (int i = 0; i < 55; ++i) { S[i] += tau * G[i]; T[i] = S[i]; }
+    double Sz[10];
+    sym_mul10(S, z, Sz);
+    res = 0; zSz = 0;
+    CVX_UNROLL for (int i = 0; i < 10; ++i) { const double v = Sz[i] - delta * z[i]; res = fabs(v) > res ? fabs(v) : res; zSz += z[i] * v; }
+    return ldl_min_pivot(T);
+}
 // Dual half: given the polished rotation c.R (and c.pobj), recover a dual and test it.
 // SYMM: recognise planar scenes (Qs blind to the third column of R), whose relaxation is invariant
 // under D = diag(-I6, I4), and build the correction in the D-even subspace so that it annihilates
 // both twins z and D z at once.
 template <bool SYMM = true, class QV = const double *, int VAR = VAR_FULL>
-CVX_HD void dual_certificate(QV Qs, const double *W, const double *Wp, double rho, double delta, double d0, Cert &c, double shift = 0.0)
+CVX_HD void dual_certificate(QV Qs, const double *W, const double *Wp, double rho, double delta, double d0, Cert &c, double shift = 0.0, const double *v2 = nullptr)
 {
     c.ok = false;
     double z[10];
@@ -1214,10 +1297,10 @@ CVX_HD void dual_certificate(QV Qs, const double *W, const double *Wp, double rh
     CVX_UNROLL for (int i = 0; i < 10; ++i) { c.res = fabs(Sz[i]) > c.res ? fabs(Sz[i]) : c.res; c.zSz += z[i] * Sz[i]; }
     CVX_UNROLL for (int i = 0; i < 10; ++i) S[sidx(i, i)] += delta;
     const bool pre = (c.res < 1e-10) && (d0 > 0) && (c.pobj == c.pobj);
-    if (shift > 0.0 && pre && !symm) {
+    if ((shift > 0.0 || v2) && pre && !symm) {
         CVX_UNROLL for (int i = 0; i < 55; ++i) T[i] = S[i];
         c.min_piv = ldl_min_pivot(T);
-        if (!(c.min_piv > 0)) { // second try: S + shift D(R)
+        if (!(c.min_piv > 0) && shift > 0.0) { // second try: S + shift D(R)
             double s6 = shift * (1.0 / 6.0);
             for (int rung = 0; rung < DUAL_RETRY_RUNGS && !(c.min_piv > 0); ++rung) { // shift, shift / 4
                 CVX_UNROLL for (int i = 0; i < 10; ++i)
@@ -1225,6 +1308,11 @@ CVX_HD void dual_certificate(QV Qs, const double *W, const double *Wp, double rh
                 c.min_piv = ldl_min_pivot(T);
                 s6 *= 0.25;
             }
+        }
+        if (!(c.min_piv > 0) && v2) { // third try: one eigen-gradient step inside the dual family
+            double res2, zSz2;
+            const double mp = dual_refine_step<VAR>(S, z, c.R, v2, delta, res2, zSz2);
+            if (mp > 0 && res2 < 1e-10) { c.min_piv = mp; c.res = res2; c.zSz = zSz2; }
         }
     } else {
         c.min_piv = ldl_min_pivot(S);
@@ -1551,6 +1639,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
             // a failed dual gets its second tries (dual_certificate) from the second attempt of a solve on: the first attempt of every
             // problem would pay for them, the later ones are the slow problems that end a launch (the lane phase makes one attempt)
             const double retry_shift = (TWIN && attempts > 0 && attempts <= DUAL_RETRY_ATTEMPTS) ? o.dual_shift : 0.0;
+            const bool refine = TWIN && o.dual_refine && attempts < DUAL_REFINE_ATTEMPTS; // (the eigen-gradient step: at the first attempt too)
             ++attempts;
             // top eigenvector of Wp (and the runner-up, see below)
             int jm = 0, j2 = 0;
@@ -1607,7 +1696,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                     polish_rotation(Qs, c.R, c.pobj);
                     if (TWIN) reused = 0;
                 }
-                dual_certificate<TWIN, decltype(Qs), VAR>(Qs, W, Wp, rho, delta, d0, c, retry_shift);
+                dual_certificate<TWIN, decltype(Qs), VAR>(Qs, W, Wp, rho, delta, d0, c, retry_shift, refine ? v2 : nullptr);
                 have_prev = d0 > 0 && (c.pobj == c.pobj);
                 CVX_UNROLL for (int i = 0; i < 9; ++i) Rprev[i] = c.R[i];
                 fprev = c.pobj;
@@ -1633,7 +1722,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                 // the dual test (it is then a global optimum, and so is z- with the same cost).
                 if (ambiguous) {
                     c.pobj = fp;
-                    dual_certificate<TWIN, decltype(Qs), VAR>(Qs, W, Wp, rho, delta, dp, c, retry_shift);
+                    dual_certificate<TWIN, decltype(Qs), VAR>(Qs, W, Wp, rho, delta, dp, c, retry_shift, refine ? v2 : nullptr);
                     ambiguous = c.ok && (tr * (fabs(c.zSz) + 4.0 * delta) <= (o.eps > 8e-13 * tr ? o.eps : 8e-13 * tr));
                     twin_tested = true;
                 }
@@ -1641,7 +1730,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                     const bool take_m = dm > 0 && (fm == fm) && (!(dp > 0) || !(fp == fp) || fm < fp);
                     if (take_m) { CVX_UNROLL for (int i = 0; i < 9; ++i) c.R[i] = Rm[i]; }
                     c.pobj = take_m ? fm : fp;
-                    dual_certificate<TWIN, decltype(Qs), VAR>(Qs, W, Wp, rho, delta, take_m ? dm : dp, c, retry_shift);
+                    dual_certificate<TWIN, decltype(Qs), VAR>(Qs, W, Wp, rho, delta, take_m ? dm : dp, c, retry_shift, refine ? v2 : nullptr);
                 } else if (!ambiguous) {
                     c.ok = false; // equal-cost twins whose certificate is not there yet: keep iterating
                 }

@@ -23,6 +23,9 @@
 #include "problem_io.h"
 #include "solver_core.h"
 
+#ifndef CVX_DUAL_REFINE_COMPILED
+#define CVX_DUAL_REFINE_COMPILED 1 // (diagnostic builds: 0 compiles the eigen-gradient step of the dual out of the kernels)
+#endif
 namespace cvxw {
 
 constexpr int WPB = 1; // waves (= problems) per block: 1, so a finished problem frees its SIMD slot at once
@@ -272,6 +275,27 @@ __device__ __forceinline__ double coop_ldl(double *L, const Roles &r, double &Me
     return minp;
 }
 
+
+// Symmetric sweep operator over all ten pivots on the matrix held one entry (a <= b) per lane: Me <- -(Me)^-1, at the price of one
+// coop_ldl (one lane read and two ds_bpermute per pivot).  Returns the smallest pivot met (they are the pivots of the LDL^T) and stops at
+// the first non-positive one (wave-uniform).  For cvx::dual_refine_step: with the inverse in hand an inverse iteration is a mat-vec.
+__device__ __forceinline__ double coop_sweep_inverse(const Roles &r, double &Me)
+{
+    double minp = 1e300;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const double d = wave_lane(Me, cvx::sidx(k, k));
+        minp = d < minp ? d : minp;
+        if (!(d > 0)) break;
+        const double id = fast_rcp(d);
+        const int ia = r.ei < k ? cvx::sidx(r.ei, k) : cvx::sidx(k, r.ei), ib = r.ej < k ? cvx::sidx(r.ej, k) : cvx::sidx(k, r.ej);
+        const double ra = __shfl(Me, ia), rb = __shfl(Me, ib); // A[ei][k], A[k][ej]
+        const bool pi = r.ei == k, pj = r.ej == k;
+        Me = (pi && pj) ? -id : (pi ? rb * id : (pj ? ra * id : Me - ra * id * rb));
+    }
+    return minp;
+}
+
 // Cooperative certificate = the steps of cvx::solve_sdp's check (solver_core.h), identical mathematics, all
 // 64 lanes: coop_round / coop_polish (primal half: cvx::round_candidate, cvx::polish_rotation) and coop_dual
 // (cvx::dual_certificate).  Inputs are the entry-lane values Qs, W, Wp; R is replicated in every lane.
@@ -408,7 +432,7 @@ __device__ __forceinline__ void coop_polish(double *L, const Roles &r, double Qs
 // Dual half (cvx::dual_certificate, all lanes) for the rotation R: returns the verdict c.ok.
 template <int VAR = cvx::VAR_FULL>
 __device__ __forceinline__ bool coop_dual(double *L, const Roles &r, double Qs, double W, double Wp, const double *R, double d0,
-                                          double pobj, double rho, double delta, double &zSz, const double shift CVXW_PH_PARAM)
+                                          double pobj, double rho, double delta, double &zSz, const double shift, const bool refine CVXW_PH_PARAM)
 {
     // planar scene (Qs blind to the third column of R): the problem is invariant under
     // D = diag(-I6, I4) and the correction is built in the D-even subspace (cvx::dual_certificate)
@@ -489,6 +513,87 @@ __device__ __forceinline__ bool coop_dual(double *L, const Roles &r, double Qs, 
             Se = S + (r.is_diag ? delta : 0.0) + sh * d6;
             minp = coop_ldl(L, r, Se);
             sh *= 0.25;
+        }
+    }
+    if (CVX_DUAL_REFINE_COMPILED && refine && pre && !symm && !(minp > 0)) { // (wave-uniform) third try: cvx::dual_refine_step, all lanes
+        // X = (S + (delta + sigma) I)^-1 by the sweep operator, two inverse iterations from the runner-up eigenvector of Z (L_V + 10..19)
+        constexpr int R_X = L_Y;            // 100  full X (the eigen columns of this iteration are dead: Wp is in registers)
+        constexpr int R_V = L_Y + 100;      // 2 x 10  iteration vector, ping-pong
+        double Xe = S + (r.is_diag ? delta + cvx::DUAL_REFINE_SIGMA : 0.0);
+        const double mps = coop_sweep_inverse(r, Xe);
+        if (mps > 0) {
+            if (lane < 55) { L[R_X + r.ei * 10 + r.ej] = -Xe; L[R_X + r.ej * 10 + r.ei] = -Xe; }
+            if (lane < 10) L[R_V + lane] = L[L_V + 10 + lane];
+            CVXW_SYNC();
+            double x[10];
+#pragma unroll
+            for (int itn = 0; itn <= cvx::DUAL_REFINE_INVITS; ++itn) {
+                const int cur = R_V + 10 * (itn & 1), nxt = R_V + 10 * ((itn + 1) & 1);
+                double zx = 0.0, n2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < 10; ++i) { x[i] = L[cur + i]; zx += L[C_XV + i] * x[i]; }
+#pragma unroll
+                for (int i = 0; i < 10; ++i) { x[i] -= 0.25 * zx * L[C_XV + i]; n2 += x[i] * x[i]; }
+                const double in = cvx::rsqrt_(n2 > 1e-300 ? n2 : 1e-300);
+#pragma unroll
+                for (int i = 0; i < 10; ++i) x[i] *= in;
+                if (itn < cvx::DUAL_REFINE_INVITS) {
+                    CVXW_SYNC();
+                    double xs = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) xs = lane == i ? x[i] : xs;
+                    if (lane < 10) L[cur + lane] = xs;
+                    CVXW_SYNC();
+                    if (lane < 10) L[nxt + lane] = dot10(L2 + (R_X + lane * 10) / 2, L2 + cur / 2);
+                    CVXW_SYNC();
+                }
+            }
+            double xi = 0.0, xj = 0.0;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) { xi = r.ei == i ? x[i] : xi; xj = r.ej == i ? x[i] : xj; }
+            const double wg = lane < 55 ? (r.is_diag ? 1.0 : 2.0) : 0.0;
+            const double E0 = xi * xj;
+            const double ray = wave_sum(wg * S * E0);
+            if (ray < 0) {
+                // G = P_U(x x^T): onto span A_i, then the minimum-norm correction onto { X z = 0 } (the two closed forms above)
+                double G = E0 - coop_proj<VAR>(L, r, E0, 0.0);
+                if (lane < 55) { L[C_SF + r.ei * 10 + r.ej] = G; L[C_SF + r.ej * 10 + r.ei] = G; }
+                CVXW_SYNC();
+                if (lane < 10) L[C_ROW + lane] = dot10(L2 + (C_SF + lane * 10) / 2, L2 + C_XV / 2);
+                CVXW_SYNC();
+                {
+                    double rhs[10], lam[10];
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) rhs[i] = L[C_ROW + i];
+                    cvx::dual_lambda<VAR>(R, rhs, false, lam);
+                    CVXW_SYNC();
+                    if (lane == 0) {
+#pragma unroll
+                        for (int i = 0; i < 10; ++i) L[C_LAM + i] = lam[i];
+                    }
+                }
+                CVXW_SYNC();
+                {
+                    const double E = 0.5 * (L[C_LAM + r.ei] * L[C_XV + r.ej] + L[C_XV + r.ei] * L[C_LAM + r.ej]);
+                    const double Nn = coop_proj<VAR>(L, r, E, 0.0);
+                    G -= E - Nn;
+                }
+                const double g2 = wave_sum(wg * G * E0);
+                if (g2 > 1e-6) {
+                    const double tau = cvx::DUAL_REFINE_GAIN * (-ray) * cvx::rcp(g2);
+                    const double Sn = S + tau * G;
+                    if (lane < 55) { L[C_SF + r.ei * 10 + r.ej] = Sn; L[C_SF + r.ej * 10 + r.ei] = Sn; }
+                    CVXW_SYNC();
+                    const int a = lane < 10 ? lane : 0;
+                    const double sz = dot10(L2 + (C_SF + a * 10) / 2, L2 + C_XV / 2);
+                    const double res2 = wave_max(lane < 10 ? fabs(sz) : 0.0);
+                    const double zSz2 = wave_sum(lane < 10 ? L[C_XV + a] * sz : 0.0);
+                    CVXW_SYNC();
+                    double Se2 = Sn + (r.is_diag ? delta : 0.0);
+                    const double mp2 = coop_ldl(L, r, Se2);
+                    if (mp2 > 0 && res2 < 1e-10) { minp = mp2; zSz = zSz2; }
+                }
+            }
         }
     }
     CVXW_PHR(PH_D_LDL2);
@@ -1009,6 +1114,7 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
         bool last = (it >= o.max_iters) || (fp_res < o.res_tol) || (it >= ipm_deadline);
         if (check || last) {
             const double retry_shift = (retries && retry_left > 0) ? o.dual_shift : 0.0;
+            const bool refine = CVX_DUAL_REFINE_COMPILED && o.dual_refine && retry_left > cvx::DUAL_RETRY_ATTEMPTS - cvx::DUAL_REFINE_ATTEMPTS; // (cvx::dual_refine_step: the first attempts of a phase, fresh solves too)
             --retry_left;
             // top eigenvector slot and the runner-up (wave-uniform)
             int smax = 0, s2nd = 0;
@@ -1066,7 +1172,7 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
                     coop_polish(L, roles, Qs, Rc, pobj CVXW_PH_ARG);
                 }
                 CVXW_PH(PH_POLISH);
-                const bool cok = coop_dual<VAR>(L, roles, Qs, W, Wp, Rc, d0, pobj, rho, delta, zSz, retry_shift CVXW_PH_ARG);
+                const bool cok = coop_dual<VAR>(L, roles, Qs, W, Wp, Rc, d0, pobj, rho, delta, zSz, retry_shift, refine CVXW_PH_ARG);
                 CVXW_PH(PH_DUAL);
                 gap_ok = cok && (tr * (fabs(zSz) + 4.0 * delta) <= gap_tol);
                 have_prev = d0 > 0 && (pobj == pobj);
@@ -1142,7 +1248,7 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
                     for (int i = 0; i < 9; ++i) Rc[i] = L[L_M + 30 + i];
                 }
                 pobj = take_m ? fm : fp;
-                const bool cok = coop_dual<VAR>(L, roles, Qs, W, Wp, Rc, take_m ? dm : dp, pobj, rho, delta, zSz, retry_shift CVXW_PH_ARG);
+                const bool cok = coop_dual<VAR>(L, roles, Qs, W, Wp, Rc, take_m ? dm : dp, pobj, rho, delta, zSz, retry_shift, refine CVXW_PH_ARG);
                 const bool ok = cok && (tr * (fabs(zSz) + 4.0 * delta) <= gap_tol);
                 ambiguous = twins && ok;
                 gap_ok = !twins && ok;

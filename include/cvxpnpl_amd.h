@@ -128,6 +128,12 @@ typedef struct {
                             About half of those failed attempts pass (N = 10; fewer iterations for the stragglers: 125 k problems
                             +6 %, four- and six-point problems +8...12 %).  The certificate that is reported is the usual float64
                             statement about the S that passed.  0: no second tries. */
+    int32_t dual_refine;    /* -1 (default): 1.  A dual that still fails after the tries of dual_shift (and the dual of a FIRST attempt, which gets none of
+                            those) gets one eigen-gradient step inside the same family: the bottom eigenvector n of S by two inverse
+                            iterations (LDL^T of S + 0.005 I, started from the runner-up eigenvector of Z), the step S + tau P_U(n n^T) with tau
+                            raising n^T S n to |lambda_min| (first order), one more LDL^T (cvx::dual_refine_step; wave-per-problem and quad
+                            layouts).  Rescues ~87 % of the failed attempts of ten-point problems (the shift tries: 48 %); the certificate
+                            that is reported is the usual float64 statement about the S that passed.  0: never. */
 } cvxpnpl_opts_t;
 
 void cvxpnpl_default_opts(cvxpnpl_opts_t *opts);

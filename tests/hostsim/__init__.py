@@ -18,7 +18,7 @@ class Opts(C.Structure):
                 ("first_check", C.c_int), ("check_every", C.c_int), ("res_tol", C.c_double), ("jacobi_sweeps", C.c_int),
                 ("jacobi_tol", C.c_double), ("warm_start", C.c_int), ("rho_tail", C.c_double), ("tail_from", C.c_int),
                 ("adapt_every", C.c_int), ("adapt_from", C.c_int), ("adapt_mu", C.c_double), ("adapt_tau", C.c_double),
-                ("stall_from", C.c_int), ("stall_lam", C.c_double), ("stall_res", C.c_double), ("stall_drop", C.c_double), ("variant", C.c_int), ("rescue_from", C.c_int), ("f32_sweeps_until", C.c_int), ("sweep_schedule", C.c_int), ("dual_shift", C.c_double)]
+                ("stall_from", C.c_int), ("stall_lam", C.c_double), ("stall_res", C.c_double), ("stall_drop", C.c_double), ("variant", C.c_int), ("rescue_from", C.c_int), ("f32_sweeps_until", C.c_int), ("sweep_schedule", C.c_int), ("dual_shift", C.c_double), ("dual_refine", C.c_int)]
 
 
 def build(force=False):

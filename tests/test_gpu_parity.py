@@ -186,7 +186,7 @@ def test_hip_equals_host_build_of_device_algorithm(gpu):
 
     d = synth.make_pnp(512, 10, 1.0, seed=77)
     hs = hostsim.solve_batch(d["pts_2d"], d["pts_3d"], None, None, d["K"], want_Z=True)
-    for layout in LAYOUTS.values():
+    for name, layout in LAYOUTS.items():
         # first_check = 5 is the host build's schedule; left at its default (0) the library attempts first after 6 iterations in
         # the lane-hybrid layout (checked at the end)
         r = _solve(gpu, d, 10, 0, want_Z=True, layout=layout, first_check=5)
@@ -195,7 +195,9 @@ def test_hip_equals_host_build_of_device_algorithm(gpu):
         assert synth.geodesic(r["R"], hs["R"])[same].max() < 1e-10
         assert np.abs(r["t"] - hs["t"])[same].max() < 1e-10
         assert np.abs(r["Z"] - hs["Z"])[same].max() < 1e-9
-        assert np.abs(r["iters"] - hs["iters"])[same].mean() < 0.1  # same algorithm, same path
+        # same algorithm, same path -- except that the lane phase makes its one attempt without the eigen-gradient step of the dual
+        # (cvx::dual_refine_step): the ~5 % of the problems that step rescues at the first attempt take two more iterations there
+        assert np.abs(r["iters"] - hs["iters"])[same].mean() < (0.2 if name == "lane" else 0.1)
     dflt = {name: _solve(gpu, d, 10, 0, layout=layout) for name, layout in LAYOUTS.items()}
     assert dflt["lane"]["iters"].min() == 6 and dflt["wave"]["iters"].min() == 5 and dflt["quad"]["iters"].min() == 5
     both = (dflt["lane"]["status"] == 0) & (dflt["wave"]["status"] == 0)
