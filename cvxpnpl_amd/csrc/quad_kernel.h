@@ -468,36 +468,6 @@ __device__ __forceinline__ double quad_ldl(double *L, const OWN &w, double *Me)
 }
 
 
-// Symmetric sweep operator over all ten pivots on the matrix held 3-4 entries per lane: Me <- -(Me)^-1, rows broadcast through LDS like
-// quad_ldl's; returns the smallest pivot (the pivots of the LDL^T).  A group whose matrix is not positive definite ends with garbage of
-// its own (the caller discards it): no branch, the four problems of the wavefront stay in step.  (cvxw::coop_sweep_inverse)
-template <class OWN>
-__device__ __forceinline__ double quad_sweep_inverse(double *L, const OWN &w, double *Me)
-{
-    double minp = 1e300;
-#pragma unroll
-    for (int k = 0; k < 10; ++k) {
-#pragma unroll
-        for (int m = 0; m < OWN::EPL; ++m)
-            if (w.ok(m)) {
-                if (w.ei(m) == k) L[C_ROW + w.ej(m)] = Me[m];
-                else if (w.ej(m) == k) L[C_ROW + w.ei(m)] = Me[m];
-            }
-        CVXW_SYNC();
-        const double d = L[C_ROW + k];
-        minp = d < minp ? d : minp;
-        const double id = cvxw::fast_rcp(d);
-#pragma unroll
-        for (int m = 0; m < OWN::EPL; ++m) {
-            const double ra = L[C_ROW + w.ei(m)], rb = L[C_ROW + w.ej(m)];
-            const bool pi = w.ei(m) == k, pj = w.ej(m) == k;
-            Me[m] = (pi && pj) ? -id : (pi ? rb * id : (pj ? ra * id : Me[m] - ra * id * rb));
-        }
-        CVXW_SYNC();
-    }
-    return minp;
-}
-
 // NPW problems per wavefront (four 16-lane or five 12-lane groups): problem b = NPW * blockIdx.x + group.
 // Second phase: the wavefront finishes the problems it could not certify within handoff_at iterations itself,
 // one after the other in the wave-per-problem layout (low latency per problem; they are the slow / ambiguous
@@ -1195,123 +1165,12 @@ CVXQ_PH(4); /* polar + Newton polish */
 #pragma unroll
             for (int m = 0; m < EPL; ++m) Se[m] = S[m] + (((w.pk[m] >> 23) & 1) ? delta : 0.0);
 CVXQ_PH(5); /* dual fit + correction */
-            double minp = quad_ldl(L, w, Se);
+            const double minp = quad_ldl(L, w, Se);
             const bool pre = (res < 1e-10) && (d0 > 0) && (pobj == pobj);
-            if (CVX_DUAL_REFINE_COMPILED && MODE == 0 && o.dual_refine && __any(!done && pre && !symm && !(minp > 0))) { // (MODE 2, the four-point schedule: its first attempt comes after 17 iterations and the step would cost that kernel its register allocation)
-                // ---- a failed dual gets one eigen-gradient step inside the dual family (cvx::dual_refine_step; cvxw::coop_dual has the
-                // one-problem-per-wavefront form).  The four problems run it together; only a problem that needs it takes the result.
-                const bool need = !done && pre && !symm && !(minp > 0);
-                constexpr int R_V = Q_X; // 2 x 10 iteration vectors (the projection's scratch: not live here)
-                {   // start vector: the runner-up eigen column of Z
-                    const double second = grp_max<LPP>(L, gl, (gl < 10 && gl != jmax) ? al : -1.0);
-                    const unsigned t2 = grp_bits<LPP>(__ballot(gl < 10 && gl != jmax && al == second), grp);
-                    const int j2 = __builtin_ctz(t2 | 0x10000u);
-                    CVXW_SYNC();
-                    if (gl == j2) {
-#pragma unroll
-                        for (int i = 0; i < 10; ++i) L[R_V + i] = vrow(i);
-                    }
-                }
-                double Xe[EPL];
-#pragma unroll
-                for (int m = 0; m < EPL; ++m) Xe[m] = S[m] + (((w.pk[m] >> 23) & 1) ? delta + cvx::DUAL_REFINE_SIGMA : 0.0);
-                const double mps = quad_sweep_inverse(L, w, Xe);
-#pragma unroll
-                for (int m = 0; m < EPL; ++m)
-                    if (w.ok(m)) { L[Q_WF + w.ei(m) * 10 + w.ej(m)] = -Xe[m]; L[Q_WF + w.ej(m) * 10 + w.ei(m)] = -Xe[m]; }
-                CVXW_SYNC();
-                double x[10];
-#pragma unroll
-                for (int itn = 0; itn <= cvx::DUAL_REFINE_INVITS; ++itn) {
-                    const int cur = R_V + 10 * (itn & 1), nxt = R_V + 10 * ((itn + 1) & 1);
-                    double zx = 0.0, n2 = 0.0;
-#pragma unroll
-                    for (int i = 0; i < 10; ++i) { x[i] = L[cur + i]; zx += L[C_XV + i] * x[i]; }
-#pragma unroll
-                    for (int i = 0; i < 10; ++i) { x[i] -= 0.25 * zx * L[C_XV + i]; n2 += x[i] * x[i]; }
-                    const double in = cvx::rsqrt_(n2 > 1e-300 ? n2 : 1e-300);
-#pragma unroll
-                    for (int i = 0; i < 10; ++i) x[i] *= in;
-                    if (itn < cvx::DUAL_REFINE_INVITS) {
-                        double xs = 0.0;
-#pragma unroll
-                        for (int i = 0; i < 10; ++i) xs = gl == i ? x[i] : xs;
-                        CVXW_SYNC();
-                        if (gl < 10) L[cur + gl] = xs;
-                        CVXW_SYNC();
-                        if (gl < 10) L[nxt + gl] = cvxw::dot10(L2 + (Q_WF + gl * 10) / 2, L2 + cur / 2);
-                        CVXW_SYNC();
-                    }
-                }
-                double E0[EPL], G[EPL];
-                double part = 0.0;
-#pragma unroll
-                for (int m = 0; m < EPL; ++m) {
-                    double xi = 0.0, xj = 0.0;
-#pragma unroll
-                    for (int i = 0; i < 10; ++i) { xi = w.ei(m) == i ? x[i] : xi; xj = w.ej(m) == i ? x[i] : xj; }
-                    E0[m] = xi * xj;
-                    G[m] = E0[m];
-                    part += w.wgt(m) * S[m] * E0[m];
-                }
-                const double ray = grp_sum<LPP>(L, gl, part);
-                // G = P_U(x x^T): onto span A_i, then the minimum-norm correction onto { X z = 0 }
-                CVXW_SYNC();
-                quad_proj<VAR>(L, w, G, 0.0);
-#pragma unroll
-                for (int m = 0; m < EPL; ++m) {
-                    G[m] = E0[m] - G[m];
-                    if (w.ok(m)) { L[Q_WF + w.ei(m) * 10 + w.ej(m)] = G[m]; L[Q_WF + w.ej(m) * 10 + w.ei(m)] = G[m]; }
-                }
-                CVXW_SYNC();
-                if (gl < 10) L[C_ROW + gl] = cvxw::dot10(L2 + (Q_WF + gl * 10) / 2, L2 + C_XV / 2);
-                CVXW_SYNC();
-                {
-                    double rhs[10], lamv[10];
-#pragma unroll
-                    for (int i = 0; i < 10; ++i) rhs[i] = L[C_ROW + i];
-                    cvx::dual_lambda<VAR>(Rc, rhs, false, lamv);
-                    if (gl == 0) {
-#pragma unroll
-                        for (int i = 0; i < 10; ++i) L[C_LAM + i] = lamv[i];
-                    }
-                }
-                CVXW_SYNC();
-                {
-                    double E[EPL], Nn[EPL];
-#pragma unroll
-                    for (int m = 0; m < EPL; ++m) {
-                        E[m] = 0.5 * (L[C_LAM + w.ei(m)] * L[C_XV + w.ej(m)] + L[C_XV + w.ei(m)] * L[C_LAM + w.ej(m)]);
-                        Nn[m] = E[m];
-                    }
-                    quad_proj<VAR>(L, w, Nn, 0.0);
-                    part = 0.0;
-#pragma unroll
-                    for (int m = 0; m < EPL; ++m) { G[m] -= E[m] - Nn[m]; part += w.wgt(m) * G[m] * E0[m]; }
-                }
-                const double g2 = grp_sum<LPP>(L, gl, part);
-                const bool go = need && mps > 0 && ray < 0 && g2 > 1e-6;
-                const double tau = go ? cvx::DUAL_REFINE_GAIN * (-ray) * cvx::rcp(g2) : 0.0;
-                double Sn[EPL];
-#pragma unroll
-                for (int m = 0; m < EPL; ++m) {
-                    Sn[m] = S[m] + tau * G[m];
-                    if (w.ok(m)) { L[Q_WF + w.ei(m) * 10 + w.ej(m)] = Sn[m]; L[Q_WF + w.ej(m) * 10 + w.ei(m)] = Sn[m]; }
-                }
-                CVXW_SYNC();
-                double res2, zSz2;
-                {
-                    const int aa = gl < 10 ? gl : 0;
-                    const double sz = cvxw::dot10(L2 + (Q_WF + aa * 10) / 2, L2 + C_XV / 2);
-                    res2 = grp_max<LPP>(L, gl, gl < 10 ? fabs(sz) : 0.0);
-                    zSz2 = grp_sum<LPP>(L, gl, gl < 10 ? L[C_XV + aa] * sz : 0.0);
-                }
-                CVXW_SYNC();
-#pragma unroll
-                for (int m = 0; m < EPL; ++m) Se[m] = Sn[m] + (((w.pk[m] >> 23) & 1) ? delta : 0.0);
-                const double mp2 = quad_ldl(L, w, Se);
-                if (go && mp2 > 0 && res2 < 1e-10) { minp = mp2; zSz = zSz2; }
-            }
+            // (The eigen-gradient step of the dual, cvx::dual_refine_step, is NOT made here -- measured, round 6, profiles/r06/refine_ab3.txt: with the
+            //  step in this phase the four problems of a wavefront pay for it in lockstep whenever one of them fails, and the wavefronts that end
+            //  a launch pay it twice before the hand-over: judged launch 50.9 M poses/s without the code, 48.4 with it compiled in and switched
+            //  off (register allocation), 46.6 with it on; 16 k 66.3 / 62.7 / 60.8.  The wave-per-problem phase behind the hand-over makes it.)
             const bool cok = (minp > 0) && pre;
             const bool gap_ok = cok && (tr * (fabs(zSz) + 4.0 * delta) <= gap_tol);
             have_prev = d0 > 0 && (pobj == pobj);

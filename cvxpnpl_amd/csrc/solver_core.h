@@ -90,8 +90,16 @@ constexpr double DUAL_REFINE_SIGMA = 0.005; // dual_refine_step: shift of the in
                                             // the next eigenvalue ~ 3e-2: two iterations with this shift resolve the bottom eigenvector to ~1e-3)
 constexpr int DUAL_REFINE_INVITS = 2;
 constexpr double DUAL_REFINE_GAIN = 2.0;    // the step raises the bottom Rayleigh quotient by this multiple of its distance from zero (first order)
-constexpr int DUAL_REFINE_ATTEMPTS = 3;     // ... at the first this many attempts of a phase: a dual it has not repaired by then is far from the cone (the long chains of a launch: their
-                                            // problems would pay for it at every attempt)
+constexpr int DUAL_REFINE_FROM = 2;         // ... from the third attempt of a solve on (the scalar core; the kernels: in the wave-per-problem phase behind a quad phase, whose
+                                            // two attempts these are) ...
+constexpr int DUAL_REFINE_ATTEMPTS = 3;     // ... for three attempts: a dual it has not repaired by then is far from the cone, and the long chain that ends a launch would
+                                            // pay for the step at every attempt.  Where: measured, round 6 (profiles/r06/refine_ab3*.txt, refine_cost.txt).  One step costs a
+                                            // wavefront 9.6 us on its chain (1.2-1.7 iterations), a rescue saves two iterations and an attempt (23.5 us): on AVERAGE a clear
+                                            // gain at a rescue rate of 87 %, but a launch ends with its slowest chain, and the problems of those chains are the ones the
+                                            // step does not rescue.  Judged 10 k launch (quad schedule, step in the wave-per-problem phase): 50.4 -> 53.6 M poses/s, other
+                                            // seeds +4 ... +15 %; in the quad phase itself: -8 % (four problems in lockstep); fresh wave-per-problem solves (2 000 problems):
+                                            // -5.5 % although the slowest problem takes 9 instead of 11 iterations; resume phase behind the lane phase (125 k): -2.2 % (its
+                                            // 33-iteration chain pays three steps for nothing).
 constexpr int DUAL_RETRY_ATTEMPTS = 10; // ... in the first this many attempts that may use them: a problem they have not rescued by then is not
                                         // one they rescue (same iteration counts with 6 / 10 / 16 / no limit on four workloads), and its long
                                         // chain stops paying for them (N = 8, 125 k problems, slowest 99 iterations: 160.4 -> 162.6 M poses/s)
@@ -1639,7 +1647,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
             // a failed dual gets its second tries (dual_certificate) from the second attempt of a solve on: the first attempt of every
             // problem would pay for them, the later ones are the slow problems that end a launch (the lane phase makes one attempt)
             const double retry_shift = (TWIN && attempts > 0 && attempts <= DUAL_RETRY_ATTEMPTS) ? o.dual_shift : 0.0;
-            const bool refine = TWIN && o.dual_refine && attempts < DUAL_REFINE_ATTEMPTS; // (the eigen-gradient step: at the first attempt too)
+            const bool refine = TWIN && o.dual_refine && attempts >= DUAL_REFINE_FROM && attempts < DUAL_REFINE_FROM + DUAL_REFINE_ATTEMPTS; // (the eigen-gradient step)
             ++attempts;
             // top eigenvector of Wp (and the runner-up, see below)
             int jm = 0, j2 = 0;

@@ -1114,7 +1114,7 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
         bool last = (it >= o.max_iters) || (fp_res < o.res_tol) || (it >= ipm_deadline);
         if (check || last) {
             const double retry_shift = (retries && retry_left > 0) ? o.dual_shift : 0.0;
-            const bool refine = CVX_DUAL_REFINE_COMPILED && o.dual_refine && retry_left > cvx::DUAL_RETRY_ATTEMPTS - cvx::DUAL_REFINE_ATTEMPTS; // (cvx::dual_refine_step: the first attempts of a phase, fresh solves too)
+            const bool refine = CVX_DUAL_REFINE_COMPILED && o.dual_refine && resume_full_in && retry_left > cvx::DUAL_RETRY_ATTEMPTS - cvx::DUAL_REFINE_ATTEMPTS; // (cvx::dual_refine_step: the first attempts of the phase behind a QUAD phase; where it pays and where not: solver_core.h at DUAL_REFINE_ATTEMPTS)
             --retry_left;
             // top eigenvector slot and the runner-up (wave-uniform)
             int smax = 0, s2nd = 0;

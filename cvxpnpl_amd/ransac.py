@@ -65,11 +65,10 @@ def ransac_pnp(pts_2d, pts_3d, K, n_hyp: int = 4096, thresh: float = 2.0, max_it
             st_new = fit.status.to(torch.int64)
             usable = ((st_new == 0) | (st_new == 2)) & (cnt.to(torch.int64) >= 4)
             take = usable & (n_new >= n_inl)          # (the refit of the same set is the better pose for it; a smaller set is not taken)
-            grow = usable & (n_new > n_inl)
             R = torch.where(take[:, None, None], fit.R, R)
             t = torch.where(take[:, None], fit.t, t)
             status = torch.where(take, st_new, status)
-            mask = torch.where(grow[:, None], mask_new, mask)
-            n_inl = torch.where(grow, n_new, n_inl)
+            mask = torch.where(take[:, None], mask_new, mask)   # pose and mask change together: on a tie the mask is the refit pose's own
+            n_inl = torch.where(take, n_new, n_inl)
     head = torch.stack([status[0], n_inl[0], (res.status == 0).sum()]).cpu()   # the frame's one synchronisation
     return {"R": R[0], "t": t[0], "inliers": mask[0].bool(), "n_inliers": int(head[1]), "status": int(head[0]), "n_certified": int(head[2]), "n_hyp": n_hyp}

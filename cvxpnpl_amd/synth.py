@@ -49,6 +49,19 @@ def make_pnpl(batch, n_p, n_l, sigma=0.0, seed=42, K=K_KINECT):
     }
 
 
+def example_pnp():
+    """The single problem of the reference's examples/pnp.py:5-26 (six points of the 0.6 cube from the legacy generator seeded with 42,
+    integer toy intrinsics, a literal pose with 8 digits): the reference's own unit of timing is one such call
+    (benchmarks/toolkit/suites/suite.py:75-85).  Returns pts_2d [6,2], pts_3d [6,3], K [3,3] (int), R_gt, t_gt."""
+    rs = np.random.RandomState(42)
+    X = LENGTH * (rs.random_sample((6, 3)) - 0.5)
+    K = np.array([[160, 0, 320], [0, 120, 240], [0, 0, 1]])
+    R = np.array([[-0.48048015, 0.1391384, -0.86589799], [-0.0333282, -0.98951829, -0.14050899], [-0.8763721, -0.03865296, 0.48008113]])
+    t = np.array([-0.10266772, 0.25450789, 1.70391109])
+    h = (X @ R.T + t) @ K.T
+    return {"pts_2d": h[:, :2] / h[:, 2:], "pts_3d": X, "K": K, "R_gt": R, "t_gt": t}
+
+
 def make_pnp(batch, n, sigma=0.0, seed=42, K=K_KINECT):
     return make_pnpl(batch, n, 0, sigma, seed, K)
 

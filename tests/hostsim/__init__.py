@@ -46,6 +46,11 @@ def _p(a):
     return a.ctypes.data_as(_dp) if a is not None else None
 
 
+def set_threads(n):
+    """OpenMP threads of the batch entry points; returns the previous maximum."""
+    return int(lib().hs_set_threads(int(n)))
+
+
 def default_opts(**kw):
     o = Opts()
     lib().hs_default_opts(C.byref(o))

@@ -6,7 +6,11 @@
 #include "../../cvxpnpl_amd/csrc/ipm_core.h"
 #include "../../cvxpnpl_amd/csrc/lane_core.h"
 
+#include <omp.h>
 extern "C" {
+
+// thread count of the OpenMP loops below (bench.py: the all-cores and the single-core host baselines); returns the previous maximum
+int hs_set_threads(int n) { const int p = omp_get_max_threads(); if (n > 0) omp_set_num_threads(n); return p; }
 
 void hs_default_opts(cvx::Opts *o) { *o = cvx::default_opts(); }
 

@@ -118,3 +118,50 @@ def test_second_tries_on_the_device():
     assert (gap >= -1e-15).all() and (gap <= 1.0001e-9 + 1e-12 * np.abs(b["cost"][:, 0])).all()
     with pytest.raises(RuntimeError, match="bad options"):
         _solve(dev, d, 10, 0, dual_shift=-0.1)
+
+
+def test_scalar_core_with_and_without_the_eigen_gradient_step():
+    """opts.dual_refine (cvx::dual_refine_step): same certified optimum, same certificate statement, fewer iterations for the stragglers."""
+    import hostsim
+    from cvxpnpl_amd import synth
+    from test_gpu_parity import geodesic_np
+
+    d = synth.make_pnpl(6000, 10, 0, 2.0, seed=42)
+    a = hostsim.solve_batch(d["pts_2d"], d["pts_3d"], None, None, d["K"], opts=hostsim.default_opts(dual_refine=0))
+    b = hostsim.solve_batch(d["pts_2d"], d["pts_3d"], None, None, d["K"], opts=hostsim.default_opts())
+    assert hostsim.default_opts().dual_refine == 1
+    assert (a["status"] == 0).all() and (b["status"] == 0).all()
+    assert max(geodesic_np(a["R"][i], b["R"][i]) for i in np.flatnonzero(a["iters"] != b["iters"])) < 1e-8   # both are the certified global optimum
+    # the step is made from the third attempt of a solve on (iteration 9): what needed 11 and more iterations mostly stops at 9
+    assert (b["iters"] <= a["iters"]).all() and (b["iters"] >= 11).sum() <= 0.5 * (a["iters"] >= 11).sum() and (a["iters"] >= 11).sum() >= 10
+    gap = b["cost"][:, 0] - b["cost"][:, 1]
+    assert (gap >= -1e-15).all() and (gap <= 1.0001e-9 + 1e-12 * np.abs(b["cost"][:, 0])).all()                # the certificate statement is unchanged
+
+
+@pytest.mark.gpu
+def test_the_eigen_gradient_step_on_the_device():
+    """quad schedule (10 000 problems): the wave-per-problem phase behind the quad phase makes the step; statuses equal, stragglers shorter,
+    poses the same certified optimum; fresh wave-per-problem launches and the lane schedule do not make it (same iteration counts)."""
+    import torch
+    from test_gpu_parity import _solve, geodesic_np
+
+    from cvxpnpl_amd import synth
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    dev = torch.device("cuda:0")
+    d = synth.make_pnpl(10000, 10, 0, 2.0, seed=3)
+    a = _solve(dev, d, 10, 0, dual_refine=0)
+    b = _solve(dev, d, 10, 0)
+    assert (a["status"] == 0).all() and (b["status"] == 0).all()
+    diff = np.flatnonzero(a["iters"] != b["iters"])
+    assert len(diff) >= 5 and max(geodesic_np(a["R"][i], b["R"][i]) for i in diff) < 1e-8
+    assert (b["iters"] <= a["iters"]).all() and (b["iters"] >= 11).sum() < (a["iters"] >= 11).sum()
+    gap = b["cost"][:, 0] - b["cost"][:, 1]
+    assert (gap >= -1e-15).all() and (gap <= 1.0001e-9 + 1e-12 * np.abs(b["cost"][:, 0])).all()
+    for layout, n in ((2, 1500), (1, 30000)):
+        dd = synth.make_pnpl(n, 10, 0, 2.0, seed=5)
+        a = _solve(dev, dd, 10, 0, layout=layout, dual_refine=0)
+        b = _solve(dev, dd, 10, 0, layout=layout)
+        assert np.array_equal(a["iters"], b["iters"]) and np.array_equal(a["status"], b["status"]), layout
+    with pytest.raises(RuntimeError, match="bad options"):
+        _solve(dev, d, 10, 0, dual_refine=2)

@@ -1,30 +1,27 @@
-"""Kernel resource table of a verbose build (container):  python -m cvxpnpl_amd.build --force -v > log 2>&1; python tools/resource_table.py log
-One line per kernel: VGPRs, AGPRs, scratch bytes per lane, wavefronts per SIMD, spilled SGPRs / VGPRs, LDS bytes per block."""
-import re
-import subprocess
+"""Kernel resource table of a build (container):  python tools/resource_table.py [remarks file]
+Default: the remarks cvxpnpl_amd/build.py keeps beside the library (cvxpnpl_amd/libcvxpnpl_amd.resources.txt).  One line per kernel:
+VGPRs, AGPRs, scratch bytes per lane, wavefronts per SIMD, spilled SGPRs / VGPRs, LDS bytes per block.
+`--write-golden` rewrites tests/golden/kernel_resources.json (the table tests/test_kernel_resources.py holds a build against)."""
+import json
+import os
 import sys
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cvxpnpl_amd import build as _b  # noqa: E402
 
-def main(path):
-    rows, cur = [], None
-    for line in open(path):
-        m = re.search(r"remark:\s+(.*?) \[-Rpass", line)
-        if not m:
-            continue
-        t = m.group(1)
-        if t.startswith("Function Name:"):
-            cur = {"name": t.split(":", 1)[1].strip()}
-            rows.append(cur)
-        elif cur is not None and ":" in t:
-            k, v = t.split(":", 1)
-            cur[k.strip()] = v.strip()
-    names = subprocess.run(["c++filt"] + [r["name"] for r in rows], capture_output=True, text=True).stdout.splitlines()
+
+def main(argv):
+    args = [a for a in argv if not a.startswith("--")]
+    table = _b.kernel_resources(args[0] if args else _b.RESOURCES)
     print(f"{'kernel':72s} {'VGPR':>5s} {'AGPR':>5s} {'scratch':>8s} {'occ':>4s} {'sgprS':>6s} {'vgprS':>6s} {'LDS':>7s}")
-    for r, d in zip(rows, names):
-        d = re.sub(r"\(.*", "", d.replace("(anonymous namespace)::", "")).replace("void ", "")
-        print(f"{d[:72]:72s} {r.get('VGPRs'):>5s} {r.get('AGPRs'):>5s} {r.get('ScratchSize [bytes/lane]'):>8s} {r.get('Occupancy [waves/SIMD]'):>4s} "
-              f"{r.get('SGPRs Spill'):>6s} {r.get('VGPRs Spill'):>6s} {r.get('LDS Size [bytes/block]'):>7s}")
+    for name, r in table.items():
+        print(f"{name[:72]:72s} {r['vgpr']:>5d} {r['agpr']:>5d} {r['scratch']:>8d} {r['occupancy']:>4d} {r['sgpr_spill']:>6d} {r['vgpr_spill']:>6d} {r['lds']:>7d}")
+    if "--write-golden" in argv:
+        path = os.path.join(ROOT, "tests", "golden", "kernel_resources.json")
+        json.dump(table, open(path, "w"), indent=1, sort_keys=True)
+        print("wrote", path)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1:])
