@@ -154,10 +154,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         backend = args.backend if args.backend != "auto" else ("gloo" if shared else "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        # rendezvous + a tiny all_reduce and all_gather under a 60 s watchdog: a rank that cannot reach the others says so in one line and
+        # exits (code 3) instead of hanging the run (cvxpnpl_amd.dist.init_with_preflight)
+        from cvxpnpl_amd.dist import init_with_preflight
+        preflight = init_with_preflight(backend, rank, world, device=dev, timeout_s=float(os.environ.get("CVXPNPL_PREFLIGHT_TIMEOUT", "60")))
 
     n_p, n_l, batch, sigma = WORKLOADS[args.workload]
     if args.workload == "pnp_scal":
@@ -287,7 +287,9 @@ def main():
             # batch -- the exchange of step k runs under the solve of step k + 1 and nothing of it sits on the solve stream.
             with torch.cuda.stream(side):
                 if handover[0] == "flag":
-                    rc = L.cvxpnpl_stream_wait_value(ptr(step_flag), step_no[0], C.c_void_p(side.cuda_stream))
+                    # (the EXPLICITLY fail-open wait: this script checks the give-up word after the warm-up and after the timed region
+                    #  and repeats a region in which a wait gave up; cvxpnpl_stream_wait_value itself holds its stream until acknowledged)
+                    rc = L.cvxpnpl_stream_wait_value_bounded(ptr(step_flag), step_no[0], 1 << 18, C.c_void_p(side.cuda_stream))
                     if rc != 0:
                         raise RuntimeError(_lib.last_error())
                 else:
@@ -726,8 +728,9 @@ def main():
         coll = {"backend": backend + (" (RCCL)" if backend == "nccl" else " (ranks share a device: diagnostics, not RCCL)"),
                 "ranks": dist.get_world_size(), "ranks_seen": int(round(float(ones.item()))), "devices": min(world, n_dev),
                 "distinct_devices": len({(x["host"], x["device_index"]) for x in descs}), "per_rank": descs,
+                "preflight": preflight,  # rendezvous + tiny all_reduce / all_gather under a watchdog, before anything else (ms per stage)
                 "value_is": "problems of all ranks over the K steps / the slowest rank's wall time (all_reduce MAX)",
-                "handover": (("device flag (cvxpnpl_stream_write_value / _wait_value)" if handover[0] == "flag" else "event") +
+                "handover": (("device flag (cvxpnpl_stream_write_value / _wait_value_bounded, checked)" if handover[0] == "flag" else "event") +
                              (f"; {handover_retries} timed region(s) discarded because a flag wait gave up" if handover_retries else "")) if gather else None,
                 "exchange": ((f"one gather to rank 0 of {world} x {batch_pad} records of 13 doubles per step" if to_root else
                               f"one all_gather_into_tensor of {world} x {batch_pad} records of 13 doubles per step") +

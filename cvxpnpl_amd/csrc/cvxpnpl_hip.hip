@@ -3,6 +3,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <map>
 #include <memory>
@@ -728,7 +729,11 @@ __global__ void stream_write_value_kernel(unsigned long long *flag, unsigned lon
     // max, not store: write kernels enqueued on different streams may complete out of order and the flag must never move backwards
     __hip_atomic_fetch_max(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void stream_wait_value_kernel(unsigned long long *flag, unsigned long long value, unsigned long long max_polls)
+// closed = true (cvxpnpl_stream_wait_value): a wait that gives up HOLDS its stream until the host has acknowledged the give-up
+// (cvxpnpl_stream_wait_gave_up clears flag[1]); nobody acknowledging within ack_polls (~2^25 polls, half a minute) is a caller bug and ends in a
+// trap -- loud, never a consumer silently reading unfinished results.  closed = false (cvxpnpl_stream_wait_value_bounded): the explicit
+// fail-open form of rounds 3-5.
+__global__ void stream_wait_value_kernel(unsigned long long *flag, unsigned long long value, unsigned long long max_polls, int closed, unsigned long long ack_polls)
 {
     // bounded (max_polls > 0): if the two streams share a hardware queue the producer's kernel sits BEHIND this one and the flag can never
     // arrive -- after max_polls polls of ~1 us (cvxpnpl_stream_wait_value: 2^18, ~0.25 s) the wait gives up and says so in flag[1]
@@ -738,6 +743,12 @@ __global__ void stream_wait_value_kernel(unsigned long long *flag, unsigned long
         __builtin_amdgcn_s_sleep(32);
     }
     __hip_atomic_store(flag + 1, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!closed) return;
+    for (unsigned long long spin = 0; spin < ack_polls; ++spin) {
+        if (__hip_atomic_load(flag + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == 0ull) return; // acknowledged: the caller knows
+        __builtin_amdgcn_s_sleep(64);
+    }
+    __builtin_trap();
 }
 
 int cvxpnpl_stream_write_value(uint64_t *d_flag, uint64_t value, void *stream)
@@ -748,26 +759,52 @@ int cvxpnpl_stream_write_value(uint64_t *d_flag, uint64_t value, void *stream)
     return e == hipSuccess ? 0 : set_err("stream_write_value_kernel launch", e);
 }
 
-int cvxpnpl_stream_wait_value_bounded(uint64_t *d_flag, uint64_t value, uint64_t max_polls, void *stream)
+static int launch_wait(uint64_t *d_flag, uint64_t value, uint64_t max_polls, int closed, void *stream)
 {
     if (!d_flag) { snprintf(g_err, sizeof(g_err), "cvxpnpl_stream_wait_value: null flag"); return -1; }
     hipLaunchKernelGGL(stream_wait_value_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long *)d_flag, (unsigned long long)value,
-                       (unsigned long long)max_polls);
+                       (unsigned long long)max_polls, closed, 1ull << 25);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : set_err("stream_wait_value_kernel launch", e);
 }
 
-int cvxpnpl_stream_wait_value(uint64_t *d_flag, uint64_t value, void *stream) { return cvxpnpl_stream_wait_value_bounded(d_flag, value, 1ull << 18, stream); }
+int cvxpnpl_stream_wait_value_bounded(uint64_t *d_flag, uint64_t value, uint64_t max_polls, void *stream) { return launch_wait(d_flag, value, max_polls, 0, stream); }
+
+int cvxpnpl_stream_wait_value(uint64_t *d_flag, uint64_t value, void *stream) { return launch_wait(d_flag, value, 1ull << 18, 1, stream); }
+
+// The give-up word is read (and cleared) on a stream of the library's own, so that the call works while a closed wait holds `stream`.
+static hipStream_t ack_stream()
+{
+    static std::mutex mu;
+    static hipStream_t s[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> g(mu);
+    if (!s[dev] && hipStreamCreateWithFlags(&s[dev], hipStreamNonBlocking) != hipSuccess) s[dev] = nullptr;
+    return s[dev];
+}
 
 int cvxpnpl_stream_wait_gave_up(uint64_t *d_flag, int32_t clear, void *stream)
 {
     if (!d_flag) { snprintf(g_err, sizeof(g_err), "cvxpnpl_stream_wait_gave_up: null flag"); return -1; }
-    unsigned long long w = 0;
-    hipError_t e = hipMemcpyAsync(&w, d_flag + 1, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream);
-    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
-    if (e == hipSuccess && clear && w != 0) e = hipMemsetAsync(d_flag + 1, 0, sizeof(w), (hipStream_t)stream);
-    if (e != hipSuccess) return set_err("cvxpnpl_stream_wait_gave_up", e);
-    return w != 0 ? 1 : 0;
+    hipStream_t as = ack_stream();
+    if (!as) { snprintf(g_err, sizeof(g_err), "cvxpnpl_stream_wait_gave_up: no stream for the acknowledgement"); return -2; }
+    for (;;) {
+        // (the state of `stream` is sampled BEFORE the word: when the stream was already idle no wait of it can set the word afterwards)
+        const hipError_t q = hipStreamQuery((hipStream_t)stream);
+        if (q != hipSuccess && q != hipErrorNotReady) return set_err("cvxpnpl_stream_wait_gave_up (stream)", q);
+        unsigned long long w = 0;
+        hipError_t e = hipMemcpyAsync(&w, d_flag + 1, sizeof(w), hipMemcpyDeviceToHost, as);
+        if (e == hipSuccess) e = hipStreamSynchronize(as);
+        if (e == hipSuccess && w != 0 && clear) {
+            e = hipMemsetAsync(d_flag + 1, 0, sizeof(w), as); // releases a closed wait that is holding `stream`
+            if (e == hipSuccess) e = hipStreamSynchronize(as);
+        }
+        if (e != hipSuccess) return set_err("cvxpnpl_stream_wait_gave_up", e);
+        if (w != 0) return 1;
+        if (q == hipSuccess) return 0; // everything the waits ordered is complete, and none gave up
+        usleep(50);
+    }
 }
 
 int cvxpnpl_pack_results(int64_t batch, const double *d_R, const double *d_t, const int32_t *d_status, double *d_packed, void *stream)

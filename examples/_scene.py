@@ -35,8 +35,11 @@ def to_pixels(X, R, t, K=K_TOY):
 
 
 def rotation_gap(R, R_true):
-    """geodesic distance on SO(3), radians"""
-    return float(np.arccos(np.clip((np.trace(R_true.T @ R) - 1.0) / 2.0, -1.0, 1.0)))
+    """geodesic distance on SO(3), radians (the atan2 form: the arccos of a trace cannot resolve angles below ~1e-8, and the
+    8-digit literals are orthogonal to ~1e-8 only)"""
+    D = R_true.T @ R
+    s = 0.5 * np.array([D[2, 1] - D[1, 2], D[0, 2] - D[2, 0], D[1, 0] - D[0, 1]])
+    return float(np.arctan2(np.linalg.norm(s), 0.5 * (np.trace(D) - 1.0)))
 
 
 def report(poses, R_true, t_true, tol=1e-6):

@@ -261,21 +261,27 @@ int cvxpnpl_pack_results(int64_t batch, const double *d_R, const double *d_t, co
    atomic max: values written from several streams may land out of order -- with more than one producing stream a wait for step n can
    then pass on the strength of step n + 1, so use one flag per producing stream); it is polled by one sleeping wavefront.  (An event
    record between two kernels of a stream costs that stream ~17 us here, this ~2 us.)
-   d_flag points to TWO 64-bit words, both zero at the start: [0] the flag, [1] set to 1 (and never cleared) by a wait that gave up
-   after ~0.25 s of polling -- which happens when the two streams share a hardware queue (the producer's kernel then sits behind the
-   wait), or when the producer simply takes longer than that.  THE WAIT FAILS OPEN: after a give-up the consumer stream goes on, and
-   what it reads may not be finished.  A consumer must therefore read d_flag[1] at EVERY point where it synchronises and uses what the
-   waits ordered -- not only after the first use -- and throw those results away (and fall back to an event) when it is set; bench.py
-   checks after its warm-up and again after its timed region, and repeats a region in which a wait gave up. */
+   d_flag points to TWO 64-bit words, both zero at the start: [0] the flag, [1] set to 1 by a wait that gave up after ~0.25 s of polling --
+   which happens when the two streams share a hardware queue (the producer's kernel then sits behind the wait), or when the producer
+   simply takes longer than that.
+   cvxpnpl_stream_wait_value FAILS CLOSED (round 6): a wait that gave up HOLDS its stream -- nothing enqueued behind it runs -- until the
+   host has acknowledged the give-up with cvxpnpl_stream_wait_gave_up(d_flag, 1, stream), which tells the caller (return value 1: discard
+   what the waits ordered, fall back to an event) and releases the stream.  A give-up nobody acknowledges within about half a minute
+   ends in a trap on that stream (a HIP error at the next call): loud, never a consumer silently reading unfinished results.  Callers of
+   this wait must therefore poll cvxpnpl_stream_wait_gave_up instead of synchronising the stream blindly. */
 int cvxpnpl_stream_write_value(uint64_t *d_flag, uint64_t value, void *stream);
 int cvxpnpl_stream_wait_value(uint64_t *d_flag, uint64_t value, void *stream);
-/* The same wait with the bound as a parameter: max_polls polls of ~1 us each before it gives up (cvxpnpl_stream_wait_value uses 2^18, about
-   0.25 s -- shorter than a legitimate large step can be); 0 = unbounded: never fails open, and hangs the consumer stream for good if the
-   two streams do share a hardware queue -- only for callers that have established (one bounded wait, checked) that they do not. */
+/* The EXPLICITLY FAIL-OPEN form, with the bound as a parameter: max_polls polls of ~1 us each before it gives up, sets d_flag[1] and lets
+   its stream go on -- what the consumer then reads may not be finished.  For callers that check d_flag[1] (cvxpnpl_stream_wait_gave_up) at
+   EVERY point where they synchronise and use what the waits ordered, and throw those results away when it is set: bench.py checks after
+   its warm-up and again after its timed region, and repeats a region in which a wait gave up.  0 = unbounded: never gives up, and hangs
+   the consumer stream for good if the two streams do share a hardware queue -- only for callers that have established (one bounded wait,
+   checked) that they do not. */
 int cvxpnpl_stream_wait_value_bounded(uint64_t *d_flag, uint64_t value, uint64_t max_polls, void *stream);
-/* The check a consumer of bounded waits owes (see above), as a call that cannot be forgotten half-way: synchronises `stream` (the
-   consumer's: everything the waits ordered is then complete or known to be unusable), returns 1 if a wait on this flag has given up since the
-   word was last cleared, 0 if none has, negative for an error; clear != 0 resets the word (on `stream`) after reading it. */
+/* The check a consumer of these waits owes, as one call: waits until `stream` is idle OR a wait on this flag has given up, whichever comes
+   first (the give-up word is read on a stream of the library's own, so the call works while a closed wait is holding `stream`).  Returns 1
+   if a wait has given up since the word was last cleared, 0 if `stream` has drained and none has, negative for an error.  clear != 0
+   resets the word after reading it -- which is also what releases a closed wait. */
 int cvxpnpl_stream_wait_gave_up(uint64_t *d_flag, int32_t clear, void *stream);
 
 /*

@@ -180,3 +180,55 @@ def test_per_rank_input_shards_and_gather_to_root(tmp_path):
     for r in range(3):
         got = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
         assert np.array_equal(got["R"], ref["R"]) and np.array_equal(got["t"], ref["t"]) and np.array_equal(got["st"], ref["status"])
+
+
+_PREFLIGHT_SCRIPT = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+rank, world, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+os.environ["MASTER_ADDR"] = "127.0.0.1"
+os.environ["MASTER_PORT"] = sys.argv[4]
+if mode == "never_starts" and rank == 1:
+    sys.exit(0)                      # a rank that died before the rendezvous
+from cvxpnpl_amd import dist as cd
+if mode == "dies_after_rendezvous" and rank == 1:
+    import datetime
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=20))
+    os._exit(0)                      # ... or right after it
+info = cd.init_with_preflight("gloo", rank, world, timeout_s=float(sys.argv[5]))
+print("PREFLIGHT_OK", info["ranks_seen"], sorted(info))
+"""
+
+
+def _run_preflight(mode, timeout_s, world=2):
+    import subprocess
+    import time
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    code = _PREFLIGHT_SCRIPT.format(root=os.path.dirname(HERE))
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(world), mode, str(port), str(timeout_s)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    return [p.returncode for p in procs], outs, time.time() - t0
+
+
+def test_preflight_passes_and_reports_its_stages():
+    rcs, outs, _ = _run_preflight("ok", 60)
+    assert rcs == [0, 0], outs
+    for so, _ in outs:
+        assert "PREFLIGHT_OK 2" in so and "all_gather_ms" in so and "all_reduce_ms" in so and "init_ms" in so
+
+
+@pytest.mark.parametrize("mode", ["never_starts", "dies_after_rendezvous"])
+def test_a_dead_rank_gives_a_diagnosis_not_a_hang(mode):
+    """first contact with a multi-GPU node must not be a debugging session: a rank whose peer is gone says so in one line within the
+    preflight's time limit (here 6 s; bench.py: 60 s) and exits non-zero"""
+    rcs, outs, took = _run_preflight(mode, 6)
+    assert rcs[0] != 0 and took < 45, (rcs, took)
+    err = outs[0][1]
+    assert "preflight" in err and "rank 0 of 2" in err and "backend gloo" in err and "127.0.0.1" in err, err[-600:]
+    assert "PREFLIGHT_OK" not in outs[0][0]

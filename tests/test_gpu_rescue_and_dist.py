@@ -177,6 +177,10 @@ def test_bench_config4_eight_ranks_on_one_device(gpu):  # noqa: F811
     out = _run_bench(["--gpus", "8", "--backend", "gloo", "--scaling", "strong", "--total", "1000000", "--workload", "pnp_n10_125k", "--no-transfer"], timeout=1500)
     col = out["config"]["collective"]
     assert out["n_gpus"] == 8 and out["scaling"] == "strong" and col["ranks"] == 8 and col["ranks_seen"] == 8, col
+    # the rendezvous and a tiny all_reduce / all_gather ran under the watchdog before anything else (cvxpnpl_amd.dist.init_with_preflight)
+    pf = col["preflight"]
+    assert pf["ranks_seen"] == 8 and pf["timeout_s"] == 60.0 and pf["all_reduce_ms"] > 0 and pf["all_gather_ms"] > 0, pf
+    assert all(x["own_ms_per_step"] > 0 for x in col["per_rank"]) and "exposed" in col["gather_ms_per_step"], col
     assert [x["rank"] for x in col["per_rank"]] == list(range(8)) and all(x["problems_per_step"] == 125000 for x in col["per_rank"])
     assert col["gather_check"]["all_ranks_ok"] and col["gather_check"]["records"] == 1000000 and col["gather_check"]["held_by"] == "every rank"
     g = col["gather_ms_per_step"]
@@ -216,3 +220,46 @@ def test_bench_config5_workload(gpu):  # noqa: F811
     assert f["last_frame"]["n_inliers"] >= f["last_frame"]["true_inliers"] - 2 and f["last_frame"]["rot_err_vs_gt_rad"] < 0.02, f
     assert f["fixed_subsets"]["best_hypothesis_inliers"] >= f["fixed_subsets"]["true_inliers"] - 2, f
     assert out["median_ms_per_step"] > 0 and out["transfer_inclusive"]["records_equal_device_run"], out.get("transfer_inclusive")
+
+
+def test_stream_wait_fails_closed(gpu):  # noqa: F811
+    """cvxpnpl_stream_wait_value (round 6): a wait whose value never arrives gives up after ~0.25 s and then HOLDS its stream until the host
+    has acknowledged the give-up -- nothing behind it runs before; cvxpnpl_stream_wait_gave_up reports it (1), clears the word and thereby
+    releases the stream.  A wait whose value arrives passes and reports 0.  The explicitly fail-open form lets its stream go on."""
+    import ctypes as C
+    import time
+
+    import torch
+
+    from cvxpnpl_amd import _lib
+
+    L = _lib.lib()
+    prod, cons = torch.cuda.Stream(gpu), torch.cuda.Stream(gpu)
+    flag = torch.zeros(2, dtype=torch.int64, device=gpu)
+    behind = torch.zeros(1, dtype=torch.int64, device=gpu)
+    torch.cuda.synchronize(gpu)
+    fp, cs, ps = C.c_void_p(flag.data_ptr()), C.c_void_p(cons.cuda_stream), C.c_void_p(prod.cuda_stream)
+    # 1. the value arrives: no give-up, the consumer goes on
+    assert L.cvxpnpl_stream_wait_value(fp, 1, cs) == 0
+    with torch.cuda.stream(cons):
+        behind.add_(1)
+    assert L.cvxpnpl_stream_write_value(fp, 1, ps) == 0
+    assert L.cvxpnpl_stream_wait_gave_up(fp, 1, cs) == 0
+    assert int(behind.item()) == 1 and int(flag[0].item()) == 1
+    # 2. the value never arrives: the stream is held beyond the give-up, until acknowledged
+    assert L.cvxpnpl_stream_wait_value(fp, 7, cs) == 0
+    with torch.cuda.stream(cons):
+        behind.add_(1)
+    time.sleep(1.0)                                   # (the wait gives up after ~0.25 s)
+    assert not cons.query()                           # still held: the kernel behind the wait has not run
+    t0 = time.time()
+    assert L.cvxpnpl_stream_wait_gave_up(fp, 1, cs) == 1   # told, cleared, released
+    cons.synchronize()
+    assert time.time() - t0 < 5.0 and int(behind.item()) == 2 and int(flag[1].item()) == 0
+    # 3. the explicitly fail-open form: gives up, marks the word, lets its stream go on
+    assert L.cvxpnpl_stream_wait_value_bounded(fp, 9, 1 << 12, cs) == 0
+    with torch.cuda.stream(cons):
+        behind.add_(1)
+    cons.synchronize()
+    assert int(behind.item()) == 3 and int(flag[1].item()) == 1
+    assert L.cvxpnpl_stream_wait_gave_up(fp, 1, cs) == 1 and L.cvxpnpl_stream_wait_gave_up(fp, 1, cs) == 0
