@@ -7,4 +7,4 @@ __version__ = "0.1.0"
 
 from ._lib import VARIANT_FULL, VARIANT_RC  # noqa: F401
 from .api import (BatchResult, assemble_batch, assemble_subsets, ipm_batch, pack_cost, pnl, pnl_batch, pnp, pnp_batch, pnpl, pnpl_batch, recover_multi,  # noqa: F401
-                  recover_multi_batch, recover_multi_device, sample_minimal_sets, score_hypotheses, solve_cost_batch, solve_relaxation, solve_relaxation_rc)
+                  recover_multi_batch, recover_multi_device, refit_update, sample_minimal_sets, score_hypotheses, select_best, solve_cost_batch, solve_relaxation, solve_relaxation_rc)

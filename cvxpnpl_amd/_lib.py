@@ -18,7 +18,7 @@ _ip = C.POINTER(C.c_int32)
 EXPORTS = (
     "cvxpnpl_default_opts", "cvxpnpl_opts_size", "cvxpnpl_solve_batch", "cvxpnpl_solve_cost_batch", "cvxpnpl_recover_multi", "cvxpnpl_recover_multi_batch", "cvxpnpl_recover_multi_device", "cvxpnpl_assemble_batch",
     "cvxpnpl_assemble_large_batch", "cvxpnpl_assemble_large_scratch_bytes",
-    "cvxpnpl_score_hypotheses", "cvxpnpl_sample_minimal_sets", "cvxpnpl_assemble_subsets", "cvxpnpl_pack_results", "cvxpnpl_stream_write_value", "cvxpnpl_stream_wait_value", "cvxpnpl_stream_wait_value_bounded", "cvxpnpl_stream_wait_gave_up", "cvxpnpl_synth_batch", "cvxpnpl_pose_errors", "cvxpnpl_disambiguate",
+    "cvxpnpl_score_hypotheses", "cvxpnpl_select_best", "cvxpnpl_refit_update", "cvxpnpl_sample_minimal_sets", "cvxpnpl_assemble_subsets", "cvxpnpl_pack_results", "cvxpnpl_stream_write_value", "cvxpnpl_stream_wait_value", "cvxpnpl_stream_wait_value_bounded", "cvxpnpl_stream_wait_gave_up", "cvxpnpl_synth_batch", "cvxpnpl_pose_errors", "cvxpnpl_disambiguate",
     "cvxpnpl_workspace_bytes", "cvxpnpl_set_workspace", "cvxpnpl_release_workspace", "cvxpnpl_calibration_copy", "cvxpnpl_ipm_batch",
     "cvxpnpl_event_create", "cvxpnpl_event_record", "cvxpnpl_event_elapsed_ms", "cvxpnpl_event_destroy",
     "cvxpnpl_last_error", "cvxpnpl_version", "cvxpnpl_device_count",
@@ -100,6 +100,13 @@ def lib():
     L.cvxpnpl_score_hypotheses.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int32,
                                            C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cvxpnpl_score_hypotheses.restype = C.c_int
+    if not os.environ.get("CVXPNPL_AMD_LIB") or hasattr(L, "cvxpnpl_select_best"):  # (an A/B library of an earlier round lacks them)
+        L.cvxpnpl_select_best.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                          C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cvxpnpl_select_best.restype = C.c_int
+        L.cvxpnpl_refit_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cvxpnpl_refit_update.restype = C.c_int
     L.cvxpnpl_sample_minimal_sets.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cvxpnpl_sample_minimal_sets.restype = C.c_int
     L.cvxpnpl_synth_batch.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -453,6 +453,40 @@ def score_hypotheses(R, t, K, pts_2d, pts_3d, thresh: float = 2.0, status=None, 
     return (count, mask) if want_mask else count
 
 
+def select_best(count, R, t, status, K, pts_2d, pts_3d, thresh: float = 2.0):
+    """The selection of a RANSAC frame in one launch (cvxpnpl_select_best): arg-max of the inlier counts `count` [H] (score_hypotheses) with the
+    lowest index winning a tie, the winner's pose, and its inlier mask over the scene.  Device tensors in, device tensors out, no
+    synchronisation: returns R [1,3,3], t [1,3], head [4] int32 = (status, inliers, index, certified hypotheses), mask [1,M] uint8."""
+    _require_gpu()
+    L = _lib.lib()
+    dev = R.device
+    H, M = R.shape[0], pts_3d.shape[0]
+    if H < 1:
+        raise ValueError("select_best needs at least one hypothesis")
+    with torch.cuda.device(dev):
+        oR = torch.empty((1, 3, 3), dtype=torch.float64, device=dev)
+        ot = torch.empty((1, 3), dtype=torch.float64, device=dev)
+        head = torch.empty((4,), dtype=torch.int32, device=dev)
+        mask = torch.empty((1, M), dtype=torch.uint8, device=dev)
+        rc = L.cvxpnpl_select_best(H, _ptr(count), _ptr(R), _ptr(t), _ptr(status), _ptr(K), M, _ptr(pts_2d), _ptr(pts_3d), float(thresh),
+                                   _ptr(oR), _ptr(ot), _ptr(head), _ptr(mask), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"cvxpnpl_select_best failed ({rc}): {_lib.last_error()}")
+    return oR, ot, head, mask
+
+
+def refit_update(fit: "BatchResult", fit_count, K, pts_2d, pts_3d, thresh, R, t, head, mask):
+    """cvxpnpl_refit_update: take the refitted pose `fit` (a one-problem BatchResult) -- pose, status, mask and inlier count together, in
+    place -- when it is usable and keeps at least head[1] inliers.  One launch, no synchronisation."""
+    L = _lib.lib()
+    dev = R.device
+    with torch.cuda.device(dev):
+        rc = L.cvxpnpl_refit_update(_ptr(fit.R), _ptr(fit.t), _ptr(fit.status), _ptr(fit_count), _ptr(K), pts_3d.shape[0], _ptr(pts_2d), _ptr(pts_3d),
+                                    float(thresh), _ptr(R), _ptr(t), _ptr(head), _ptr(mask), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"cvxpnpl_refit_update failed ({rc}): {_lib.last_error()}")
+
+
 def assemble_subsets(pts_2d, pts_3d, K, mask):
     """Constraint assembly for subsets of ONE scene (cvxpnpl_assemble_subsets): pts_2d [M,2], pts_3d [M,3], mask [B,M] (non-zero = taken, e.g.
     the mask of score_hypotheses) -> (B27 [B,27], Q45 [B,45], count [B] int32) on the device; feed solve_cost_batch.  The refit of a RANSAC

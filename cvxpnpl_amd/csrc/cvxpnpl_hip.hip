@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(64) assemble_kernel(BatchArgs a, double *Bout,
 
 // Assembly for subsets of ONE scene: problem b takes the correspondences m with mask[b][m] != 0 (the refit of a RANSAC consensus set:
 // the mask is what cvxs::score_kernel wrote, so that the size of the set never has to travel to the host).  One lane per problem; the
-// Gram sums are the ones of cvx::assemble, taken about the same kind of centre (median of the scene's first three points: any centre is
+// Gram sums are the ones of cvx::assemble, taken about the same kind of centre (median of the subset's first three points: any centre is
 // exact).  Fewer than three correspondences give a singular N^T N: NaN, as cvx::assemble reports it.
 __global__ void __launch_bounds__(64) assemble_subsets_kernel(int64_t batch, int n_corr, const double *s2, const double *s3, const uint8_t *mask, const double *K,
                                                               double *Bout, double *Qout, int32_t *count)
@@ -108,9 +108,19 @@ __global__ void __launch_bounds__(64) assemble_subsets_kernel(int64_t batch, int
     cvx::inv3(Kc, Ki, det);
     cvx::Gram g;
     cvx::gram_zero(g);
-    double c[3];
-    cvx::shift_centre(n_corr, s3, 0, nullptr, c);
+    // centre of the Gram sums: the median of the subset's OWN first three correspondences (round 5 took the scene's first three whether
+    // selected or not: a non-finite or far-away outlier among them spoilt every subset, also those that mask it out -- advisor)
     const uint8_t *mk = mask + b * n_corr;
+    double c[3] = {0.0, 0.0, 0.0}, first3[9];
+    int nf = 0;
+    for (int m = 0; m < n_corr && nf < 3; ++m)
+        if (mk[m]) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) // (static indices: the array stays in registers)
+                if (nf == k) { first3[3 * k] = s3[3 * m]; first3[3 * k + 1] = s3[3 * m + 1]; first3[3 * k + 2] = s3[3 * m + 2]; }
+            ++nf;
+        }
+    if (nf > 0) cvx::shift_centre(nf, first3, 0, nullptr, c);
     int n = 0;
     for (int m = 0; m < n_corr; ++m) {
         if (!mk[m]) continue;
@@ -817,6 +827,36 @@ int cvxpnpl_pack_results(int64_t batch, const double *d_R, const double *d_t, co
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err("pack_kernel launch", e);
     return 0;
+}
+
+int cvxpnpl_select_best(int64_t n_hyp, const int32_t *d_count, const double *d_R, const double *d_t, const int32_t *d_status, const double *d_K,
+                        int32_t n_corr, const double *d_pts_2d, const double *d_pts_3d, double thresh_px, double *d_out_R, double *d_out_t,
+                        int32_t *d_head, uint8_t *d_mask, void *stream)
+{
+    if (n_hyp < 1 || n_hyp > 0x7fffffffLL || n_corr < 0 || !d_count || !d_R || !d_t || !d_status || !d_K || !d_out_R || !d_out_t || !d_head ||
+        (n_corr > 0 && (!d_pts_2d || !d_pts_3d || !d_mask)) || !(thresh_px > 0.0)) {
+        snprintf(g_err, sizeof(g_err), "cvxpnpl_select_best: bad arguments");
+        return -1;
+    }
+    cvxs::SelectArgs a{n_hyp, d_count, d_R, d_t, d_status, d_K, n_corr, d_pts_2d, d_pts_3d, thresh_px, d_out_R, d_out_t, d_head, d_mask};
+    hipLaunchKernelGGL(cvxs::select_best_kernel, dim3(1), dim3(cvxs::SELECT_BLOCK), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : set_err("select_best_kernel launch", e);
+}
+
+int cvxpnpl_refit_update(const double *d_fit_R, const double *d_fit_t, const int32_t *d_fit_status, const int32_t *d_fit_count, const double *d_K,
+                         int32_t n_corr, const double *d_pts_2d, const double *d_pts_3d, double thresh_px, double *d_R, double *d_t, int32_t *d_head,
+                         uint8_t *d_mask, void *stream)
+{
+    if (n_corr < 0 || !d_fit_R || !d_fit_t || !d_fit_status || !d_fit_count || !d_K || !d_R || !d_t || !d_head ||
+        (n_corr > 0 && (!d_pts_2d || !d_pts_3d || !d_mask)) || !(thresh_px > 0.0)) {
+        snprintf(g_err, sizeof(g_err), "cvxpnpl_refit_update: bad arguments");
+        return -1;
+    }
+    cvxs::RefitArgs a{d_fit_R, d_fit_t, d_fit_status, d_fit_count, d_K, n_corr, d_pts_2d, d_pts_3d, thresh_px, d_R, d_t, d_head, d_mask};
+    hipLaunchKernelGGL(cvxs::refit_update_kernel, dim3(1), dim3(cvxs::SELECT_BLOCK), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : set_err("refit_update_kernel launch", e);
 }
 
 int cvxpnpl_score_hypotheses(int64_t n_hyp, const double *d_R, const double *d_t, const int32_t *d_status, uint32_t usable_mask,

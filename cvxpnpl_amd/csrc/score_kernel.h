@@ -147,4 +147,120 @@ __global__ void __launch_bounds__(256) sample_sets_kernel(SampleArgs a)
     }
 }
 
+// ---- the selection of a RANSAC frame (round 6): what ~40 small torch kernels did around the arg-max ----------------------------------
+// select_best_kernel: ONE block.  Arg-max of the inlier counts over all hypotheses with a deterministic tie-break (the LOWEST index among
+// the best counts -- torch.argmax's choice, whatever the launch geometry), the number of certified hypotheses on the way, then the
+// winner's pose, status and -- scored again against the scene by the block's lanes -- its inlier mask and count.
+// head: int32[4] = { status of the pose, inliers, index of the winning hypothesis, certified hypotheses } -- the frame's one read-back.
+constexpr int SELECT_BLOCK = 1024;
+struct SelectArgs {
+    int64_t n_hyp;
+    const int32_t *count;    // [n_hyp] (score_kernel)
+    const double *R, *t;     // [n_hyp][9], [n_hyp][3]
+    const int32_t *status;   // [n_hyp]
+    const double *K;         // [9]
+    int32_t n_corr;
+    const double *p2, *p3;   // scene
+    double thresh;
+    double *out_R, *out_t;   // [9], [3]
+    int32_t *head;           // [4]
+    uint8_t *mask;           // [n_corr]
+};
+// inliers of ONE pose over the scene, by the lanes of one block: writes mask (optional) and returns the count to every lane
+__device__ inline int block_score_pose(const double *R, const double *t, const double *K, int n_corr, const double *p2, const double *p3, double thresh,
+                                       uint8_t *mask, int *red /* LDS, blockDim.x / 64 + 1 ints */)
+{
+    double M[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) M[i * 4 + j] = K[i * 3] * R[j] + K[i * 3 + 1] * R[3 + j] + K[i * 3 + 2] * R[6 + j];
+        M[i * 4 + 3] = K[i * 3] * t[0] + K[i * 3 + 1] * t[1] + K[i * 3 + 2] * t[2];
+    }
+    const double th2 = thresh * thresh;
+    int cnt = 0;
+    for (int m = threadIdx.x; m < n_corr; m += blockDim.x) {
+        const double X = p3[3 * m], Y = p3[3 * m + 1], Z = p3[3 * m + 2];
+        const double u = M[0] * X + M[1] * Y + M[2] * Z + M[3], v = M[4] * X + M[5] * Y + M[6] * Z + M[7], w = M[8] * X + M[9] * Y + M[10] * Z + M[11];
+        const double depth = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+        const double du = u / w - p2[2 * m], dv = v / w - p2[2 * m + 1];
+        const bool in = depth > 0.0 && (du * du + dv * dv < th2); // (the arithmetic of score_kernel: the same mask, bit for bit)
+        cnt += in ? 1 : 0;
+        if (mask) mask[m] = in ? 1 : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    int tot = 0;
+    for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) tot += red[wv];
+    return tot;
+}
+__global__ void __launch_bounds__(SELECT_BLOCK) select_best_kernel(SelectArgs a)
+{
+    __shared__ int red[SELECT_BLOCK / 64 + 1];
+    __shared__ long long best_w[SELECT_BLOCK / 64];
+    __shared__ int cert_w[SELECT_BLOCK / 64];
+    // (count, index) packed so that a plain max picks the highest count and, among equals, the LOWEST index
+    long long best = -1;
+    int cert = 0;
+    for (int64_t h = threadIdx.x; h < a.n_hyp; h += SELECT_BLOCK) {
+        const long long key = ((long long)a.count[h] << 32) | (long long)(0x7fffffffLL - h);
+        best = key > best ? key : best;
+        cert += a.status[h] == 0 ? 1 : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const long long o = __shfl_down(best, off);
+        best = o > best ? o : best;
+        cert += __shfl_down(cert, off);
+    }
+    if ((threadIdx.x & 63) == 0) { best_w[threadIdx.x >> 6] = best; cert_w[threadIdx.x >> 6] = cert; }
+    __syncthreads();
+    best = best_w[0]; cert = cert_w[0];
+    for (int wv = 1; wv < SELECT_BLOCK / 64; ++wv) { best = best_w[wv] > best ? best_w[wv] : best; cert += cert_w[wv]; }
+    const int64_t hb = a.n_hyp > 0 ? 0x7fffffffLL - (best & 0xffffffffLL) : 0;
+    double R[9], t[3], K[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { R[i] = a.R[hb * 9 + i]; K[i] = a.K[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = a.t[hb * 3 + i];
+    const int n_inl = block_score_pose(R, t, K, a.n_corr, a.p2, a.p3, a.thresh, a.mask, red);
+    if (threadIdx.x < 9) a.out_R[threadIdx.x] = R[threadIdx.x];
+    if (threadIdx.x < 3) a.out_t[threadIdx.x] = t[threadIdx.x];
+    if (threadIdx.x == 0) { a.head[0] = a.status[hb]; a.head[1] = n_inl; a.head[2] = (int32_t)hb; a.head[3] = cert; }
+}
+// refit_update_kernel: ONE block.  The refitted pose of the consensus set (assemble_subsets + solve at the cost seam) is scored against the
+// scene and TAKEN -- pose, status, mask and count together -- when it is usable (status 0 or 2, at least four correspondences in its set)
+// and keeps at least the consensus it was fitted to; otherwise everything stays.
+struct RefitArgs {
+    const double *fit_R, *fit_t;   // [9], [3]
+    const int32_t *fit_status;     // [1]
+    const int32_t *fit_cnt;        // [1] size of the set it was fitted to
+    const double *K;
+    int32_t n_corr;
+    const double *p2, *p3;
+    double thresh;
+    double *io_R, *io_t;           // [9], [3]
+    int32_t *head;                 // [4] (select_best_kernel)
+    uint8_t *mask;                 // [n_corr]
+};
+__global__ void __launch_bounds__(SELECT_BLOCK) refit_update_kernel(RefitArgs a)
+{
+    __shared__ int red[SELECT_BLOCK / 64 + 1];
+    double R[9], t[3], K[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { R[i] = a.fit_R[i]; K[i] = a.K[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = a.fit_t[i];
+    const int st = a.fit_status[0];
+    const int n_new = block_score_pose(R, t, K, a.n_corr, a.p2, a.p3, a.thresh, nullptr, red);
+    const bool take = (st == 0 || st == 2) && a.fit_cnt[0] >= 4 && n_new >= a.head[1]; // (block-uniform)
+    __syncthreads();
+    if (!take) return;
+    (void)block_score_pose(R, t, K, a.n_corr, a.p2, a.p3, a.thresh, a.mask, red); // pose and mask change together
+    if (threadIdx.x < 9) a.io_R[threadIdx.x] = R[threadIdx.x];
+    if (threadIdx.x < 3) a.io_t[threadIdx.x] = t[threadIdx.x];
+    if (threadIdx.x == 0) { a.head[0] = st; a.head[1] = n_new; }
+}
+
 } // namespace cvxs

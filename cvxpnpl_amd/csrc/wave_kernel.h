@@ -897,7 +897,10 @@ __device__ __forceinline__ bool solve_pass(const WaveArgs &a, const cvx::Opts &o
         it = (int)rd(RS_IT);
         if (post_ipm) { it = -it; total_sweeps = a.work ? a.work[2 * b + 1] : 0; }
         next_check = it + 1 > o.first_check ? it + 1 : o.first_check;
-        if (resume_full) { // the attempt schedule of the first phase goes on (an attempt costs two to three iterations)
+#ifndef CVXW_RESUME_EARLY_CHECK
+#define CVXW_RESUME_EARLY_CHECK 0
+#endif
+        if (resume_full && !(CVXW_RESUME_EARLY_CHECK && CVX_DUAL_REFINE_COMPILED && o.dual_refine && a.n_p + a.n_l >= 6)) { // the attempt schedule of the first phase goes on (an attempt costs two to three iterations)
             const int nc = (int)rd(RS_NC);
             next_check = nc > next_check ? nc : next_check;
         }

@@ -4,13 +4,13 @@ The reference has no RANSAC; this is the natural consumer of tens of thousands o
 hypotheses per frame: sample 4-subsets, solve them all in one launch, score every hypothesis by
 reprojection inliers over the whole scene, refit the best consensus set (assembled on the device from scene + inlier mask,
 solved at the cost seam: no host round trip inside a frame).  Sampling, the solves and the scoring are the HIP path (cvxpnpl_sample_minimal_sets, cvxpnpl_solve_batch,
-cvxpnpl_score_hypotheses, cvxpnpl_assemble_subsets, cvxpnpl_solve_cost_batch); torch takes the arg-max.
+cvxpnpl_score_hypotheses, cvxpnpl_select_best, cvxpnpl_assemble_subsets, cvxpnpl_solve_cost_batch, cvxpnpl_refit_update): no torch kernel in a frame.
 """
 from typing import Optional
 
 import torch
 
-from .api import assemble_subsets, pnp_batch, sample_minimal_sets, score_hypotheses, solve_cost_batch
+from .api import assemble_subsets, pnp_batch, refit_update, sample_minimal_sets, score_hypotheses, select_best, solve_cost_batch
 
 
 def reprojection_inliers(R: torch.Tensor, t: torch.Tensor, K: torch.Tensor, pts_3d: torch.Tensor, pts_2d: torch.Tensor,
@@ -47,28 +47,17 @@ def ransac_pnp(pts_2d, pts_3d, K, n_hyp: int = 4096, thresh: float = 2.0, max_it
     x4, X4 = sample_minimal_sets(x, X, n_hyp, 4, seed)
     res = pnp_batch(x4, X4, Kd, eps=eps, max_iters=max_iters)
     score = score_hypotheses(res.R, res.t, Kd, x, X, thresh, status=res.status, usable=(0, 2))
-    # From here on everything stays on the device until the one read-back at the end (round 5): the consensus set of the best hypothesis
-    # is a MASK (cvxpnpl_score_hypotheses), the refit assembles straight from scene + mask (cvxpnpl_assemble_subsets -- the size of the
-    # set, which used to be the N of a second cvxpnpl_solve_batch call and so a host argument, never leaves the device) and solves at the
-    # cost seam; the refit's pose is taken (torch.where) when it is usable and keeps at least the consensus it was fitted to.
-    best = torch.argmax(score).reshape(1)
-    R, t = res.R.index_select(0, best), res.t.index_select(0, best)          # [1,3,3], [1,3]
-    status = res.status.index_select(0, best).to(torch.int64)               # [1]
-    n_inl, mask = score_hypotheses(R, t, Kd, x, X, thresh, want_mask=True)   # [1], [1,M]
-    n_inl = n_inl.to(torch.int64)
+    # From here on everything stays on the device until the one read-back at the end, and (round 6) nothing of it is a torch kernel:
+    # cvxpnpl_select_best takes the arg-max (lowest index on a tie), gathers the winner's pose and scores it for its inlier MASK; the refit
+    # assembles straight from scene + mask (cvxpnpl_assemble_subsets -- the size of the set never leaves the device), solves at the cost
+    # seam, and cvxpnpl_refit_update takes the refitted pose, with its own mask and count, when it is usable and keeps at least the
+    # consensus it was fitted to.  (Round 5: ~40 small torch kernels around torch.argmax / torch.where, 0.35 ms of a 2.2 ms frame.)
+    R, t, head, mask = select_best(score, res.R, res.t, res.status, Kd, x, X, thresh)
     if refit:
         for _ in range(max(1, int(refit_rounds))):  # refit on the consensus set (a second round re-fits the set the first one found)
             Bt, Qt, cnt = assemble_subsets(x, X, Kd, mask)
             fit = solve_cost_batch(Qt, Bt, eps=1e-9, max_iters=2500, device=device)
-            n_new, mask_new = score_hypotheses(fit.R, fit.t, Kd, x, X, thresh, want_mask=True)
-            n_new = n_new.to(torch.int64)
-            st_new = fit.status.to(torch.int64)
-            usable = ((st_new == 0) | (st_new == 2)) & (cnt.to(torch.int64) >= 4)
-            take = usable & (n_new >= n_inl)          # (the refit of the same set is the better pose for it; a smaller set is not taken)
-            R = torch.where(take[:, None, None], fit.R, R)
-            t = torch.where(take[:, None], fit.t, t)
-            status = torch.where(take, st_new, status)
-            mask = torch.where(take[:, None], mask_new, mask)   # pose and mask change together: on a tie the mask is the refit pose's own
-            n_inl = torch.where(take, n_new, n_inl)
-    head = torch.stack([status[0], n_inl[0], (res.status == 0).sum()]).cpu()   # the frame's one synchronisation
-    return {"R": R[0], "t": t[0], "inliers": mask[0].bool(), "n_inliers": int(head[1]), "status": int(head[0]), "n_certified": int(head[2]), "n_hyp": n_hyp}
+            refit_update(fit, cnt, Kd, x, X, thresh, R, t, head, mask)
+    h = head.cpu()   # the frame's one synchronisation
+    return {"R": R[0], "t": t[0], "inliers": mask[0].bool(), "n_inliers": int(h[1]), "status": int(h[0]), "n_certified": int(h[3]), "n_hyp": n_hyp,
+            "best_index": int(h[2])}

@@ -294,6 +294,22 @@ int cvxpnpl_stream_wait_gave_up(uint64_t *d_flag, int32_t clear, void *stream);
  * reprojection K (R P + t) lies within thresh_px of the measured pixel.  d_count [n_hyp] inlier counts;
  * d_mask [n_hyp][n_corr] (0/1) or NULL.  Non-finite poses score 0.  Returns 0, -1 for bad arguments.
  */
+/* The selection of a RANSAC frame on the device (round 6; replaces ~40 small torch kernels around an arg-max).  DEVICE pointers, one launch of
+ * one block each.
+ * cvxpnpl_select_best: arg-max of d_count [n_hyp] (cvxpnpl_score_hypotheses) with a deterministic tie-break -- the lowest index among the
+ *   best counts --, the winner's pose into d_out_R [9] / d_out_t [3], its inlier mask over the scene into d_mask [n_corr] (0/1, the
+ *   arithmetic of cvxpnpl_score_hypotheses), and d_head [4] = { status of the winner, its inliers, its index, number of hypotheses with
+ *   status CERTIFIED }: the one read-back a frame needs.  n_hyp >= 1.
+ * cvxpnpl_refit_update: the pose refitted to the consensus set (cvxpnpl_assemble_subsets on d_mask, cvxpnpl_solve_cost_batch; d_fit_*: its
+ *   R [9], t [3], status [1], d_fit_count [1] = size of the set) is scored against the scene and replaces pose, mask and d_head[0..1] TOGETHER
+ *   when it is usable (status 0 or 2, at least four correspondences) and has at least d_head[1] inliers; otherwise nothing changes.
+ * Return 0, -1 for bad arguments. */
+int cvxpnpl_select_best(int64_t n_hyp, const int32_t *d_count, const double *d_R, const double *d_t, const int32_t *d_status, const double *d_K,
+                        int32_t n_corr, const double *d_pts_2d, const double *d_pts_3d, double thresh_px, double *d_out_R, double *d_out_t,
+                        int32_t *d_head, uint8_t *d_mask, void *stream);
+int cvxpnpl_refit_update(const double *d_fit_R, const double *d_fit_t, const int32_t *d_fit_status, const int32_t *d_fit_count, const double *d_K,
+                         int32_t n_corr, const double *d_pts_2d, const double *d_pts_3d, double thresh_px, double *d_R, double *d_t, int32_t *d_head,
+                         uint8_t *d_mask, void *stream);
 int cvxpnpl_score_hypotheses(int64_t n_hyp, const double *d_R, const double *d_t, const int32_t *d_status, uint32_t usable_mask,
                              const double *d_K, int32_t n_corr, const double *d_pts_2d, const double *d_pts_3d, double thresh_px,
                              int32_t *d_count, uint8_t *d_mask, void *stream);

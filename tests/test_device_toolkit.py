@@ -207,3 +207,79 @@ def test_subset_assembly_equals_the_assembly_of_the_gathered_subset():
     L = __import__("cvxpnpl_amd._lib", fromlist=["lib"]).lib()
     assert L.cvxpnpl_assemble_subsets(0, 60, None, None, None, None, None, None, None, None) == 0
     assert L.cvxpnpl_assemble_subsets(4, 0, None, None, None, None, None, None, None, None) == -1
+
+
+@pytest.mark.gpu
+def test_subset_assembly_ignores_what_the_mask_leaves_out():
+    """advisor (round 5): the Gram sums' centre is taken from the SUBSET's own first correspondences -- a non-finite or far-away outlier among
+    the scene's first three points no longer spoils the subsets that mask it out"""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import cvxpnpl_amd as ca
+    from cvxpnpl_amd import synth
+
+    d = synth.make_ransac(1, n_corr=40, outlier_frac=0.0, sigma=0.3, seed=4)
+    x, X = d["scene_2d"].copy(), d["scene_3d"].copy()
+    mask = np.ones((2, 40), np.uint8)
+    mask[:, 1] = 0                                  # correspondence 1 is masked out of both subsets ...
+    clean = ca.assemble_subsets(torch.as_tensor(x, device="cuda"), torch.as_tensor(X, device="cuda"), torch.as_tensor(d["K"], device="cuda"),
+                                torch.as_tensor(mask, device="cuda"))
+    X[1] = [np.nan, 1e9, -1e9]                      # ... and is rubbish
+    x[1] = [np.inf, 0.0]
+    dirty = ca.assemble_subsets(torch.as_tensor(x, device="cuda"), torch.as_tensor(X, device="cuda"), torch.as_tensor(d["K"], device="cuda"),
+                                torch.as_tensor(mask, device="cuda"))
+    assert torch.equal(clean[0], dirty[0]) and torch.equal(clean[1], dirty[1]) and torch.isfinite(dirty[1]).all()
+
+
+@pytest.mark.gpu
+def test_frame_selection_kernels_against_torch():
+    """cvxpnpl_select_best / cvxpnpl_refit_update (round 6) against the torch ops they replace: arg-max with the lowest index on a tie, the
+    winner's pose / status / mask / count, the number of certified hypotheses; the refit is taken -- pose, mask and count together -- exactly
+    when it is usable and keeps the consensus."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import cvxpnpl_amd as ca
+    from cvxpnpl_amd import synth
+
+    dev = torch.device("cuda:0")
+    d = synth.make_ransac(6000, n_corr=100, outlier_frac=0.3, sigma=0.5, seed=46)
+    x, X, K = (torch.as_tensor(d[k], device=dev) for k in ("scene_2d", "scene_3d", "K"))
+    res = ca.pnp_batch(torch.as_tensor(d["pts_2d"], device=dev), torch.as_tensor(d["pts_3d"], device=dev), K, eps=1e-6, max_iters=100)
+    score = ca.score_hypotheses(res.R, res.t, K, x, X, 2.0, status=res.status, usable=(0, 2))
+    for trial in range(3):
+        sc = score.clone()
+        if trial == 1:      # a tie between the best hypotheses: the lowest index wins
+            top = int(sc.max())
+            idx = torch.nonzero(sc >= top - 1).flatten()
+            sc[idx] = top
+        if trial == 2:      # the best hypothesis is the last one
+            sc[-1] = int(sc.max()) + 1
+        R, t, head, mask = ca.select_best(sc, res.R, res.t, res.status, K, x, X, 2.0)
+        b = int(torch.argmax(sc))
+        if trial == 1:
+            b = int(torch.nonzero(sc == sc.max()).flatten()[0])
+        h = head.cpu().tolist()
+        cnt1, mask1 = ca.score_hypotheses(res.R[b:b + 1], res.t[b:b + 1], K, x, X, 2.0, want_mask=True)
+        assert h[2] == b and h[0] == int(res.status[b]) and h[1] == int(cnt1[0]) and h[3] == int((res.status == 0).sum())
+        assert torch.equal(R[0], res.R[b]) and torch.equal(t[0], res.t[b]) and torch.equal(mask, mask1)
+    # refit: taken when usable and no smaller
+    R, t, head, mask = ca.select_best(score, res.R, res.t, res.status, K, x, X, 2.0)
+    Bt, Qt, cnt = ca.assemble_subsets(x, X, K, mask)
+    fit = ca.solve_cost_batch(Qt, Bt)
+    n_new, mask_new = ca.score_hypotheses(fit.R, fit.t, K, x, X, 2.0, want_mask=True)
+    before = (R.clone(), t.clone(), head.clone(), mask.clone())
+    ca.refit_update(fit, cnt, K, x, X, 2.0, R, t, head, mask)
+    take = int(fit.status[0]) in (0, 2) and int(cnt[0]) >= 4 and int(n_new[0]) >= int(before[2][1])
+    assert take, "the refit of the consensus set of this scene is expected to be taken"
+    assert torch.equal(R, fit.R) and torch.equal(t, fit.t) and torch.equal(mask, mask_new) and head.cpu().tolist()[:2] == [int(fit.status[0]), int(n_new[0])]
+    # ... and refused when it would lose inliers (a pose fitted to a corrupted set)
+    bad = ca.solve_cost_batch(Qt.roll(1, 1), Bt)
+    n_bad = ca.score_hypotheses(bad.R, bad.t, K, x, X, 2.0)
+    keep = (R.clone(), t.clone(), head.clone(), mask.clone())
+    ca.refit_update(bad, cnt, K, x, X, 2.0, R, t, head, mask)
+    if not (int(bad.status[0]) in (0, 2) and int(n_bad[0]) >= int(keep[2][1])):
+        assert torch.equal(R, keep[0]) and torch.equal(t, keep[1]) and torch.equal(head, keep[2]) and torch.equal(mask, keep[3])
