@@ -745,6 +745,7 @@ def main():
         "dtype": ("f64" if opts.f32_sweeps_until == 0 else "f64 (f32 Jacobi sweeps)"),  # what the timed region ran; the other mode beside it
         "data": "synthetic",
         "config": {"workload": args.workload, "n_points": n_p, "n_lines": n_l, "problems_per_gpu_per_step": batch,
+                   "layout_effective": {0: None, 1: "lane-hybrid", 2: "wave", 3: "quad-hybrid", 4: "penta"}.get(int(L.cvxpnpl_last_layout()) if hasattr(L, "cvxpnpl_last_layout") else 0),
                    "pixel_noise_sigma": sigma, "eps": opts.eps, "max_iters": opts.max_iters,
                    "precision": ("f64 throughout, as the reference (opts.f32_sweeps_until = 0); value_mixed is the same run with the library's default "
                                  "(single-precision Jacobi sweeps while a solve is younger than 64 iterations)" if opts.f32_sweeps_until == 0 else

@@ -21,7 +21,7 @@ EXPORTS = (
     "cvxpnpl_score_hypotheses", "cvxpnpl_select_best", "cvxpnpl_refit_update", "cvxpnpl_sample_minimal_sets", "cvxpnpl_assemble_subsets", "cvxpnpl_pack_results", "cvxpnpl_stream_write_value", "cvxpnpl_stream_wait_value", "cvxpnpl_stream_wait_value_bounded", "cvxpnpl_stream_wait_gave_up", "cvxpnpl_synth_batch", "cvxpnpl_pose_errors", "cvxpnpl_disambiguate",
     "cvxpnpl_workspace_bytes", "cvxpnpl_set_workspace", "cvxpnpl_release_workspace", "cvxpnpl_calibration_copy", "cvxpnpl_ipm_batch",
     "cvxpnpl_event_create", "cvxpnpl_event_record", "cvxpnpl_event_elapsed_ms", "cvxpnpl_event_destroy",
-    "cvxpnpl_last_error", "cvxpnpl_version", "cvxpnpl_device_count",
+    "cvxpnpl_last_error", "cvxpnpl_last_layout", "cvxpnpl_version", "cvxpnpl_device_count",
 )
 
 VARIANT_FULL, VARIANT_RC = 0, 1

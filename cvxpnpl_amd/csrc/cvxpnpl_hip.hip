@@ -149,6 +149,7 @@ struct Workspace { void *ptr = nullptr; size_t bytes = 0; int64_t cap = 0; size_
 std::mutex g_ws_mutex;
 std::map<std::pair<int, void *>, Workspace> g_ws;
 thread_local char g_err[512] = "";
+thread_local int g_last_layout = 0; // the layout the last solve of this thread ran (cvxpnpl_last_layout)
 
 // One solve is two or three dependent launches that share the queue and the parked-iterate buffer of their (device, stream):
 // host threads calling on the SAME stream (ctypes drops the GIL; torch's default stream is shared by every thread) must not
@@ -327,6 +328,8 @@ void cvxpnpl_default_opts(cvxpnpl_opts_t *opts)
 
 size_t cvxpnpl_opts_size(void) { return sizeof(cvxpnpl_opts_t); }
 
+int cvxpnpl_last_layout(void) { return g_last_layout; }
+
 static int check_args(int64_t batch, int32_t n_p, const double *p2, const double *p3, int32_t n_l, const double *l2,
                       const double *l3, const double *K)
 {
@@ -432,6 +435,26 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     const bool penta_req = layout == CVXPNPL_LAYOUT_PENTA;
     const bool penta = penta_req && !(o.f32_sweeps_until < quad_iters); // (float64 sweeps: built for the sixteen-lane geometry only)
     if (layout == 9 || layout == 11 || layout == 12 || layout == 13 || penta_req) layout = CVXPNPL_LAYOUT_QUAD; // (9: experiment (tools/README.md): quad iterations only, 3 waves/SIMD, solve_quad_kernel<1>)
+    // The register-budgeted lane kernel (lane_core.h) covers the schedule of the defaults: one attempt, right at the hand-off point, warm-started
+    // eigen-solves.  Any other combination of options (first_check != lane_iters, warm_start = 0) used to fall through to the general scalar
+    // core on lanes (solve_lane_kernel: 1 008-1 014 spilled registers, 2.2-2.7 KB of scratch per lane, a third of the speed) without saying
+    // so; round 5 sent such a request to the wave-per-problem layout -- one problem per wavefront, also at 125 000 problems, and with the
+    // attempt schedule already derived for the lane layout (advisor).  Now the layout is settled HERE, before anything is derived from it:
+    // a lane request the budgeted kernel cannot serve runs the next-best schedule for its size (quad from 2 560 problems, wave below), the
+    // first attempt then follows THAT layout's default, and cvxpnpl_last_layout() says what ran.
+    int lane_iters = opts ? opts->lane_iters : -1;
+    {
+        const int fc_lane = o.first_check > 0 ? o.first_check : 6;
+        if (lane_iters <= 0) lane_iters = fc_lane;
+        if (lane_iters > 6) lane_iters = 6; // (see the lane branch below)
+#ifndef CVXPNPL_EXPERIMENTS
+        const bool budgeted = !lane_general && fc_lane == lane_iters && lane_iters >= 2 && o.warm_start != 0;
+        if (layout == CVXPNPL_LAYOUT_LANE && !budgeted) {
+            layout = batch >= 2560 ? CVXPNPL_LAYOUT_QUAD : CVXPNPL_LAYOUT_WAVE;
+            quad_iters = 7; // (the caller's lane_iters was meant for the lane phase)
+        }
+#endif
+    }
     if (layout == CVXPNPL_LAYOUT_QUAD && !(quad_iters >= 1 && o.max_iters > quad_iters)) layout = CVXPNPL_LAYOUT_WAVE;
     // (rc with float64 sweeps: solve_quad_kernel<0, 2, 16, true, VAR_RC> since round 5 -- until then such a request ran the wave layout)
     // First certificate attempt (0 = by layout): after 5 iterations 94 % of N = 10 problems certify, after 6 99 %.  In the lane-hybrid
@@ -468,18 +491,9 @@ static int launch_solve(const BatchArgs &a, const cvxpnpl_opts_t *opts, void *st
     const bool rescue = o.rescue_from > 0 && o.max_iters > o.rescue_from;
     // ONE workspace view per solve, fetched after the layout is settled and with the stride of the schedule that will run: a second
     // fetch with a larger stride may free and reallocate the buffer, and queue pointers taken from the first would dangle
-    int lane_iters = opts ? opts->lane_iters : -1;
-    if (lane_iters <= 0) lane_iters = o.first_check;
-    if (lane_iters > 6) lane_iters = 6; // (see the lane branch below)
-    // The register-budgeted lane kernel (lane_core.h) covers the schedule of the defaults: one attempt, right at the hand-off point, warm-started
-    // eigen-solves.  Any other combination of options (first_check != lane_iters, warm_start = 0) used to fall through to the general scalar
-    // core on lanes (solve_lane_kernel: 1 008-1 014 spilled registers, 2.2-2.7 KB of scratch per lane, a third of the speed) without saying
-    // so; since round 5 such a request runs the wave-per-problem layout, which honours every option, and the general lane kernel is
-    // compiled into experiment builds only (layout 10).
+    // (lane_iters and the budgeted / not budgeted decision: above, where the layout is settled)
     const bool lane_budgeted = !lane_general && o.first_check == lane_iters && lane_iters >= 2 && o.warm_start != 0;
-#ifndef CVXPNPL_EXPERIMENTS
-    if (layout == CVXPNPL_LAYOUT_LANE && !lane_budgeted) layout = CVXPNPL_LAYOUT_WAVE;
-#endif
+    g_last_layout = (layout == CVXPNPL_LAYOUT_QUAD && penta) ? CVXPNPL_LAYOUT_PENTA : layout;
     const bool lane_hybrid = layout == CVXPNPL_LAYOUT_LANE && o.max_iters > lane_iters;
     // The interior-point path comes in two builds.  Fused (cvxw::rescue_wave_kernel: the solve compiled into a resume kernel, one launch
     // behind the first kernel) where it is a safety net -- seven correspondences and more: its queue is empty in nearly every launch and

@@ -21,6 +21,7 @@
 #include "solver_core.h"
 
 namespace cvx {
+inline namespace CVX_UNIT_TAG {
 
 constexpr int IPM_M = 21;
 // Independent rows of the constraint set: 21 of the reference's 22 (cvxpnpl.py:387-451), or -- VAR_RC, the ablation of
@@ -360,4 +361,5 @@ CVX_HD void ipm_problem(const double *Q9, const double *B, const Opts &o, Soluti
     }
 }
 
+} // inline namespace CVX_UNIT_TAG
 } // namespace cvx

@@ -19,6 +19,7 @@
 #include "solver_core.h"
 
 namespace cvxl {
+inline namespace CVX_UNIT_TAG {
 
 using namespace cvx;
 
@@ -562,4 +563,5 @@ CVX_HD void lane_phase(const ProblemView &pv, const Opts &o, Solution &sol, doub
     }
 }
 
+} // inline namespace CVX_UNIT_TAG
 } // namespace cvxl

@@ -4,8 +4,8 @@
 // end of round 5 -- two / one float64 operations fewer per call, which the quad and wave-per-problem kernels turn into 1-3 % -- and the same change,
 // which does not alter the instruction count of THIS kernel (14 376 -> 14 372), moved its register allocation (scratch 84 -> 184 B / 520 -> 600 B per
 // lane) and cost the lane-layout launches 0.2-2 % (profiles/r05/rsq_c3_ab.txt).  Built with CVX_REFINE_NEWTON2 this unit keeps the two-Newton
-// sequences and with them the allocation it had.  Device code of the two units never meets (no relocatable device code); the host sides of the
-// shared inline functions are identical.
+// sequences and with them the allocation it had.  The shared headers put their definitions into an inline namespace named after the macro
+// (solver_core.h: CVX_UNIT_TAG), so the two units' versions of the same inline function are different symbols.
 #define CVX_REFINE_NEWTON2
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -8,6 +8,7 @@
 #include "solver_core.h"
 
 namespace cvx {
+inline namespace CVX_UNIT_TAG {
 
 struct ProblemView {
     int n_p, n_l;
@@ -94,4 +95,5 @@ CVX_HD void solve_problem(const ProblemView &v, const Opts &o, Solution &sol, do
     if (!ok) { CVX_UNROLL for (int i = 0; i < 3; ++i) sol.t[i] = NAN; }
 }
 
+} // inline namespace CVX_UNIT_TAG
 } // namespace cvx

@@ -41,7 +41,17 @@
 #define CVX_UNROLL
 #endif
 
+// One definition per translation unit.  csrc/lane_kernel.hip compiles these headers with CVX_REFINE_NEWTON2: other bodies of rcp / rsqrt_ /
+// jacobi_cs_dl -- and therefore of every inline function that inlines them.  The inline namespace gives the two sets of definitions
+// different (mangled) names, so that linking both units into one library is no violation of the one-definition rule whatever the build
+// does later (-fgpu-rdc, LTO, a host-visible difference); `cvx::name` resolves as before.  (advisor, round 5)
+#if defined(CVX_REFINE_NEWTON2)
+#define CVX_UNIT_TAG unit_newton2
+#else
+#define CVX_UNIT_TAG unit_c3
+#endif
 namespace cvx {
+// (plain data first -- the types that cross between the translation units, e.g. in cvxb::launch_lane2's signature, are the same type in both)
 
 enum Status : int {
     ST_CERTIFIED = 0,   // rank-1, certified globally optimal (gap <= eps)
@@ -103,6 +113,7 @@ constexpr int DUAL_REFINE_ATTEMPTS = 3;     // ... for three attempts: a dual it
 constexpr int DUAL_RETRY_ATTEMPTS = 10; // ... in the first this many attempts that may use them: a problem they have not rescued by then is not
                                         // one they rescue (same iteration counts with 6 / 10 / 16 / no limit on four workloads), and its long
                                         // chain stops paying for them (N = 8, 125 k problems, slowest 99 iterations: 160.4 -> 162.6 M poses/s)
+inline namespace CVX_UNIT_TAG { // (functions from here on: one set per translation unit, see above)
 // Sweeps the eigen-solve of iteration `it` (2, 3, ...: iteration 1 needs none) may take in the first phases of the hybrid schedules,
 // where a wavefront runs the MAXIMUM over its problems (64 in the lane phase, 4 in the quad phase): the first eigen-solve of a solve
 // takes 3-4 sweeps, the later ones 1-2 on average but 2-3 at wavefront level (measured, 200 wavefronts of 64 N = 10 problems: mean per
@@ -1862,4 +1873,5 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
     }
 }
 
+} // inline namespace CVX_UNIT_TAG
 } // namespace cvx

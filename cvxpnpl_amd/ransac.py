@@ -21,7 +21,7 @@ def reprojection_inliers(R: torch.Tensor, t: torch.Tensor, K: torch.Tensor, pts_
 
 
 def ransac_pnp(pts_2d, pts_3d, K, n_hyp: int = 4096, thresh: float = 2.0, max_iters: int = 100, eps: float = 1e-6,
-               seed: Optional[int] = 0, refit: bool = True, device=None, refit_rounds: int = 1):
+               seed: Optional[int] = 0, refit: bool = True, device=None, refit_rounds: int = 1, **solver_opts):
     """Robust PnP for one scene with outliers.
 
     pts_2d [M,2], pts_3d [M,3] (numpy or torch), K [3,3].  Returns dict with R [3,3], t [3],
@@ -45,7 +45,7 @@ def ransac_pnp(pts_2d, pts_3d, K, n_hyp: int = 4096, thresh: float = 2.0, max_it
     if seed is None:
         seed = int(torch.randint(0, 2**31 - 1, (1,)).item())
     x4, X4 = sample_minimal_sets(x, X, n_hyp, 4, seed)
-    res = pnp_batch(x4, X4, Kd, eps=eps, max_iters=max_iters)
+    res = pnp_batch(x4, X4, Kd, eps=eps, max_iters=max_iters, **solver_opts)  # (solver_opts: e.g. f32_sweeps_until=0, every sweep in float64)
     score = score_hypotheses(res.R, res.t, Kd, x, X, thresh, status=res.status, usable=(0, 2))
     # From here on everything stays on the device until the one read-back at the end, and (round 6) nothing of it is a torch kernel:
     # cvxpnpl_select_best takes the arg-max (lowest index on a tie), gathers the winner's pose and scores it for its inlier MASK; the refit

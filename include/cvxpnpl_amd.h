@@ -138,6 +138,10 @@ typedef struct {
 
 void cvxpnpl_default_opts(cvxpnpl_opts_t *opts);
 size_t cvxpnpl_opts_size(void); /* sizeof(cvxpnpl_opts_t) in this build of the library (see struct_size) */
+/* The layout (CVXPNPL_LAYOUT_LANE ... _PENTA) the calling thread's last cvxpnpl_solve_batch / cvxpnpl_solve_cost_batch actually ran: AUTO resolves by
+   launch size, and a request the chosen kernels cannot serve with the given options (e.g. LANE with first_check != lane_iters or warm_start = 0,
+   PENTA with float64 sweeps) runs the next-best schedule for its size -- this says which.  0 before the first solve. */
+int cvxpnpl_last_layout(void);
 
 /*
  * Solve `batch` independent problems, each with n_p point and n_l line correspondences

@@ -132,6 +132,30 @@ def test_penta_request_with_float64_sweeps_runs_the_quad_geometry(gpu):  # noqa:
         assert np.array_equal(np.nan_to_num(a["R"]), np.nan_to_num(b["R"])) and np.array_equal(np.nan_to_num(a["t"]), np.nan_to_num(b["t"]))
 
 
+def test_a_lane_request_the_lane_kernel_cannot_serve_runs_the_next_best_schedule(gpu):  # noqa: F811
+    """Round-5 advisor finding: a LANE request with options the register-budgeted lane kernel does not cover (lane_iters != first_check,
+    warm_start = 0) used to run the wave layout -- one problem per wavefront also at 30 000 problems -- with the attempt schedule of the
+    lane layout, and nothing said so.  The layout is now settled before anything is derived from it: quad from 2 560 problems, wave below,
+    and cvxpnpl_last_layout() reports what ran."""
+    from cvxpnpl_amd import _lib, synth
+
+    L = _lib.lib()
+    d = synth.make_pnpl(30000, 10, 0, 2.0, seed=9)
+    r = _solve(gpu, d, 10, 0)
+    assert L.cvxpnpl_last_layout() == 1 and r["iters"].min() == 6                    # AUTO at this size: the lane-hybrid schedule
+    q = _solve(gpu, d, 10, 0, layout=3)
+    assert L.cvxpnpl_last_layout() == 3 and q["iters"].min() == 5
+    for kw in (dict(lane_iters=4), dict(warm_start=0)):
+        a = _solve(gpu, d, 10, 0, layout=1, **kw)
+        assert L.cvxpnpl_last_layout() == 3, kw                                      # ... served by the quad schedule, with ITS first attempt
+        assert a["iters"].min() == 5 and (a["status"] == 0).all()
+    small = {k: (v[:1000] if isinstance(v, np.ndarray) and v.ndim > 2 else v) for k, v in d.items()}
+    _solve(gpu, small, 10, 0, layout=1, lane_iters=4)
+    assert L.cvxpnpl_last_layout() == 2
+    _solve(gpu, small, 10, 0, layout=4, f32_sweeps_until=0)
+    assert L.cvxpnpl_last_layout() == 3                                              # (a PENTA request with float64 sweeps: the sixteen-lane kernel)
+
+
 def test_f32_sweeps_until_is_validated(gpu):  # noqa: F811
     from cvxpnpl_amd import synth
 
