@@ -70,6 +70,37 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X public datasheet (the loc
 REFERENCE_PYTHON_OVERHEAD_US = 224.0  # measured per-pose cost of the reference's Python side with the solve stubbed out
 
 
+def _host_link(dev_index):
+    """What the transfer-inclusive rate depends on outside this code (round-5 verdict: 31-58 M poses/s across boxes): the PCIe link of the
+    device as the kernel driver reports it, the NUMA node it hangs off, and where this process's threads may run."""
+    import glob
+    info = {}
+    try:
+        import torch
+        bus = None
+        props = torch.cuda.get_device_properties(dev_index)
+        if hasattr(props, "pci_bus_id"):
+            bus = f"{getattr(props, 'pci_domain_id', 0):04x}:{props.pci_bus_id:02x}:{getattr(props, 'pci_device_id', 0):02x}.0"
+        cands = [f"/sys/bus/pci/devices/{bus}"] if bus else []
+        cands += sorted(glob.glob("/sys/class/drm/card*/device"))
+        for c in cands:
+            if os.path.exists(os.path.join(c, "current_link_speed")):
+                rd = lambda n: open(os.path.join(c, n)).read().strip() if os.path.exists(os.path.join(c, n)) else None  # noqa: E731
+                info.update({"sysfs": c, "current_link_speed": rd("current_link_speed"), "current_link_width": rd("current_link_width"),
+                             "max_link_speed": rd("max_link_speed"), "max_link_width": rd("max_link_width"), "numa_node": rd("numa_node")})
+                break
+    except Exception as e:  # diagnostics only
+        info["error"] = str(e)[:120]
+    try:
+        aff = sorted(os.sched_getaffinity(0))
+        info["cpu_affinity"] = f"{len(aff)} cpus, {aff[0]}..{aff[-1]}"
+        nodes = sorted(glob.glob("/sys/devices/system/node/node[0-9]*"))
+        info["host_numa_nodes"] = len(nodes)
+    except Exception:
+        pass
+    return info
+
+
 def _kernel_name(layout, batch, blocked=False, n_corr=10):
     """kernels of one step (AUTO policy of cvxpnpl_solve_batch: by launch size; four-correspondence problems stay in the quad schedule)"""
     if blocked:
@@ -587,6 +618,7 @@ def main():
                     "two_streams": {"value": batch * args.steps / dt2, "ms_per_step": 1e3 * dt2 / args.steps},
                     "h2d_bytes_per_step": int(bytes_in), "d2h_bytes_per_step": int(bytes_out),
                     "pcie_GBps_both_ways": (bytes_in + bytes_out) * args.steps / dtt / 1e9, "records_equal_device_run": same,
+                    "host_link": _host_link(dev.index),
                     "how": "pinned host inputs (one buffer) -> H2D -> cvxpnpl_solve_batch -> cvxpnpl_pack_results -> D2H of the [batch][13] records to "
                            "pinned memory, in order on a stream; one_stream: a single stream, nothing overlapped; two_streams: steps alternate between "
                            "two such streams (each with its own buffers), so that one step's copies can run under the other's solve; wall clock over the "
