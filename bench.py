@@ -93,7 +93,10 @@ def _host_link(dev_index):
         info["error"] = str(e)[:120]
     try:
         aff = sorted(os.sched_getaffinity(0))
-        info["cpu_affinity"] = f"{len(aff)} cpus, {aff[0]}..{aff[-1]}"
+        # (with OMP_PROC_BIND set -- main() does, for the host baselines -- the OpenMP runtime binds the calling thread to its first place when it
+        #  starts: a two-cpu answer here is that binding of THIS thread, not a limit of the box; os.cpu_count() is the box)
+        info["main_thread_affinity"] = f"{len(aff)} cpus, {aff[0]}..{aff[-1]}"
+        info["host_cpus"] = os.cpu_count()
         nodes = sorted(glob.glob("/sys/devices/system/node/node[0-9]*"))
         info["host_numa_nodes"] = len(nodes)
     except Exception:
