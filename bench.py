@@ -608,6 +608,17 @@ def main():
         dt2 = timed(2)
         dt1 = min(dt1, timed(1))
         dt2 = min(dt2, timed(2))
+        # Round 6 (profiles/r06/xfer_numa.txt): on ONE box the two-stream schedule is bimodal -- 62-64 M poses/s in eight of ten processes, 43 M in
+        # the other two, whatever NUMA node the feeding thread runs on (the one-stream figure is 33 M in all ten; PCIe Gen5 x16 every time).  The
+        # slow mode belongs to the PAIR of streams a process happened to get (both repeats of a process agree): how the runtime maps the second
+        # stream's copies and kernels onto hardware queues / copy engines.  So a pair that does not overlap is replaced: up to two fresh second
+        # streams, the best pair counts, and the line says how many were tried.
+        pair_ms = [1e3 * dt2 / args.steps]
+        while dt2 > 0.62 * dt1 and len(pair_ms) < 3:
+            t_streams[1] = torch.cuda.Stream(dev)
+            d_new = min(timed(2), timed(2))
+            pair_ms.append(1e3 * d_new / args.steps)
+            dt2 = min(dt2, d_new)
         best_two = dt2 < dt1
         dtt = min(dt1, dt2)
         # the records that arrived on the host are those of the device-resident run (same inputs, same options)
@@ -618,7 +629,7 @@ def main():
         transfer = {"value": batch * args.steps / dtt, "unit": "poses/s", "ms_per_step": 1e3 * dtt / args.steps,
                     "schedule": "two_streams" if best_two else "one_stream",
                     "one_stream": {"value": batch * args.steps / dt1, "ms_per_step": 1e3 * dt1 / args.steps},
-                    "two_streams": {"value": batch * args.steps / dt2, "ms_per_step": 1e3 * dt2 / args.steps},
+                    "two_streams": {"value": batch * args.steps / dt2, "ms_per_step": 1e3 * dt2 / args.steps, "stream_pairs_tried_ms_per_step": pair_ms},
                     "h2d_bytes_per_step": int(bytes_in), "d2h_bytes_per_step": int(bytes_out),
                     "pcie_GBps_both_ways": (bytes_in + bytes_out) * args.steps / dtt / 1e9, "records_equal_device_run": same,
                     "host_link": _host_link(dev.index),

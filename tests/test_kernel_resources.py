@@ -58,6 +58,10 @@ def test_shipped_kernels_match_the_committed_resource_table():
     assert len(table) >= 30, len(table)
     problems = _compare(table, golden)
     assert not problems, "\n".join(problems)
+    # The general scalar core on lanes (cvx::solve_sdp<TWIN = false> as a kernel of its own: solve_lane_kernel) is NOT part of the shipped
+    # library: run beyond the six iterations it is specified for it produces NaN iterates in -O1 builds (tools/microbench/lane_twin_repro.*,
+    # profiles/r06/lane_twin_repro.txt) -- it exists in experiment builds only.
+    assert not [k for k in table if "solve_lane_kernel" in k], [k for k in table if "solve_lane_kernel" in k]
 
 
 @pytest.mark.slow

@@ -14,7 +14,7 @@
 #define REPRO_WAVES 1 // __launch_bounds__(64, REPRO_WAVES): 1 -> 512 registers per lane, 2 -> 256, 4 -> 128 (more spills, other allocations)
 #endif
 
-template <bool TWIN>
+template <bool TWIN, bool DBL = TWIN>
 __global__ void __launch_bounds__(64, REPRO_WAVES) lane_full_kernel(int64_t batch, int n_p, const double *p2, const double *p3, const double *K, cvx::Opts o,
                                                                     double *R, int32_t *status, int32_t *iters, double *Z)
 {
@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(64, REPRO_WAVES) lane_full_kernel(int64_t batc
     cvx::ProblemView pv = cvx::make_view(b, n_p, p2, p3, 0, nullptr, nullptr, K, 0);
     cvx::Solution sol;
     double Zl[55];
-    cvx::solve_problem<TWIN>(pv, o, sol, Zl);
+    cvx::solve_problem<TWIN, cvx::RegStore, cvx::VAR_FULL, DBL>(pv, o, sol, Zl);
     for (int i = 0; i < 9; ++i) R[b * 9 + i] = sol.R[i];
     for (int i = 0; i < 55; ++i) Z[b * 55 + i] = Zl[i];
     status[b] = sol.status;
@@ -35,10 +35,13 @@ extern "C" int repro_run(int twin, int64_t batch, int n_p, const double *p2, con
 {
     cvx::Opts o = cvx::default_opts();
     o.max_iters = max_iters;
+    o.sweep_schedule = (f64 & 2) ? 0 : 1; // (bit 1: no cap on the sweeps of an eigen-solve -- without the twin logic the cap is the LANE PHASE's: one sweep from iteration 5 on)
+    f64 &= 1;
     o.f32_sweeps_until = f64 ? 0 : 64;
     o.rescue_from = 0;
     const unsigned grid = (unsigned)((batch + 63) / 64);
-    if (twin) hipLaunchKernelGGL(lane_full_kernel<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream, batch, n_p, p2, p3, K, o, R, status, iters, Z);
+    if (twin == 2) hipLaunchKernelGGL((lane_full_kernel<false, true>), dim3(grid), dim3(64), 0, (hipStream_t)stream, batch, n_p, p2, p3, K, o, R, status, iters, Z); // no twin logic, float64 sweeps
+    else if (twin) hipLaunchKernelGGL(lane_full_kernel<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream, batch, n_p, p2, p3, K, o, R, status, iters, Z);
     else hipLaunchKernelGGL(lane_full_kernel<false>, dim3(grid), dim3(64), 0, (hipStream_t)stream, batch, n_p, p2, p3, K, o, R, status, iters, Z);
     return (int)hipGetLastError();
 }
