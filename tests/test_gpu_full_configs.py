@@ -324,3 +324,17 @@ def test_host_threads_on_one_stream_do_not_interleave_their_launches(gpu):
     for t_ in th:
         t_.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("script", ["pnp.py", "pnl.py", "pnpl.py", "pnp_batch.py", "ransac.py"])
+def test_example_callers_reach_their_known_answers(gpu, script):  # noqa: F811
+    """examples/: the reference's three example callers (call pattern of its examples/pnp.py:30-41, pnl.py, pnpl.py) against this package, a
+    10 000-problem batch and a RANSAC frame -- each script asserts its own known answer (the literal poses carry 8 digits: 1e-6) and prints it"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", script)], capture_output=True, text=True, timeout=600, cwd=os.path.join(root, "examples"))
+    assert r.returncode == 0, r.stderr[-1500:]
+    if script in ("pnp.py", "pnl.py", "pnpl.py"):
+        assert "Nr of possible poses: 1" in r.stdout and "rotation off by" in r.stdout, r.stdout[-500:]
