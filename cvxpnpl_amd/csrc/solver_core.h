@@ -1240,8 +1240,9 @@ CVX_HD void ldl_solve10(const double *T, double *x) // (L D L^T) x = b with the 
     }
 }
 template <int VAR = VAR_FULL>
-CVX_HD double dual_refine_step(double *S, const double *z, const double *R, const double *v2, double delta, double &res, double &zSz)
+CVX_HD double dual_refine_step(double *S, const double *z, const double *R, const double *v2, double delta, double &res, double &zSz, double *ray_out = nullptr)
 {
+    if (ray_out) *ray_out = NAN;
     double x[10], T[55];
     CVX_UNROLL for (int i = 0; i < 55; ++i) T[i] = S[i];
     CVX_UNROLL for (int i = 0; i < 10; ++i) T[sidx(i, i)] += DUAL_REFINE_SIGMA;
@@ -1260,6 +1261,7 @@ CVX_HD double dual_refine_step(double *S, const double *z, const double *R, cons
     sym_mul10(S, x, Sx);
     double ray = -delta;
     CVX_UNROLL for (int i = 0; i < 10; ++i) ray += x[i] * Sx[i];
+    if (ray_out) *ray_out = ray;
     if (!(ray < 0)) return -1.0;
     // G = P_U(x x^T)
     double G[55], N[55];
@@ -1283,12 +1285,219 @@ CVX_HD double dual_refine_step(double *S, const double *z, const double *R, cons
     CVX_UNROLL for (int i = 0; i < 10; ++i) { const double v = Sz[i] - delta * z[i]; res = fabs(v) > res ? fabs(v) : res; zSz += z[i] * v; }
     return ldl_min_pivot(T);
 }
+// ---------------------------------------------------------------------------------------
+// The dual of a pose by a barrier Newton method inside the dual family (round 6; Opts::dual_refine >= 2).
+//
+// For a pose z that IS the optimum of the relaxation the family { S1 + U : U in span A_i, U z = 0 } of dual_certificate contains a
+// positive semidefinite member from the first attempt on -- the optimal dual itself -- whatever the first-order iterate has delivered so far
+// (host check on the slowest problems of 125 000: max_v lambda_min = 1e-4 ... 3e-3 at iteration 6 for problems that iterate to 14 ... 32 for
+// it, tools/experiments/dual_newton/).  Finding it is a 15-variable convex problem,   max t  s.t.  S1 + sum_k v_k U_k - t T >= 0 on the
+// complement of z,   T = I - z z^T / 4,   solved here by Newton steps on   -log det(S1 + U(v) - t T + z z^T / 4)   with the barrier weight
+// chosen such that the t-component of the gradient vanishes (mu = 1 / tr X on the complement of z), from t0 = lambda - max(0.3 |lambda|, 1e-3)
+// (lambda: an estimate of the bottom eigenvalue, e.g. the Rayleigh quotient of dual_refine_step; a start that is not feasible lowers t0).
+// Everything is done in the FRAME OF R: S' = P(R)^T S1 P(R), P = blkdiag(R, R, R, 1), where z becomes z_I = [vec I3; 1] and the family has a
+// constant sparse integer basis (kNt*: generated by tools/gen_newton_tables.py, 14 signed sums of constraint matrices with 4, 6 or 13 upper
+// entries, and T_I as the 15th) -- gradient and Hessian are sums over those entries of products of two entries of X = (...)^-1:
+//     g_a = sum_(p,q) w c X_pq,      H_ab = sum_(p,q) sum_(r,s) c c' (w w' / 2) (X_pr X_qs + X_ps X_qr),      w = 1 on the diagonal, 2 off it.
+// Host experiments (same directory): every failed attempt whose pose is final certifies within 3 steps -- 36 of 36 on the slow problems of
+// 125 000, 627 of 628 on the judged set (599 after ONE step).  The certificate that is reported is the usual one: LDL^T(S(v) + delta I) > 0,
+// S z and z^T S z re-measured on the matrix that passed (eigenvalues are those of the world-frame matrix: P is orthogonal).
+// WHERE IT RUNS: in this scalar core only (host build; Opts::dual_refine = 2).  The cooperative device version was built and measured
+// (tools/experiments/patches/r06_coop_newton_device.patch, profiles/r06/newton_check.txt, newton_ab.txt): identical outcomes -- 2 000 fresh solves end
+// after at most 7 iterations instead of 11, the 125 k launch's slowest problem after 19 instead of 33 -- but as a table-driven routine it costs a
+// wavefront ~150 us per solve, and its mere presence cost the kernels around it 4-10 % (register allocation): not in the library.  What it
+// establishes stays: the iterations after the fifth buy nothing but a dual that this 15-variable problem delivers at once.
+constexpr int NT_N = 15, NT_MAX = 16;
+constexpr int kNtCount[NT_N] = {4, 6, 6, 4, 6, 6, 6, 13, 13, 6, 6, 6, 13, 6, 16};
+constexpr signed char kNtP[NT_N][NT_MAX] = {
+    {1, 2, 3, 6, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 0, 1, 2, 3, 6, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 0, 1, 2, 3, 6, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 3, 5, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 3, 4, 4, 5, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 1, 2, 3, 6, 6, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 1, 2, 4, 7, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 0, 1, 1, 2, 3, 4, 5, 6, 7, 8, 8, 9, 0, 0, 0},
+    {0, 0, 1, 2, 3, 4, 4, 5, 5, 6, 7, 8, 9, 0, 0, 0},
+    {0, 1, 3, 3, 5, 6, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 2, 3, 3, 4, 6, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 1, 2, 3, 3, 6, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 0, 1, 2, 2, 3, 4, 4, 5, 6, 7, 8, 9, 0, 0, 0},
+    {0, 1, 1, 4, 5, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 0, 0, 0, 1, 2, 3, 4, 4, 4, 5, 6, 7, 8, 8, 9},
+};
+constexpr signed char kNtQ[NT_N][NT_MAX] = {
+    {1, 2, 3, 6, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 3, 4, 5, 4, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {2, 6, 7, 8, 5, 8, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 3, 5, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {2, 6, 5, 7, 8, 8, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {2, 5, 4, 5, 8, 9, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {5, 2, 3, 5, 8, 9, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 4, 1, 3, 2, 3, 4, 5, 6, 7, 8, 9, 9, 0, 0, 0},
+    {0, 9, 1, 2, 3, 4, 8, 5, 7, 6, 7, 8, 9, 0, 0, 0},
+    {1, 9, 4, 8, 6, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {2, 9, 5, 7, 6, 8, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 8, 7, 4, 9, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 8, 1, 2, 6, 3, 4, 9, 5, 6, 7, 8, 9, 0, 0, 0},
+    {7, 2, 6, 5, 9, 8, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 4, 8, 9, 1, 2, 3, 4, 8, 9, 5, 6, 7, 8, 9, 9},
+};
+constexpr double kNtC[NT_N][NT_MAX] = {
+    {1.0, 1.0, -1.0, -1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0},
+    {-1.0, 1.0, 1.0, 1.0, -1.0, -1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0},
+    {-1.0, 1.0, 1.0, 1.0, -1.0, -1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0},
+    {-1.0, 1.0, 1.0, -1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0},
+    {-1.0, 1.0, -1.0, 1.0, 1.0, -1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0},
+    {1.0, 1.0, -1.0, 1.0, 1.0, -1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0},
+    {-1.0, 1.0, 1.0, 1.0, 1.0, -1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0},
+    {-1.0, 1.0, -1.0, -1.0, 1.0, -1.0, -1.0, 1.0, -1.0, -1.0, 1.0, -1.0, 1.0, 0.0, 0.0, 0.0},
+    {1.0, -1.0, -1.0, -1.0, 1.0, -1.0, 1.0, -1.0, -1.0, 1.0, -1.0, -1.0, 1.0, 0.0, 0.0, 0.0},
+    {1.0, -1.0, 1.0, -1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0},
+    {1.0, -1.0, 1.0, 1.0, -1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0},
+    {1.0, -1.0, 1.0, 1.0, -1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0},
+    {-1.0, 1.0, 1.0, -1.0, -1.0, -1.0, 1.0, -1.0, -1.0, -1.0, 1.0, -1.0, 1.0, 0.0, 0.0, 0.0},
+    {-1.0, 1.0, 1.0, 1.0, -1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0},
+    {0.75, -0.25, -0.25, -0.25, 1.0, 1.0, 1.0, 0.75, -0.25, -0.25, 1.0, 1.0, 1.0, 0.75, -0.25, 0.75},
+};
+constexpr int NT_PAIRS = 120;
+constexpr signed char kNtPairA[NT_PAIRS] = {14, 7, 8, 12, 7, 7, 7, 8, 8, 12, 1, 2, 4, 5, 6, 9, 10, 11, 13, 1, 1, 1, 2, 2, 2, 4, 4, 4, 5, 5, 5, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8, 8, 9, 10, 11, 12, 0, 3, 0, 0, 0, 3, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 4, 4, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 6, 6, 6, 6, 6, 9, 9, 9, 9, 10, 10, 10, 11, 11, 13, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 2, 3, 3, 3, 3, 3, 3, 3, 0, 0, 3};
+constexpr signed char kNtPairB[NT_PAIRS] = {14, 14, 14, 14, 7, 8, 12, 8, 12, 12, 14, 14, 14, 14, 14, 14, 14, 14, 14, 7, 8, 12, 7, 8, 12, 7, 8, 12, 7, 8, 12, 7, 8, 12, 9, 10, 11, 13, 9, 10, 11, 13, 12, 12, 12, 13, 14, 14, 7, 8, 12, 7, 8, 12, 1, 2, 4, 5, 6, 9, 10, 11, 13, 2, 4, 5, 6, 9, 10, 11, 13, 4, 5, 6, 9, 10, 11, 13, 5, 6, 9, 10, 11, 13, 6, 9, 10, 11, 13, 9, 10, 11, 13, 10, 11, 13, 11, 13, 13, 1, 2, 4, 5, 6, 9, 10, 11, 13, 3, 3, 4, 5, 6, 9, 10, 11, 13, 0, 3, 3};
+
+constexpr int DUAL_NEWTON_STEPS = 3;
+constexpr double DUAL_NEWTON_MARGIN = 0.3, DUAL_NEWTON_FLOOR = 1e-3;
+
+// inverse of a symmetric positive definite n x n matrix (full storage, row stride ld) by Gauss-Jordan without pivoting; false: a pivot <= 0
+template <int N>
+CVX_HD bool spd_inverse(double *A, int ld)
+{
+    for (int k = 0; k < N; ++k) {
+        const double d = A[k * ld + k];
+        if (!(d > 0)) return false;
+        const double id = 1.0 / d;
+        for (int j = 0; j < N; ++j) A[k * ld + j] *= id;
+        A[k * ld + k] = id;
+        for (int i = 0; i < N; ++i) {
+            if (i == k) continue;
+            const double f = A[i * ld + k];
+            A[i * ld + k] = 0.0;
+            for (int j = 0; j < N; ++j) A[i * ld + j] -= f * A[k * ld + j];
+        }
+    }
+    return true;
+}
+
+// S: the failed dual of dual_certificate (55 packed, delta ON its diagonal), R: the polished rotation, lam: estimate of its bottom eigenvalue
+// (< 0; NaN: unknown).  Returns the smallest pivot of the refined dual + delta I (<= 0: no luck) with res / zSz re-measured; steps: Newton steps made.
+CVX_HD double dual_newton(const double *S, const double *R, double delta, double lam, double &res, double &zSz, int *steps = nullptr)
+{
+    const double zI[10] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 1};
+    // S' = P^T (S - delta I) P:  S'[3j+a][3k+b] = sum_cd R[c][a] S[3j+c][3k+d] R[d][b],  S'[3j+a][9] = sum_c R[c][a] S[3j+c][9]
+    double Sp[10][10];
+    for (int j = 0; j < 3; ++j)
+        for (int a = 0; a < 3; ++a) {
+            for (int k = 0; k < 3; ++k)
+                for (int b = 0; b < 3; ++b) {
+                    double acc = 0;
+                    for (int c = 0; c < 3; ++c)
+                        for (int d = 0; d < 3; ++d) {
+                            const int p = 3 * j + c, q = 3 * k + d;
+                            acc += R[c * 3 + a] * (S[sidx(p < q ? p : q, p < q ? q : p)] - (p == q ? delta : 0.0)) * R[d * 3 + b];
+                        }
+                    Sp[3 * j + a][3 * k + b] = acc;
+                }
+            double acc = 0;
+            for (int c = 0; c < 3; ++c) acc += R[c * 3 + a] * S[sidx(3 * j + c, 9)];
+            Sp[3 * j + a][9] = acc; Sp[9][3 * j + a] = acc;
+        }
+    Sp[9][9] = S[sidx(9, 9)] - delta;
+    double v[NT_N];
+    for (int a = 0; a < NT_N; ++a) v[a] = 0.0;
+    // M(v, t) = S' + sum_a v_a U_a - t T + z_I z_I^T / 4   (v[14] = -t)
+    auto build = [&](const double *vv, double M[10][10], bool with_t) {
+        for (int i = 0; i < 10; ++i) for (int j = 0; j < 10; ++j) M[i][j] = Sp[i][j] + (with_t ? 0.25 * zI[i] * zI[j] : 0.0);
+        for (int a = 0; a < (with_t ? NT_N : NT_N - 1); ++a)
+            for (int e = 0; e < kNtCount[a]; ++e) {
+                const int p = kNtP[a][e], q = kNtQ[a][e];
+                M[p][q] += vv[a] * kNtC[a][e];
+                if (p != q) M[q][p] += vv[a] * kNtC[a][e];
+            }
+    };
+    double X[10][10];
+    double margin = (lam == lam && lam < 0) ? (DUAL_NEWTON_MARGIN * -lam > DUAL_NEWTON_FLOOR ? DUAL_NEWTON_MARGIN * -lam : DUAL_NEWTON_FLOOR) : 4e-3;
+    const double l0 = (lam == lam && lam < 0) ? lam : -1e-2;
+    bool feas = false;
+    for (int tr_ = 0; tr_ < 4 && !feas; ++tr_) { // (a start that is not inside the cone: the estimate was too high -- lower t0)
+        v[NT_N - 1] = -(l0 - margin);
+        build(v, X, true);
+        feas = spd_inverse<10>(&X[0][0], 10);
+        margin *= 4.0;
+    }
+    if (steps) *steps = 0;
+    if (!feas) return -1.0;
+    for (int k = 0; k < DUAL_NEWTON_STEPS; ++k) {
+        // gradient and Hessian over the tables
+        double g[NT_N], H[NT_N][NT_N + 1];
+        for (int a = 0; a < NT_N; ++a) {
+            double ga = 0;
+            for (int e = 0; e < kNtCount[a]; ++e) ga += kNtC[a][e] * (kNtP[a][e] == kNtQ[a][e] ? 1.0 : 2.0) * X[kNtP[a][e]][kNtQ[a][e]];
+            g[a] = ga;
+            for (int b = a; b < NT_N; ++b) {
+                double h = 0;
+                for (int e = 0; e < kNtCount[a]; ++e) {
+                    const int p = kNtP[a][e], q = kNtQ[a][e];
+                    const double ca = kNtC[a][e] * (p == q ? 1.0 : 2.0);
+                    for (int f = 0; f < kNtCount[b]; ++f) {
+                        const int r = kNtP[b][f], s_ = kNtQ[b][f];
+                        h += ca * kNtC[b][f] * (r == s_ ? 0.5 : 1.0) * (X[p][r] * X[q][s_] + X[p][s_] * X[q][r]);
+                    }
+                }
+                H[a][b] = h; H[b][a] = h;
+            }
+        }
+        // Newton direction of -log det(M) in (v_0..v_13, v_14 = -t); the barrier weight makes the last component of the gradient vanish
+        for (int a = 0; a < NT_N; ++a) H[a][NT_N] = (a == NT_N - 1) ? 0.0 : g[a];
+        double Hi[NT_N][NT_N];
+        for (int a = 0; a < NT_N; ++a) for (int b = 0; b < NT_N; ++b) Hi[a][b] = H[a][b];
+        if (!spd_inverse<NT_N>(&Hi[0][0], NT_N)) return -1.0;
+        double dx[NT_N];
+        for (int a = 0; a < NT_N; ++a) { double acc = 0; for (int b = 0; b < NT_N; ++b) acc += Hi[a][b] * H[b][NT_N]; dx[a] = acc; }
+        // step: the longest of 1, 1/2, ... 1/16 that stays inside the cone
+        double al = 1.0, vn[NT_N];
+        bool ok = false;
+        for (int ls = 0; ls < 5 && !ok; ++ls) {
+            for (int a = 0; a < NT_N; ++a) vn[a] = v[a] + al * dx[a];
+            build(vn, X, true);
+            ok = spd_inverse<10>(&X[0][0], 10);
+            al *= 0.5;
+        }
+        if (!ok) return -1.0;
+        for (int a = 0; a < NT_N; ++a) v[a] = vn[a];
+        if (steps) *steps = k + 1;
+        // the certificate's own test on S(v) = S' + sum v_a U_a (+ delta I)
+        double M[10][10], T[55];
+        build(v, M, false);
+        for (int i = 0; i < 10; ++i) for (int j = i; j < 10; ++j) T[sidx(i, j)] = M[i][j] + (i == j ? delta : 0.0);
+        const double mp = ldl_min_pivot(T);
+        if (mp > 0) {
+            res = 0; zSz = 0;
+            for (int i = 0; i < 10; ++i) {
+                double acc = 0;
+                for (int j = 0; j < 10; ++j) acc += M[i][j] * zI[j];
+                res = fabs(acc) > res ? fabs(acc) : res;
+                zSz += zI[i] * acc;
+            }
+            return mp;
+        }
+    }
+    return -1.0;
+}
 // Dual half: given the polished rotation c.R (and c.pobj), recover a dual and test it.
 // SYMM: recognise planar scenes (Qs blind to the third column of R), whose relaxation is invariant
 // under D = diag(-I6, I4), and build the correction in the D-even subspace so that it annihilates
 // both twins z and D z at once.
 template <bool SYMM = true, class QV = const double *, int VAR = VAR_FULL>
-CVX_HD void dual_certificate(QV Qs, const double *W, const double *Wp, double rho, double delta, double d0, Cert &c, double shift = 0.0, const double *v2 = nullptr)
+CVX_HD void dual_certificate(QV Qs, const double *W, const double *Wp, double rho, double delta, double d0, Cert &c, double shift = 0.0, const double *v2 = nullptr, bool newton = false)
 {
     c.ok = false;
     double z[10];
@@ -1329,8 +1538,10 @@ CVX_HD void dual_certificate(QV Qs, const double *W, const double *Wp, double rh
             }
         }
         if (!(c.min_piv > 0) && v2) { // third try: one eigen-gradient step inside the dual family
-            double res2, zSz2;
-            const double mp = dual_refine_step<VAR>(S, z, c.R, v2, delta, res2, zSz2);
+            double res2, zSz2, ray = NAN, S0[55];
+            CVX_UNROLL for (int i = 0; i < 55; ++i) S0[i] = S[i];
+            double mp = dual_refine_step<VAR>(S, z, c.R, v2, delta, res2, zSz2, &ray);
+            if (!(mp > 0 && res2 < 1e-10) && newton && VAR == VAR_FULL) mp = dual_newton(S0, c.R, delta, ray, res2, zSz2); // fourth: the barrier Newton solve
             if (mp > 0 && res2 < 1e-10) { c.min_piv = mp; c.res = res2; c.zSz = zSz2; }
         }
     } else {
@@ -1658,7 +1869,15 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
             // a failed dual gets its second tries (dual_certificate) from the second attempt of a solve on: the first attempt of every
             // problem would pay for them, the later ones are the slow problems that end a launch (the lane phase makes one attempt)
             const double retry_shift = (TWIN && attempts > 0 && attempts <= DUAL_RETRY_ATTEMPTS) ? o.dual_shift : 0.0;
-            const bool refine = TWIN && o.dual_refine && attempts >= DUAL_REFINE_FROM && attempts < DUAL_REFINE_FROM + DUAL_REFINE_ATTEMPTS; // (the eigen-gradient step)
+            // (dual_refine: low two bits 1 = the eigen-gradient step, 2 = and the barrier Newton solve behind it; the higher bits say in which phases
+            //  of the kernels' schedules -- this scalar core is one phase.  CVX_REFINE_FROM_EXPERIMENT: tools/experiments/dual_newton/policy_host.py)
+#ifdef CVX_REFINE_FROM_EXPERIMENT
+            const int refine_from = (o.dual_refine >> 4) > 0 ? (o.dual_refine >> 4) - 1 : DUAL_REFINE_FROM;
+#else
+            constexpr int refine_from = DUAL_REFINE_FROM;
+#endif
+            const bool refine = TWIN && (o.dual_refine & 3) && attempts >= refine_from && attempts < refine_from + DUAL_REFINE_ATTEMPTS; // (the eigen-gradient step)
+            const bool newton = refine && (o.dual_refine & 3) >= 2;
             ++attempts;
             // top eigenvector of Wp (and the runner-up, see below)
             int jm = 0, j2 = 0;
@@ -1715,7 +1934,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                     polish_rotation(Qs, c.R, c.pobj);
                     if (TWIN) reused = 0;
                 }
-                dual_certificate<TWIN, decltype(Qs), VAR>(Qs, W, Wp, rho, delta, d0, c, retry_shift, refine ? v2 : nullptr);
+                dual_certificate<TWIN, decltype(Qs), VAR>(Qs, W, Wp, rho, delta, d0, c, retry_shift, refine ? v2 : nullptr, newton);
                 have_prev = d0 > 0 && (c.pobj == c.pobj);
                 CVX_UNROLL for (int i = 0; i < 9; ++i) Rprev[i] = c.R[i];
                 fprev = c.pobj;
@@ -1741,7 +1960,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                 // the dual test (it is then a global optimum, and so is z- with the same cost).
                 if (ambiguous) {
                     c.pobj = fp;
-                    dual_certificate<TWIN, decltype(Qs), VAR>(Qs, W, Wp, rho, delta, dp, c, retry_shift, refine ? v2 : nullptr);
+                    dual_certificate<TWIN, decltype(Qs), VAR>(Qs, W, Wp, rho, delta, dp, c, retry_shift, refine ? v2 : nullptr, newton);
                     ambiguous = c.ok && (tr * (fabs(c.zSz) + 4.0 * delta) <= (o.eps > 8e-13 * tr ? o.eps : 8e-13 * tr));
                     twin_tested = true;
                 }
@@ -1749,7 +1968,7 @@ CVX_HD void solve_sdp(const double *Q9, const double *B, const Opts &o, Solution
                     const bool take_m = dm > 0 && (fm == fm) && (!(dp > 0) || !(fp == fp) || fm < fp);
                     if (take_m) { CVX_UNROLL for (int i = 0; i < 9; ++i) c.R[i] = Rm[i]; }
                     c.pobj = take_m ? fm : fp;
-                    dual_certificate<TWIN, decltype(Qs), VAR>(Qs, W, Wp, rho, delta, take_m ? dm : dp, c, retry_shift, refine ? v2 : nullptr);
+                    dual_certificate<TWIN, decltype(Qs), VAR>(Qs, W, Wp, rho, delta, take_m ? dm : dp, c, retry_shift, refine ? v2 : nullptr, newton);
                 } else if (!ambiguous) {
                     c.ok = false; // equal-cost twins whose certificate is not there yet: keep iterating
                 }

@@ -186,6 +186,25 @@ def dual_retry_direction(R):
     return D
 
 
+def newton_tables():
+    """constant tables of cvx::dual_newton as dense matrices [15, 10, 10]"""
+    M = np.zeros((15, 10, 10))
+    lib().hs_newton_tables.argtypes = [_dp]
+    lib().hs_newton_tables(_p(M))
+    return M
+
+
+def dual_newton(S55, R, delta, lam=float("nan")):
+    """cvx::dual_newton on one failed dual (S55: packed, delta on the diagonal) -> (min pivot, |S z|_inf, z^T S z, Newton steps)"""
+    S = np.ascontiguousarray(S55, dtype=np.float64)
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    out = np.zeros(3)
+    lib().hs_dual_newton.argtypes = [_dp, _dp, C.c_double, C.c_double, _dp]
+    lib().hs_dual_newton.restype = C.c_int
+    steps = lib().hs_dual_newton(_p(S), _p(R), float(delta), float(lam), _p(out))
+    return out[0], out[1], out[2], steps
+
+
 def proj_affine_homog(E55, variant=0):
     E = np.ascontiguousarray(E55, dtype=np.float64).copy()
     lib().hs_proj_affine_homog.argtypes = [_dp, C.c_int]

@@ -26,6 +26,28 @@ void hs_dual_retry_direction(const double *R9, double *D100)
     for (int a = 0; a < 10; ++a)
         for (int b = 0; b < 10; ++b) D100[a * 10 + b] = cvx::dual_retry_entry6(R9, a < b ? a : b, a < b ? b : a) * (1.0 / 6.0);
 }
+// the barrier Newton solve of the dual (solver_core.h: dual_newton) on one failed dual: S55 with delta on its diagonal, R9 row-major;
+// out = {smallest pivot of the dual that passed (<= 0: none), |S z|_inf, z^T S z}; returns the Newton steps made
+int hs_dual_newton(const double *S55, const double *R9, double delta, double lam, double *out3)
+{
+    int steps = 0;
+    double res = 0, zSz = 0;
+    out3[0] = cvx::dual_newton(S55, R9, delta, lam, res, zSz, &steps);
+    out3[1] = res; out3[2] = zSz;
+    return steps;
+}
+// its constant tables as dense matrices [15][100] (14 basis matrices of the dual family in the frame of R, then T_I)
+void hs_newton_tables(double *M)
+{
+    for (int a = 0; a < cvx::NT_N; ++a) {
+        for (int e = 0; e < 100; ++e) M[a * 100 + e] = 0.0;
+        for (int e = 0; e < cvx::kNtCount[a]; ++e) {
+            const int p = cvx::kNtP[a][e], q = cvx::kNtQ[a][e];
+            M[a * 100 + p * 10 + q] += cvx::kNtC[a][e];
+            if (p != q) M[a * 100 + q * 10 + p] += cvx::kNtC[a][e];
+        }
+    }
+}
 // homogeneous projection onto the direction space of the equalities (solver_core.h: proj_affine), packed 55 in place
 void hs_proj_affine_homog(double *E55, int variant)
 {

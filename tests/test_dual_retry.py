@@ -138,6 +138,44 @@ def test_scalar_core_with_and_without_the_eigen_gradient_step():
     assert (gap >= -1e-15).all() and (gap <= 1.0001e-9 + 1e-12 * np.abs(b["cost"][:, 0])).all()                # the certificate statement is unchanged
 
 
+def test_newton_tables_are_a_basis_of_the_dual_family_in_the_frame_of_R():
+    """cvx::kNt* (solver_core.h, generated by tools/gen_newton_tables.py): 14 independent matrices of span A_i that annihilate z_I = [vec I3; 1]
+    -- with the constraint matrices built from the oracle's own static data -- and T_I = I - z_I z_I^T / 4 as the 15th."""
+    import hostsim
+    import oracle
+
+    M = hostsim.newton_tables()
+    zI = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 1.0])
+    assert np.abs(M[:14] @ zI).max() == 0.0 and np.allclose(M[14], np.eye(10) - np.outer(zI, zI) / 4)
+    assert np.linalg.matrix_rank(M[:14].reshape(14, 100)) == 14
+    Ad, _ = oracle.sdp_constraints()                     # the reference's _A (cvxpnpl.py:387-451): rows 0..21 are the equalities on vech(Z)
+    A = np.stack([oracle.vech10_inv(Ad[i]) for i in range(22)])
+    A = 0.5 * (A + np.stack([np.diag(np.diag(a)) for a in A]))   # <A_i, Z> = row . vech(Z): every off-diagonal pair counted once
+    F = A.reshape(len(A), 100)
+    coef, res, *_ = np.linalg.lstsq(F.T, M[:14].reshape(14, 100).T, rcond=None)
+    assert np.abs(F.T @ coef - M[:14].reshape(14, 100).T).max() < 1e-12          # inside span A_i
+    assert 14 == 21 - np.linalg.matrix_rank(np.stack([a @ zI for a in A], 1))    # ... and they span all of { X in span A_i : X z_I = 0 }
+
+
+def test_scalar_core_with_the_newton_solve_of_the_dual():
+    """opts.dual_refine = 2 (cvx::dual_newton; the scalar core only): the same certified optimum and certificate statement, and what the
+    eigen-gradient step leaves at 11 and more iterations stops at the third attempt -- the dual family holds a certifying member as soon as
+    the pose is final."""
+    import hostsim
+    from cvxpnpl_amd import synth
+    from test_gpu_parity import geodesic_np
+
+    d = synth.make_pnpl(20000, 10, 0, 2.0, seed=42)
+    a = hostsim.solve_batch(d["pts_2d"], d["pts_3d"], None, None, d["K"], opts=hostsim.default_opts(first_check=6))
+    b = hostsim.solve_batch(d["pts_2d"], d["pts_3d"], None, None, d["K"], opts=hostsim.default_opts(first_check=6, dual_refine=2))
+    assert (a["status"] == 0).all() and (b["status"] == 0).all()
+    diff = np.flatnonzero(a["iters"] != b["iters"])
+    assert len(diff) >= 1 and max(geodesic_np(a["R"][i], b["R"][i]) for i in diff) < 1e-8
+    assert (b["iters"] <= a["iters"]).all() and (b["iters"] > 10).sum() < (a["iters"] > 10).sum()
+    gap = b["cost"][:, 0] - b["cost"][:, 1]
+    assert (gap >= -1e-15).all() and (gap <= 1.0001e-9 + 1e-12 * np.abs(b["cost"][:, 0])).all()
+
+
 @pytest.mark.gpu
 def test_the_eigen_gradient_step_on_the_device():
     """quad schedule (10 000 problems): the wave-per-problem phase behind the quad phase makes the step; statuses equal, stragglers shorter,
