@@ -1360,10 +1360,6 @@ constexpr double kNtC[NT_N][NT_MAX] = {
     {-1.0, 1.0, 1.0, 1.0, -1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0},
     {0.75, -0.25, -0.25, -0.25, 1.0, 1.0, 1.0, 0.75, -0.25, -0.25, 1.0, 1.0, 1.0, 0.75, -0.25, 0.75},
 };
-constexpr int NT_PAIRS = 120;
-constexpr signed char kNtPairA[NT_PAIRS] = {14, 7, 8, 12, 7, 7, 7, 8, 8, 12, 1, 2, 4, 5, 6, 9, 10, 11, 13, 1, 1, 1, 2, 2, 2, 4, 4, 4, 5, 5, 5, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8, 8, 9, 10, 11, 12, 0, 3, 0, 0, 0, 3, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 4, 4, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 6, 6, 6, 6, 6, 9, 9, 9, 9, 10, 10, 10, 11, 11, 13, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 2, 3, 3, 3, 3, 3, 3, 3, 0, 0, 3};
-constexpr signed char kNtPairB[NT_PAIRS] = {14, 14, 14, 14, 7, 8, 12, 8, 12, 12, 14, 14, 14, 14, 14, 14, 14, 14, 14, 7, 8, 12, 7, 8, 12, 7, 8, 12, 7, 8, 12, 7, 8, 12, 9, 10, 11, 13, 9, 10, 11, 13, 12, 12, 12, 13, 14, 14, 7, 8, 12, 7, 8, 12, 1, 2, 4, 5, 6, 9, 10, 11, 13, 2, 4, 5, 6, 9, 10, 11, 13, 4, 5, 6, 9, 10, 11, 13, 5, 6, 9, 10, 11, 13, 6, 9, 10, 11, 13, 9, 10, 11, 13, 10, 11, 13, 11, 13, 13, 1, 2, 4, 5, 6, 9, 10, 11, 13, 3, 3, 4, 5, 6, 9, 10, 11, 13, 0, 3, 3};
-
 constexpr int DUAL_NEWTON_STEPS = 3;
 constexpr double DUAL_NEWTON_MARGIN = 0.3, DUAL_NEWTON_FLOOR = 1e-3;
 

@@ -2,7 +2,7 @@
 """Generates the constant tables of cvx::dual_newton (csrc/solver_core.h: kNt*): a sparse integer basis of the dual family in the frame of R,
 U_I = { X in span A_i : X z_I = 0 }, z_I = [vec I3; 1] (14 matrices, each a signed sum of constraint matrices: 4, 6 or 13 upper entries), and
 T_I = I - z_I z_I^T / 4 as the 15th.  The constraint matrices are the 22 rows of SURVEY.md A.5 (= the reference's _A, cvxpnpl.py:387-451, on
-the unscaled vech).  tests/test_dual_retry.py checks the tables in the header against the same construction.   python tools/gen_newton_tables.py"""
+the unscaled vech).  tests/test_dual_retry.py checks the tables in the header against the same construction.   python tools/gen_newton_tables.py [--device]"""
 import numpy as np
 import sympy as sp
 
@@ -70,8 +70,12 @@ if __name__ == "__main__":
     for t in tabs:
         print("    {" + ", ".join(repr(e[2]) for e in t + [(0, 0, 0.0)] * (nmax - len(t))) + "},")
     print("};")
-    # the 120 pairs a <= b of the Hessian, heaviest first (count_a * count_b terms): a wavefront's lane l takes pairs l and 119 - l
-    pairs = sorted(((a, b) for a in range(len(tabs)) for b in range(a, len(tabs))), key=lambda ab: (-len(tabs[ab[0]]) * len(tabs[ab[1]]), ab))
+    if "--device" not in __import__("sys").argv:
+        raise SystemExit(0)
+    # (device experiment only -- tools/experiments/patches/r06_coop_newton_device.patch) the 120 pairs of the Hessian, A = the matrix with fewer entries (the device loops over A's entries and runs B's sixteen slots unrolled),
+    # heaviest first (count_A): a wavefront's lane l takes pairs l and 119 - l
+    pairs = [(a, b) if len(tabs[a]) <= len(tabs[b]) else (b, a) for a in range(len(tabs)) for b in range(a, len(tabs))]
+    pairs.sort(key=lambda ab: (-len(tabs[ab[0]]), -len(tabs[ab[1]]), ab))
     print(f"constexpr int NT_PAIRS = {len(pairs)};")
     print("constexpr signed char kNtPairA[NT_PAIRS] = {" + ", ".join(str(a) for a, b in pairs) + "};")
     print("constexpr signed char kNtPairB[NT_PAIRS] = {" + ", ".join(str(b) for a, b in pairs) + "};")

@@ -14,14 +14,11 @@ run() { # workload args ... -- modes
   args=(); while [ "$1" != "--" ]; do args+=("$1"); shift; done; shift
   for i in $(seq $n); do for m in "$@"; do one "refine=$m" "${args[@]}" --opt dual_refine=$m; done; done
 }
+run --workload pnp_n10_125k --steps 20 -- 1 2
+run --workload pnpl_5p5l_100k --steps 20 -- 1 2
+run --workload pnp_n10_125k --batch 1000000 --steps 5 --warmup 2 -- 1 2
+run --workload pnp_n10_125k --batch 30000 --steps 20 -- 1 2
+run --workload pnp_n4_50k --steps 10 -- 1 2
+run --workload ransac_n4_50k --steps 10 -- 1 2
 run --workload pnp_n10_10k -- 1 2
-run --workload pnp_n10_10k --seed 1 -- 1 2
-run --workload pnp_n10_10k --seed 3 -- 1 2
-run --workload pnp_n10_10k --batch 16000 -- 1 2
-run --workload pnp_n10_10k --batch 2000 -- 1 9 10
-run --workload pnp_n10_125k --steps 20 -- 1 5 6
-run --workload pnpl_5p5l_100k --steps 20 -- 1 5 6
-run --workload pnp_n10_125k --batch 1000000 --steps 5 --warmup 2 -- 1 6
-run --workload pnp_n4_50k --steps 10 -- 1 2 6
-run --workload ransac_n4_50k --steps 10 -- 1 2 6
 cat $out

@@ -24,11 +24,11 @@ def hist(it):
 for name, d, n_p, n_l, kw, modes in (
         ("pnp10 10k quad", synth.make_pnpl(10000, 10, 0, 2.0, seed=42), 10, 0, {}, (0, 1, 2)),
         ("pnp10 10k quad seed 1", synth.make_pnpl(10000, 10, 0, 2.0, seed=1), 10, 0, {}, (0, 1, 2)),
-        ("pnp10 2k wave", synth.make_pnpl(2000, 10, 0, 2.0, seed=42), 10, 0, {}, (0, 1 + 8, 2 + 8)),
-        ("pnp10 125k lane", synth.make_pnpl(125000, 10, 0, 2.0, seed=42), 10, 0, {}, (0, 1 + 4, 2 + 4)),
-        ("pnpl 5+5 100k lane", synth.make_pnpl(100000, 5, 5, 2.0, seed=42), 5, 5, {}, (0, 1 + 4, 2 + 4)),
-        ("pnp6 30k", synth.make_pnpl(30000, 6, 0, 2.0, seed=42), 6, 0, {}, (0, 1 + 4, 2 + 4)),
-        ("pnp4 20k", synth.make_pnpl(20000, 4, 0, 1.0, seed=42), 4, 0, {}, (0, 1 + 4, 2 + 4))):
+        ("pnp10 2k wave", synth.make_pnpl(2000, 10, 0, 2.0, seed=42), 10, 0, {}, (0, 1, 2)),
+        ("pnp10 125k lane", synth.make_pnpl(125000, 10, 0, 2.0, seed=42), 10, 0, {}, (0, 1, 2)),
+        ("pnpl 5+5 100k lane", synth.make_pnpl(100000, 5, 5, 2.0, seed=42), 5, 5, {}, (0, 1, 2)),
+        ("pnp6 30k", synth.make_pnpl(30000, 6, 0, 2.0, seed=42), 6, 0, {}, (0, 1, 2)),
+        ("pnp4 20k", synth.make_pnpl(20000, 4, 0, 1.0, seed=42), 4, 0, {}, (0, 1, 2))):
     ref = None
     for m in modes:
         r = _solve(dev, d, n_p, n_l, dual_refine=m, **kw)
