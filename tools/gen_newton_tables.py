@@ -72,10 +72,23 @@ if __name__ == "__main__":
     print("};")
     if "--device" not in __import__("sys").argv:
         raise SystemExit(0)
-    # (device experiment only -- tools/experiments/patches/r06_coop_newton_device.patch) the 120 pairs of the Hessian, A = the matrix with fewer entries (the device loops over A's entries and runs B's sixteen slots unrolled),
-    # heaviest first (count_A): a wavefront's lane l takes pairs l and 119 - l
-    pairs = [(a, b) if len(tabs[a]) <= len(tabs[b]) else (b, a) for a in range(len(tabs)) for b in range(a, len(tabs))]
-    pairs.sort(key=lambda ab: (-len(tabs[ab[0]]), -len(tabs[ab[1]]), ab))
-    print(f"constexpr int NT_PAIRS = {len(pairs)};")
-    print("constexpr signed char kNtPairA[NT_PAIRS] = {" + ", ".join(str(a) for a, b in pairs) + "};")
-    print("constexpr signed char kNtPairB[NT_PAIRS] = {" + ", ".join(str(b) for a, b in pairs) + "};")
+    # (device routine cvxw::coop_newton) the work items of the Hessian over the 14 basis matrices (T_I is handled in closed form): a pair (A, B)
+    # loops over A's entries e0..e1 with B's slots unrolled in registers (width 6 if B has at most six entries, else 14); the orientation with
+    # the smaller entries x width, the pairs of two 13-entry matrices split in two; heaviest first: lane l takes items l and NT_ITEMS - 1 - l
+    nb14 = len(tabs) - 1
+    items = []
+    for a in range(nb14):
+        for b in range(a, nb14):
+            na, nb = len(tabs[a]), len(tabs[b])
+            wid = lambda n: 6 if n <= 6 else 14
+            A, B = (a, b) if na * wid(nb) <= nb * wid(na) else (b, a)
+            nA = len(tabs[A])
+            if nA > 6 and len(tabs[B]) > 6:
+                items += [(A, B, 0, (nA + 1) // 2), (A, B, (nA + 1) // 2, nA)]
+            else:
+                items.append((A, B, 0, nA))
+    cost = lambda it: (it[3] - it[2]) * (6 if len(tabs[it[1]]) <= 6 else 14)
+    items.sort(key=lambda it: (-cost(it), it))
+    print(f"constexpr int NT_ITEMS = {len(items)}; // heaviest {cost(items[0])} slots, lane maximum {max(cost(items[l]) + (cost(items[len(items) - 1 - l]) if len(items) - 1 - l >= 64 else 0) for l in range(64))}")
+    for name, k in (("kNtItemA", 0), ("kNtItemB", 1), ("kNtItemE0", 2), ("kNtItemE1", 3)):
+        print(f"constexpr signed char {name}[NT_ITEMS] = {{" + ", ".join(str(it[k]) for it in items) + "};")

@@ -8,6 +8,7 @@
 __device__ long long g_nclk[8 * 512];
 #define CVXW_NCLK_INIT long long nclk_t = __builtin_readcyclecounter();
 #define CVXW_NCLK(i) do { if (lane == 0) { const long long t_ = __builtin_readcyclecounter(); g_nclk[blockIdx.x * 8 + (i)] += t_ - nclk_t; nclk_t = t_; } } while (0)
+#define CVXW_NO_KERNELS
 #include "problem_io.h"
 #include "solver_core.h"
 #include "ipm_core.h"
