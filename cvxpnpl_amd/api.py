@@ -6,6 +6,7 @@ arithmetic runs in the HIP library (include/cvxpnpl_amd.h) on the current torch 
 PyTorch is used for device memory and streams only.
 """
 import ctypes as C
+import threading
 import warnings
 from typing import List, Optional, Tuple
 
@@ -308,6 +309,81 @@ def _poses_of_single(res, Bt, Qt, verbose, certify_warning=True) -> List[Tuple[n
     return [(res.R[0].cpu().numpy(), res.t[0].cpu().numpy())]
 
 
+class _SingleCtx:
+    """Staging of one single-problem call (pnp / pnl / pnpl: the reference's unit of use and of timing, suite.py:75-85): ONE pinned host buffer
+    and ONE device buffer for the inputs [pts_2d | pts_3d | line_2d | line_3d | K], one of each for every output, so that a call is one
+    H2D copy, the solve, one D2H copy and one synchronisation -- no allocation, no pageable copy, no per-field read-back."""
+
+    N_OUT = 9 + 3 + 2 + 55  # R, t, cost | dobj, Z (doubles); then status, iters, work[2] as int32 in two more doubles
+
+    def __init__(self, device, n_p, n_l):
+        self.n_p, self.n_l = n_p, n_l
+        self.sizes = (2 * n_p, 3 * n_p, 4 * n_l, 6 * n_l, 9)
+        self.offs = np.cumsum((0,) + self.sizes)
+        n_in = int(self.offs[-1])
+        self.h_in = torch.empty(n_in, dtype=torch.float64).pin_memory()
+        self.h_np = self.h_in.numpy()
+        self.d_in = torch.empty(n_in, dtype=torch.float64, device=device)
+        self.d_out = torch.empty(self.N_OUT + 2, dtype=torch.float64, device=device)
+        self.h_out = torch.empty(self.N_OUT + 2, dtype=torch.float64).pin_memory()
+        self.o_np = self.h_out.numpy()
+        self.i_np = self.o_np[self.N_OUT:].view(np.int32)
+        base_in, base_out = self.d_in.data_ptr(), self.d_out.data_ptr()
+        pin = [C.c_void_p(base_in + 8 * int(o)) if sz else C.c_void_p(0) for o, sz in zip(self.offs[:-1], self.sizes)]
+        self.p2, self.p3, self.l2, self.l3, self.K = pin
+        o = lambda k: C.c_void_p(base_out + 8 * k)  # noqa: E731
+        self.R, self.t, self.cost, self.Z = o(0), o(9), o(12), o(14)
+        self.status, self.iters, self.work = o(self.N_OUT), C.c_void_p(base_out + 8 * self.N_OUT + 4), C.c_void_p(base_out + 8 * self.N_OUT + 8)
+
+
+_single_tls = threading.local()
+
+
+def _single_fast(p2, l2, p3, l3, Kn, eps, max_iters):
+    """One problem through the staging of _SingleCtx; the outputs as a BatchResult of host tensors (batch 1)."""
+    _require_gpu()
+    L = _lib.lib()
+    device = torch.device("cuda", torch.cuda.current_device())
+    n_p = 0 if p3 is None else p3.shape[1]
+    n_l = 0 if l3 is None else l3.shape[1]
+    cache = getattr(_single_tls, "ctx", None)
+    if cache is None:
+        cache = _single_tls.ctx = {}
+    key = (device.index, n_p, n_l)
+    ctx = cache.get(key)
+    if ctx is None:
+        if len(cache) > 64:
+            cache.clear()
+        ctx = cache[key] = _SingleCtx(device, n_p, n_l)
+    h, of = ctx.h_np, ctx.offs
+    if n_p:
+        h[of[0]:of[1]] = p2.reshape(-1)
+        h[of[1]:of[2]] = p3.reshape(-1)
+    if n_l:
+        h[of[2]:of[3]] = l2.reshape(-1)
+        h[of[3]:of[4]] = l3.reshape(-1)
+    h[of[4]:of[5]] = Kn.reshape(-1)
+    okey = (float(eps), int(max_iters))
+    opts = getattr(_single_tls, "opts", {}).get(okey)
+    if opts is None:
+        if not hasattr(_single_tls, "opts"):
+            _single_tls.opts = {}
+        opts = _single_tls.opts[okey] = _lib.default_opts(eps=float(eps), max_iters=int(max_iters), res_tol=0.0)
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device)
+        ctx.d_in.copy_(ctx.h_in, non_blocking=True)
+        rc = L.cvxpnpl_solve_batch(1, n_p, ctx.p2, ctx.p3, n_l, ctx.l2, ctx.l3, ctx.K, 0, C.byref(opts), ctx.R, ctx.t, ctx.status, ctx.iters, ctx.cost, ctx.Z,
+                                   ctx.work, C.c_void_p(stream.cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"cvxpnpl_solve_batch failed ({rc}): {_lib.last_error()}")
+        ctx.h_out.copy_(ctx.d_out, non_blocking=True)
+        stream.synchronize()
+    o, i = ctx.o_np, ctx.i_np
+    return BatchResult(R=torch.from_numpy(o[0:9].reshape(1, 3, 3).copy()), t=torch.from_numpy(o[9:12].reshape(1, 3).copy()),
+                       status=torch.from_numpy(i[0:1].copy()), iters=torch.from_numpy(i[1:2].copy()), cost=torch.from_numpy(o[12:14].reshape(1, 2).copy()),
+                       work=torch.from_numpy(i[2:4].reshape(1, 2).copy()), Z=torch.from_numpy(o[14:69].reshape(1, 55).copy()))
+
+
 def _single(pts_2d, line_2d, pts_3d, line_3d, K, eps, max_iters, verbose) -> List[Tuple[np.ndarray, np.ndarray]]:
     def b(x, tail):
         if x is None:
@@ -324,7 +400,13 @@ def _single(pts_2d, line_2d, pts_3d, line_3d, K, eps, max_iters, verbose) -> Lis
     # reference + SCS would hand back whatever 2 500 first-order iterations reached -- and a Z that has settled at rank > 1
     # (opts.stall_from = 300) stops as rank > 1.  Certified poses are unaffected; for non-tight problems the poses recovered
     # from Z (recover_multi) are those of the converged Z, not of SCS's iterate.  INTEGRATION.md section 3 says the same.
-    res = pnpl_batch(p2, l2, p3, l3, Kn, eps=eps, max_iters=max_iters, want_Z=True, res_tol=0.0)
+    n_corr = (0 if p3 is None else p3.shape[1]) + 2 * (0 if l3 is None else l3.shape[1])
+    paired = (p3 is None) == (p2 is None) and (l3 is None) == (l2 is None) and (p3 is None or p2.shape[1] == p3.shape[1]) and \
+        (l3 is None or l2.shape[1] == l3.shape[1])  # (anything else: the batch entry point raises the error the caller should see)
+    if paired and Kn.shape == (3, 3) and (p3 is not None or l3 is not None) and not use_blocked_assembly(n_corr, 1):
+        res = _single_fast(p2, l2, p3, l3, Kn, eps, max_iters)  # one H2D, the solve, one D2H (same entry point, same options)
+    else:
+        res = pnpl_batch(p2, l2, p3, l3, Kn, eps=eps, max_iters=max_iters, want_Z=True, res_tol=0.0)
     Bt = Qt = None
     if int(res.status[0]) == 1:
         Bt, Qt = _translation_map(p2, l2, p3, l3, Kn)

@@ -806,3 +806,24 @@ def test_solve_is_hipgraph_capturable_and_replayable(gpu):
             torch.cuda.synchronize()
             assert torch.equal(res.status, ref.status)
             assert torch.equal(res.R, ref.R) and torch.equal(res.t, ref.t)
+
+
+def test_single_problem_staging_equals_the_batch_entry_point(gpu):
+    """pnp / pnl / pnpl go through one pinned staging buffer each way (api._SingleCtx): bit-identical to the batch entry point on the same problem,
+    for every shape, repeated calls and interleaved shapes (the buffers are cached per shape)."""
+    from cvxpnpl_amd import api, synth
+
+    for rep in range(2):
+        for n_p, n_l, seed in ((6, 0, 1), (0, 6, 2), (5, 5, 3), (10, 0, 4), (4, 0, 5)):
+            d = synth.make_pnpl(3, n_p, n_l, 1.0, seed=seed)
+            for i in range(3):
+                p2 = d["pts_2d"][i:i + 1] if n_p else None
+                p3 = d["pts_3d"][i:i + 1] if n_p else None
+                l2 = d["line_2d"][i:i + 1] if n_l else None
+                l3 = d["line_3d"][i:i + 1] if n_l else None
+                a = api._single_fast(p2, l2, p3, l3, d["K"], 1e-9, 2500)
+                b = api.pnpl_batch(p2, l2, p3, l3, d["K"], want_Z=True, res_tol=0.0)
+                for k in ("R", "t", "status", "iters", "cost", "work", "Z"):
+                    assert np.array_equal(a[k].numpy(), b[k].cpu().numpy(), equal_nan=True), (n_p, n_l, i, k)
+    with pytest.raises(ValueError):
+        api.pnp(np.zeros((5, 2)), np.zeros((6, 3)), np.eye(3))
