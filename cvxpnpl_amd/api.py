@@ -318,7 +318,8 @@ class _SingleCtx:
 
     def __init__(self, device, n_p, n_l):
         self.n_p, self.n_l = n_p, n_l
-        self.sizes = (2 * n_p, 3 * n_p, 4 * n_l, 6 * n_l, 9)
+        # (n_p = -1: the cost seam -- [Q45 | B27] instead of correspondences and K)
+        self.sizes = (2 * n_p, 3 * n_p, 4 * n_l, 6 * n_l, 9) if n_p >= 0 else (45, 27, 0, 0, 0)
         self.offs = np.cumsum((0,) + self.sizes)
         n_in = int(self.offs[-1])
         self.h_in = torch.empty(n_in, dtype=torch.float64).pin_memory()
@@ -384,6 +385,40 @@ def _single_fast(p2, l2, p3, l3, Kn, eps, max_iters):
                        work=torch.from_numpy(i[2:4].reshape(1, 2).copy()), Z=torch.from_numpy(o[14:69].reshape(1, 55).copy()))
 
 
+def _single_cost_fast(Q45, B27, eps, max_iters, variant):
+    """The same staging for the cost seam (solve_relaxation / solve_relaxation_rc: one problem given as packed A^T A and B)."""
+    _require_gpu()
+    L = _lib.lib()
+    device = torch.device("cuda", torch.cuda.current_device())
+    cache = getattr(_single_tls, "ctx", None)
+    if cache is None:
+        cache = _single_tls.ctx = {}
+    key = (device.index, -1, 0)
+    ctx = cache.get(key)
+    if ctx is None:
+        ctx = cache[key] = _SingleCtx(device, -1, 0)
+    ctx.h_np[0:45] = Q45
+    ctx.h_np[45:72] = B27
+    if not hasattr(_single_tls, "opts"):
+        _single_tls.opts = {}
+    okey = (float(eps), int(max_iters), int(variant))
+    opts = _single_tls.opts.get(okey)
+    if opts is None:
+        opts = _single_tls.opts[okey] = _lib.default_opts(eps=float(eps), max_iters=int(max_iters), res_tol=0.0, variant=int(variant))
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device)
+        ctx.d_in.copy_(ctx.h_in, non_blocking=True)
+        rc = L.cvxpnpl_solve_cost_batch(1, ctx.p2, ctx.p3, C.byref(opts), ctx.R, ctx.t, ctx.status, ctx.iters, ctx.cost, ctx.Z, ctx.work, C.c_void_p(stream.cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"cvxpnpl_solve_cost_batch failed ({rc}): {_lib.last_error()}")
+        ctx.h_out.copy_(ctx.d_out, non_blocking=True)
+        stream.synchronize()
+    o, i = ctx.o_np, ctx.i_np
+    return BatchResult(R=torch.from_numpy(o[0:9].reshape(1, 3, 3).copy()), t=torch.from_numpy(o[9:12].reshape(1, 3).copy()),
+                       status=torch.from_numpy(i[0:1].copy()), iters=torch.from_numpy(i[1:2].copy()), cost=torch.from_numpy(o[12:14].reshape(1, 2).copy()),
+                       work=torch.from_numpy(i[2:4].reshape(1, 2).copy()), Z=torch.from_numpy(o[14:69].reshape(1, 55).copy()))
+
+
 def _single(pts_2d, line_2d, pts_3d, line_3d, K, eps, max_iters, verbose) -> List[Tuple[np.ndarray, np.ndarray]]:
     def b(x, tail):
         if x is None:
@@ -421,7 +456,7 @@ def solve_relaxation(A: np.ndarray, B: np.ndarray, eps: float = 1e-9, max_iters:
     A = np.asarray(A, dtype=np.float64)
     Bn = np.ascontiguousarray(B, dtype=np.float64).reshape(27)
     Q45 = np.ascontiguousarray(pack_cost(A.T @ A))
-    res = solve_cost_batch(Q45[None], Bn[None], eps=eps, max_iters=max_iters, want_Z=True, variant=variant, res_tol=0.0)
+    res = _single_cost_fast(Q45, Bn, eps, max_iters, variant)  # (= solve_cost_batch(Q45[None], Bn[None], ..., want_Z=True, res_tol=0.0) through one staging buffer each way)
     # the reference's rc variant returns its poses without the certificate check (rc.py:118-131)
     return _poses_of_single(res, Bn, Q45, verbose, certify_warning=(variant == _lib.VARIANT_FULL))
 

@@ -827,3 +827,19 @@ def test_single_problem_staging_equals_the_batch_entry_point(gpu):
                     assert np.array_equal(a[k].numpy(), b[k].cpu().numpy(), equal_nan=True), (n_p, n_l, i, k)
     with pytest.raises(ValueError):
         api.pnp(np.zeros((5, 2)), np.zeros((6, 3)), np.eye(3))
+
+
+def test_cost_seam_staging_equals_the_batch_entry_point(gpu):
+    """solve_relaxation / solve_relaxation_rc (the reference's private seam, one problem) through the staging buffers: bit-identical to
+    cvxpnpl_solve_cost_batch on the same cost, both constraint sets."""
+    from cvxpnpl_amd import api, synth
+
+    d = synth.make_pnpl(4, 8, 0, 1.0, seed=11)
+    Bt, Qt = api.assemble_batch(d["pts_2d"], None, d["pts_3d"], None, d["K"])
+    Bn, Qn = Bt.cpu().numpy(), Qt.cpu().numpy()
+    for variant in (0, 1):
+        for i in range(4):
+            a = api._single_cost_fast(Qn[i], Bn[i].reshape(27), 1e-9, 2500, variant)
+            b = api.solve_cost_batch(Qn[i:i + 1], Bn[i:i + 1].reshape(1, 27), want_Z=True, variant=variant, res_tol=0.0)
+            for k in ("R", "t", "status", "iters", "cost", "work", "Z"):
+                assert np.array_equal(a[k].numpy(), b[k].cpu().numpy(), equal_nan=True), (variant, i, k)
