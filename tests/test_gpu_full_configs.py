@@ -145,7 +145,9 @@ def test_four_point_schedule_equals_the_wave_layout(gpu, kw):  # noqa: F811
     assert np.isin(a["status"], (0, 1, 2, 4)).all() and (a["iters"] >= 1).all()
     both = (a["status"] == 0) & (b["status"] == 0)
     # (a budget that ends a few iterations after the first phase: WHEN the attempts are made decides what is certified by then -- measured 0.991)
-    # (round 5, alternating sweep ordering in the quad phase: 5 551 / 5 626 certified by iteration 28, 5 509 by both = 0.987 / 0.979)
+    # (round 5, alternating sweep ordering in the quad phase: 5 551 / 5 626 certified by iteration 28, 5 509 by both = 0.987 / 0.979: the short-budget
+    #  threshold went 0.985 -> 0.98.  At the DEFAULT budget the certified count did not fall: 50 000 four-point problems [49 981, 19] in round 4,
+    #  [49 989, 11] in rounds 5 and 6 -- profiles/r04 ... r06/bench_n4_50k.json, solver.status_hist)
     short = kw.get("max_iters", 2500) <= 32
     lo = 0.98 if short else 0.995
     assert (a["status"] == 0).sum() >= lo * (b["status"] == 0).sum() and both.sum() >= (lo - (0.01 if short else 0.005)) * (b["status"] == 0).sum(), ((a["status"] == 0).sum(), (b["status"] == 0).sum(), both.sum())
